@@ -1,0 +1,99 @@
+"""Deterministic input/weight recipes shared by ``tools/make_goldens.py`` (which
+feeds them to the imported reference) and by the tests (which feed the same
+tensors to the oracle and to the HIP path).  Keeping the recipe here means the
+committed fixtures only need to hold the reference's *outputs*.
+
+Everything is generated on CPU with an explicit ``torch.Generator`` so the
+stream does not depend on global RNG state.
+"""
+from __future__ import annotations
+
+import hashlib
+from typing import Dict, Iterable, Tuple
+
+import numpy as np
+import torch
+
+
+def _seed_for(tag: str, seed: int) -> int:
+    h = hashlib.sha256(f"{seed}:{tag}".encode()).digest()
+    return int.from_bytes(h[:4], "little")
+
+
+def tensor_for(tag: str, shape: Iterable[int], seed: int = 0, scale: float = 1.0, shift: float = 0.0,
+               dtype=torch.float32) -> torch.Tensor:
+    g = torch.Generator(device="cpu")
+    g.manual_seed(_seed_for(tag, seed))
+    return (torch.randn(*shape, generator=g, dtype=torch.float32) * scale + shift).to(dtype)
+
+
+def params_for(shapes: Dict[str, Tuple[int, ...]], seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Weights: N(0, 0.02) for matrices/conv kernels, N(0, 0.02) biases (so that
+    biases are exercised), N(1, 0.02) for LayerNorm / layer-scale weights."""
+    out = {}
+    for name, shape in shapes.items():
+        is_norm_w = (name.endswith("norm1.weight") or name.endswith("norm2.weight")
+                     or name.endswith("fc_norm.weight") or name == "norm.weight")
+        out[name] = tensor_for(name, shape, seed, scale=0.02, shift=1.0 if is_norm_w else 0.0)
+    return out
+
+
+def vit_param_shapes(embed_dim: int, depth: int, num_classes: int, in_chans: int = 3, tubelet: int = 2,
+                     patch: int = 16, mlp_ratio: int = 4, final_reduction: str = "fc_norm"):
+    """State-dict keys/shapes of the reference VisionTransformer with qkv_bias=True
+    (SURVEY.md section 8b), in the reference's registration order."""
+    D = embed_dim
+    s = {"patch_embed.proj.weight": (D, in_chans, tubelet, patch, patch), "patch_embed.proj.bias": (D,)}
+    for i in range(depth):
+        p = f"blocks.{i}."
+        s[p + "norm1.weight"] = (D,)
+        s[p + "norm1.bias"] = (D,)
+        s[p + "attn.q_bias"] = (D,)
+        s[p + "attn.v_bias"] = (D,)
+        s[p + "attn.qkv.weight"] = (3 * D, D)
+        s[p + "attn.proj.weight"] = (D, D)
+        s[p + "attn.proj.bias"] = (D,)
+        s[p + "norm2.weight"] = (D,)
+        s[p + "norm2.bias"] = (D,)
+        s[p + "mlp.fc1.weight"] = (mlp_ratio * D, D)
+        s[p + "mlp.fc1.bias"] = (mlp_ratio * D,)
+        s[p + "mlp.fc2.weight"] = (D, mlp_ratio * D)
+        s[p + "mlp.fc2.bias"] = (D,)
+    if final_reduction == "fc_norm":
+        s["fc_norm.weight"] = (D,)
+        s["fc_norm.bias"] = (D,)
+    else:
+        s["norm.weight"] = (D,)
+        s["norm.bias"] = (D,)
+    s["head.weight"] = (num_classes, D)
+    s["head.bias"] = (num_classes,)
+    return s
+
+
+def summarize(t: torch.Tensor, head: int = 256) -> Dict[str, np.ndarray]:
+    """Compact pin for a large tensor: fp64 sum, fp64 sum of squares and the
+    first ``head`` flattened elements."""
+    f = t.detach().double().flatten()
+    return {
+        "sum": np.array(f.sum().item()),
+        "sqsum": np.array((f * f).sum().item()),
+        "head": t.detach().flatten()[:head].clone().numpy(),
+    }
+
+
+def check_summary(t: torch.Tensor, npz, key: str, rtol: float, atol_scale: float = 1.0):
+    """Assert tensor ``t`` matches the stored summary ``key.*`` in ``npz``."""
+    f = t.detach().double().flatten()
+    head = torch.from_numpy(npz[key + ".head"]).double()
+    n = head.numel()
+    scale = max(head.abs().max().item(), 1e-30)
+    err = (f[:n] - head).abs().max().item() / scale
+    assert err <= rtol, f"{key}: head mismatch rel {err:.3e} > {rtol}"
+    sq = float(npz[key + ".sqsum"])
+    got = (f * f).sum().item()
+    assert abs(got - sq) <= 4 * rtol * max(sq, 1e-30) * atol_scale, f"{key}: sqsum {got} vs {sq}"
+
+
+# the tiny full-model configuration used by G3 (real head geometry d=64, K_patch % 64 == 0)
+TINY = dict(img_size=16, patch_size=8, embed_dim=128, depth=2, num_heads=2, all_frames=4, tubelet_size=2,
+            num_classes=2)

@@ -1,0 +1,364 @@
+#!/usr/bin/env python3
+"""Generate ``tests/golden/*.npz`` by running the REAL reference (imported from
+/root/reference, CPU, fp32/fp64) on the deterministic inputs of
+``tests/golden_recipe.py``.
+
+Runs only in the build container (the reference never travels to the GPU box).
+The fixtures hold data only: inputs are regenerated from the recipe, outputs
+are stored.  Nothing from the reference's source text is copied.
+
+Third-party modules the reference imports but this image lacks are satisfied
+as follows: ``timm.models.layers.{to_2tuple,trunc_normal_}`` are taken from the
+reference's own in-repo copies (run_inference_simple.py:40-105);
+``timm.models.layers.drop_path`` is never reached (drop_path_rate=0 in every
+fixture); ``register_model`` is the identity decorator; ``flash_attention_class``
+is never reached (use_flash_attn=False; it needs the CUDA flash-attn wheel).
+
+usage: python tools/make_goldens.py [--only g3]
+"""
+import argparse
+import hashlib
+import os
+import sys
+import types
+from functools import partial
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+OUT = os.path.join(ROOT, "tests", "golden")
+
+import golden_recipe as R  # noqa: E402
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    cv2 = types.ModuleType("cv2")
+    natsort = types.ModuleType("natsort")
+    natsort.natsorted = sorted
+    sys.modules["cv2"] = cv2
+    sys.modules["natsort"] = natsort
+    import run_inference_simple as ris
+
+    timm = types.ModuleType("timm")
+    models = types.ModuleType("timm.models")
+    layers = types.ModuleType("timm.models.layers")
+    registry = types.ModuleType("timm.models.registry")
+
+    def _no_drop_path(x, drop_prob=0.0, training=False):
+        assert not (training and drop_prob), "fixtures use drop_path_rate=0"
+        return x
+
+    layers.drop_path = _no_drop_path
+    layers.to_2tuple = ris.to_2tuple
+    layers.trunc_normal_ = ris.trunc_normal_
+    registry.register_model = lambda f: f
+    sys.modules.update({"timm": timm, "timm.models": models, "timm.models.layers": layers,
+                        "timm.models.registry": registry})
+    fa = types.ModuleType("flash_attention_class")
+
+    class _NoFlash(nn.Module):
+        def __init__(self, *a, **k):
+            raise RuntimeError("flash-attn is not available; fixtures use use_flash_attn=False")
+
+    fa.FlashAttention = _NoFlash
+    sys.modules["flash_attention_class"] = fa
+    import modeling_finetune as mf
+    import masking_generator as mg
+    return ris, mf, mg
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def load_params(module: nn.Module, P):
+    sd = module.state_dict()
+    assert set(sd.keys()) == set(P.keys()), (sorted(set(sd) ^ set(P)))
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(P[k].shape), k
+    module.load_state_dict({k: v.clone() for k, v in P.items()})
+
+
+# ----------------------------------------------------------------------------
+def g1(mf):
+    arrs = {}
+    for (n, d) in [(784, 384), (1568, 384), (1568, 768), (1568, 1024), (8, 128)]:
+        t = mf.get_sinusoid_encoding_table(n, d)
+        assert t.shape == (1, n, d) and t.dtype == torch.float32
+        arrs[f"sha256_{n}_{d}"] = np.frombuffer(hashlib.sha256(t.numpy().tobytes()).digest(), dtype=np.uint8)
+        rows = [r for r in (0, 1, 195, 196, 783, 1567) if r < n]
+        arrs[f"rows_{n}_{d}"] = t[0, rows].numpy()
+        arrs[f"rowidx_{n}_{d}"] = np.array(rows)
+    # patch-index bookkeeping: identity weights, voxel-coded input -> out[b,n,k] = code
+    pe = mf.PatchEmbed(img_size=32, patch_size=16, in_chans=3, embed_dim=1536, num_frames=4, tubelet_size=2)
+    with torch.no_grad():
+        pe.proj.weight.copy_(torch.eye(1536).reshape(1536, 3, 2, 16, 16))
+        pe.proj.bias.zero_()
+        x = torch.arange(2 * 3 * 4 * 32 * 32, dtype=torch.float32).reshape(2, 3, 4, 32, 32)
+        y = pe(x)
+    assert y.shape == (2, 8, 1536)
+    arrs["patch_codes"] = y.round().to(torch.int32).numpy()
+    assert (y - y.round()).abs().max() == 0
+    for (img, p, T, tub) in [(224, 16, 8, 2), (224, 16, 16, 2), (32, 16, 4, 2), (16, 8, 4, 2)]:
+        arrs[f"num_patches_{img}_{p}_{T}_{tub}"] = np.array(
+            mf.PatchEmbed(img_size=img, patch_size=p, embed_dim=8, num_frames=T, tubelet_size=tub).num_patches)
+    save("g1_bookkeeping", **arrs)
+
+
+def g2(mf):
+    torch.manual_seed(0)
+    arrs = {}
+    # PatchEmbed
+    pe = mf.PatchEmbed(img_size=32, patch_size=16, in_chans=3, embed_dim=64, num_frames=4, tubelet_size=2).double()
+    P = {"proj.weight": R.tensor_for("pe.w", (64, 3, 2, 16, 16), scale=0.02).double(),
+         "proj.bias": R.tensor_for("pe.b", (64,), scale=0.02).double()}
+    load_params(pe, P)
+    x = R.tensor_for("pe.x", (1, 3, 4, 32, 32)).double()
+    y = pe(x)
+    dy = R.tensor_for("pe.dy", tuple(y.shape)).double()
+    y.backward(dy)
+    arrs.update({"pe.y": y.detach().numpy(), "pe.dw": pe.proj.weight.grad.numpy(), "pe.db": pe.proj.bias.grad.numpy()})
+
+    # LayerNorm eps=1e-6
+    ln = nn.LayerNorm(128, eps=1e-6).double()
+    load_params(ln, {"weight": R.tensor_for("ln.w", (128,), scale=0.1, shift=1.0).double(),
+                     "bias": R.tensor_for("ln.b", (128,), scale=0.1).double()})
+    x = R.tensor_for("ln.x", (3, 50, 128), scale=2.0, shift=0.5).double().requires_grad_()
+    y = ln(x)
+    dy = R.tensor_for("ln.dy", tuple(y.shape)).double()
+    y.backward(dy)
+    arrs.update({"ln.y": y.detach().numpy(), "ln.dx": x.grad.numpy(), "ln.dw": ln.weight.grad.numpy(),
+                 "ln.db": ln.bias.grad.numpy()})
+
+    # Attention dim=128 heads=2 (d=64), N=100, non-zero q_bias / v_bias
+    att = mf.Attention(128, num_heads=2, qkv_bias=True, use_flash_attn=False).double()
+    PA = {"q_bias": R.tensor_for("att.qb", (128,), scale=0.1).double(),
+          "v_bias": R.tensor_for("att.vb", (128,), scale=0.1).double(),
+          "qkv.weight": R.tensor_for("att.qkv", (384, 128), scale=0.08).double(),
+          "proj.weight": R.tensor_for("att.pw", (128, 128), scale=0.08).double(),
+          "proj.bias": R.tensor_for("att.pb", (128,), scale=0.1).double()}
+    load_params(att, PA)
+    x = R.tensor_for("att.x", (2, 100, 128)).double().requires_grad_()
+    y = att(x)
+    dy = R.tensor_for("att.dy", tuple(y.shape)).double()
+    y.backward(dy)
+    arrs.update({"att.y": y.detach().numpy(), "att.dx": x.grad.numpy()})
+    for k, p in att.named_parameters():
+        arrs["att.d." + k] = p.grad.numpy()
+
+    # Mlp 128 -> 512 -> 128
+    m = mf.Mlp(128, 512).double()
+    PM = {"fc1.weight": R.tensor_for("mlp.w1", (512, 128), scale=0.08).double(),
+          "fc1.bias": R.tensor_for("mlp.b1", (512,), scale=0.1).double(),
+          "fc2.weight": R.tensor_for("mlp.w2", (128, 512), scale=0.08).double(),
+          "fc2.bias": R.tensor_for("mlp.b2", (128,), scale=0.1).double()}
+    load_params(m, PM)
+    x = R.tensor_for("mlp.x", (2, 100, 128)).double().requires_grad_()
+    y = m(x)
+    dy = R.tensor_for("mlp.dy", tuple(y.shape)).double()
+    y.backward(dy)
+    arrs.update({"mlp.y": y.detach().numpy(), "mlp.dx": x.grad.numpy()})
+    for k, p in m.named_parameters():
+        arrs["mlp.d." + k] = p.grad.numpy()
+
+    # Block dim=128 heads=2
+    blk = mf.Block(128, 2, mlp_ratio=4., qkv_bias=True, init_values=0., norm_layer=partial(nn.LayerNorm, eps=1e-6),
+                   use_flash_attn=False).double()
+    shapes = {k: tuple(v.shape) for k, v in blk.state_dict().items()}
+    PB = {k: R.tensor_for("blk." + k, s, scale=0.08, shift=1.0 if k.endswith(("norm1.weight", "norm2.weight")) else 0.0).double()
+          for k, s in shapes.items()}
+    load_params(blk, PB)
+    x = R.tensor_for("blk.x", (2, 100, 128)).double().requires_grad_()
+    y = blk(x)
+    dy = R.tensor_for("blk.dy", tuple(y.shape)).double()
+    y.backward(dy)
+    arrs.update({"blk.y": y.detach().numpy(), "blk.dx": x.grad.numpy()})
+    arrs["blk.keys"] = np.array(list(shapes.keys()))
+    for k, p in blk.named_parameters():
+        arrs["blk.d." + k] = p.grad.numpy()
+    # stored as fp32 (outputs were computed in fp64, so they are correctly-rounded fp32 pins)
+    arrs = {k: (v.astype(np.float32) if v.dtype == np.float64 else v) for k, v in arrs.items()}
+    save("g2_ops", **arrs)
+
+
+def build_tiny(mf, dtype=torch.float64):
+    c = R.TINY
+    model = mf.VisionTransformer(img_size=c["img_size"], patch_size=c["patch_size"], embed_dim=c["embed_dim"],
+                                 depth=c["depth"], num_heads=c["num_heads"], mlp_ratio=4, qkv_bias=True,
+                                 norm_layer=partial(nn.LayerNorm, eps=1e-6), all_frames=c["all_frames"],
+                                 tubelet_size=c["tubelet_size"], num_classes=c["num_classes"], init_scale=1.0,
+                                 drop_path_rate=0.0, use_flash_attn=False)
+    shapes = R.vit_param_shapes(c["embed_dim"], c["depth"], c["num_classes"], tubelet=c["tubelet_size"],
+                                patch=c["patch_size"])
+    assert list(model.state_dict().keys()) == list(shapes.keys()), "state-dict key order differs from recipe"
+    P = R.params_for(shapes, seed=3)
+    load_params(model, P)
+    return model.to(dtype), P
+
+
+def g3(mf):
+    """Tiny full model: fwd, CE loss, all grads, grad-norm, one AdamW step -- fp64 reference run."""
+    model, P = build_tiny(mf, torch.float64)
+    c = R.TINY
+    x = R.tensor_for("tiny.x", (2, 3, c["all_frames"], c["img_size"], c["img_size"]), seed=3).double()
+    labels = torch.tensor([0, 1])
+    model.train()
+    feats = model.forward_features(x)
+    logits = model.head(feats)
+    loss = nn.CrossEntropyLoss()(logits, labels)
+    loss.backward()
+    grads = {k: p.grad.clone() for k, p in model.named_parameters()}
+    # utils.get_grad_norm_ definition
+    total = torch.norm(torch.stack([torch.norm(g.detach(), 2.0) for g in grads.values()]), 2.0)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.05, betas=(0.9, 0.999))
+    opt.step()
+    arrs = {"features": feats.detach().numpy(), "logits": logits.detach().numpy(), "loss": np.array(loss.item()),
+            "grad_norm": np.array(total.item()), "keys": np.array(list(grads.keys()))}
+    for k, g in grads.items():
+        for kk, v in R.summarize(g.float()).items():
+            arrs[f"grad.{k}.{kk}"] = v
+    for k, p in model.named_parameters():
+        for kk, v in R.summarize(p.detach().float()).items():
+            arrs[f"after.{k}.{kk}"] = v
+    # second view: fp32 run of the same thing (what the reference computes by default)
+    model32, _ = build_tiny(mf, torch.float32)
+    with torch.no_grad():
+        arrs["logits_fp32"] = model32(x.float()).numpy()
+    arrs = {k: (v.astype(np.float32) if getattr(v, "dtype", None) == np.float64 and v.ndim > 0 else v)
+            for k, v in arrs.items()}
+    save("g3_tiny_model", **arrs)
+
+
+def g4(mf, ris):
+    """Real-shape logits: S8 B=2 (BASELINE config 1, via run_inference_simple's model) and B16 B=2.
+    Weights come from the reference's own seeded init (torch.manual_seed(0), init_scale=1.0);
+    per-tensor checksums let the tests prove a regenerated model has identical weights."""
+    arrs = {}
+    for tag, factory, frames in (("s8", mf.vit_small_patch16_224, 8), ("b16", mf.vit_base_patch16_224, 16)):
+        torch.manual_seed(0)
+        model = factory(num_classes=2, all_frames=frames, tubelet_size=2, final_reduction="fc_norm",
+                        use_flash_attn=False, init_scale=1.0, drop_path_rate=0.0)
+        model.eval()
+        # exercise biases too: re-randomise every 1-D parameter ~ N(0,0.02) (+1 for norm weights), in order
+        g = torch.Generator().manual_seed(1234)
+        with torch.no_grad():
+            for k, p in model.named_parameters():
+                if p.dim() == 1:
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.02 + (1.0 if "norm" in k and k.endswith("weight") else 0.0))
+        torch.manual_seed(1)
+        x = torch.randn(2, 3, frames, 224, 224)
+        with torch.no_grad():
+            feats = model.forward_features(x)
+            logits = model.head(feats)
+        arrs[f"{tag}.features"] = feats.numpy()
+        arrs[f"{tag}.logits"] = logits.numpy()
+        arrs[f"{tag}.nparams"] = np.array(sum(p.numel() for p in model.parameters()))
+        keys = list(model.state_dict().keys())
+        arrs[f"{tag}.keys"] = np.array(keys)
+        arrs[f"{tag}.wsum"] = np.array([model.state_dict()[k].double().sum().item() for k in keys])
+        arrs[f"{tag}.wabs"] = np.array([model.state_dict()[k].double().abs().sum().item() for k in keys])
+        if tag == "s8":
+            # the same weights through run_inference_simple's self-contained model (BASELINE config 1);
+            # it bakes a softmax into forward (run_inference_simple.py:378-382)
+            m2 = ris.VisionTransformerInfer(img_size=224, patch_size=16, embed_dim=384, depth=12, num_heads=6,
+                                            mlp_ratio=4, qkv_bias=True, num_classes=2, all_frames=frames,
+                                            tubelet_size=2, final_reduction="fc_norm", use_flash_attn=False,
+                                            norm_layer=partial(nn.LayerNorm, eps=1e-6)) \
+                if hasattr(ris, "VisionTransformerInfer") else None
+            if m2 is not None:
+                missing = m2.load_state_dict(model.state_dict(), strict=False)
+                m2.eval()
+                with torch.no_grad():
+                    arrs["s8.infer_probs"] = m2(x).numpy()
+                arrs["s8.infer_missing"] = np.array([str(missing)])
+    save("g4_real_shape", **arrs)
+
+
+def g5():
+    sys.path.insert(0, REF)
+    # utils.py imports tensorboardX etc.; restate-free approach: exec only the function's module deps are heavy,
+    # so import optim_factory/utils pieces via importlib with stubs
+    for name in ("tensorboardX",):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.SummaryWriter = object
+            sys.modules[name] = m
+    timm_utils = types.ModuleType("timm.utils")
+    timm_utils.get_state_dict = lambda *a, **k: None
+    timm_utils.accuracy = None
+    timm_utils.ModelEma = object
+    sys.modules["timm.utils"] = timm_utils
+    try:
+        import utils as ref_utils
+    except Exception as e:  # pragma: no cover
+        print("could not import reference utils:", e)
+        raise
+    sched = ref_utils.cosine_scheduler(1e-3, 1e-6, epochs=3, niter_per_ep=10, warmup_epochs=1)
+    sched2 = ref_utils.cosine_scheduler(5e-4, 1e-6, epochs=2, niter_per_ep=7, warmup_epochs=0)
+    sched3 = ref_utils.cosine_scheduler(1e-3, 1e-5, epochs=4, niter_per_ep=5, warmup_epochs=1, start_warmup_value=1e-6,
+                                        warmup_steps=3)
+    g = [torch.full((3, 4), 0.5), torch.arange(5, dtype=torch.float32)]
+    params = [nn.Parameter(torch.zeros_like(t)) for t in g]
+    for p, t in zip(params, g):
+        p.grad = t
+    gn = ref_utils.get_grad_norm_(params).item()
+    arrs = {"cos_1e-3_1e-6_3_10_1": sched, "cos_5e-4_1e-6_2_7_0": sched2, "cos_warmup_steps": sched3,
+            "grad_norm_known": np.array(gn)}
+    # layer-decay map: optim_factory imports a timm optimizer zoo -> stub those modules
+    for sub in ("adafactor", "adahessian", "adamp", "lookahead", "nadam", "novograd", "nvnovograd", "radam",
+                "rmsprop_tf", "sgdp"):
+        m = types.ModuleType("timm.optim." + sub)
+        for cls in ("Adafactor", "Adahessian", "AdamP", "Lookahead", "Nadam", "NovoGrad", "NvNovoGrad", "RAdam",
+                    "RMSpropTF", "SGDP"):
+            setattr(m, cls, object)
+        sys.modules["timm.optim." + sub] = m
+    sys.modules["timm.optim"] = types.ModuleType("timm.optim")
+    import optim_factory as of
+    names = list(R.vit_param_shapes(128, 12, 2).keys()) + ["pos_embed", "cls_token", "mask_token", "rel_pos_bias.x"]
+    arrs["layer_names"] = np.array(names)
+    arrs["layer_ids"] = np.array([of.get_num_layer_for_vit(n, 14) for n in names])
+    num_layers = 12
+    ld = 0.75
+    arrs["layer_scales_0.75_12"] = np.array([ld ** (num_layers + 1 - i) for i in range(num_layers + 2)])
+    save("g5_schedules", **arrs)
+
+
+def g6(mg):
+    arrs = {}
+    np.random.seed(0)
+    gen = mg.TubeMaskingGenerator((8, 14, 14), 0.75)
+    m = gen()
+    arrs["mask_8_14_14_075"] = m.astype(np.uint8)
+    arrs["total_masks"] = np.array(gen.total_masks)
+    arrs["per_frame"] = np.array(gen.num_masks_per_frame)
+    gen2 = mg.TubeMaskingGenerator((8, 14, 14), 0.9)
+    arrs["per_frame_09"] = np.array(gen2.num_masks_per_frame)
+    save("g6_tube_mask", **arrs)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    torch.set_num_threads(8)
+    ris, mf, mg = import_reference()
+    jobs = {"g1": lambda: g1(mf), "g2": lambda: g2(mf), "g3": lambda: g3(mf), "g4": lambda: g4(mf, ris),
+            "g5": g5, "g6": lambda: g6(mg)}
+    for k, fn in jobs.items():
+        if a.only and a.only != k:
+            continue
+        print("==", k)
+        fn()
+
+
+if __name__ == "__main__":
+    main()
