@@ -1,0 +1,151 @@
+/*
+ * tad_mi355x.h -- C ABI of libtad_mi355x.so: the MI355X (gfx950) kernels behind
+ * simple-tad's Video-ViT forward/backward path.
+ *
+ * The reference (tue-mps/simple-tad) has no FFI of its own: its hot path is the
+ * Python nn.Module surface of modeling_finetune.py, whose arithmetic runs inside
+ * third-party wheels (ATen / cuDNN / cuBLAS / flash-attn).  Each entry point below
+ * names the reference call site whose native arithmetic it replaces.  The nearest
+ * existing analogue of a C-level boundary in the reference is
+ *   flash_attn_varlen_qkvpacked_func(qkv, cu_seqlens, max_s, dropout_p, softmax_scale, causal)
+ * (flash_attention_class.py:47-50).
+ *
+ * Conventions (all entry points):
+ *   - plain C: device pointers + explicit sizes; no torch / C++ types.
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream).
+ *   - return 0 on success, a negative TAD_E* code otherwise; never throw; the text of
+ *     the last error on the calling thread is available from tad_last_error_string().
+ *   - never allocate device memory, never synchronise the device, re-entrant per stream.
+ *     Scratch memory is passed in by the caller; sizes come from the *_workspace_bytes()
+ *     queries.
+ *   - "bf16" = bfloat16 stored as uint16_t; "f32" = IEEE float.
+ *   - row-major everywhere; leading dimension == number of columns unless stated.
+ */
+#ifndef TAD_MI355X_H
+#define TAD_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TAD_ABI_VERSION 1
+
+enum tad_status {
+  TAD_OK = 0,
+  TAD_EINVAL = -1,   /* bad argument / unsupported shape */
+  TAD_ELAUNCH = -2,  /* hipLaunch / runtime error         */
+  TAD_ENOSPACE = -3  /* workspace too small               */
+};
+
+enum tad_dtype { TAD_F32 = 0, TAD_BF16 = 1 };
+
+/* Linear-layer epilogues (tad_linear_fwd). */
+enum tad_epilogue {
+  TAD_EPI_BIAS = 0,          /* y = x W^T + b                                  (F.linear)            */
+  TAD_EPI_BIAS_GELU = 1,     /* y = gelu_erf(x W^T + b); optional pre-activation copy (Mlp.fc1+act)  */
+  TAD_EPI_BIAS_RESIDUAL = 2  /* y = res + rowscale[m/rows_per_scale] * gamma[n] * (x W^T + b)       */
+};
+
+typedef void* tad_stream_t;
+
+int tad_abi_version(void);
+const char* tad_last_error_string(void);
+
+/* ---- weight preparation -------------------------------------------------------------
+ * fp32 master weights stay owned by the caller (torch nn.Parameter); the kernels consume
+ * bf16 copies: W [N,K] for forward, W^T [K,N] for the input-gradient GEMM. */
+int tad_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, tad_stream_t stream);
+int tad_transpose_cast_f32_bf16(const float* src /*[R,C]*/, uint16_t* dst /*[C,R]*/, int R, int C,
+                                tad_stream_t stream);
+
+/* ---- PatchEmbed: nn.Conv3d(3,D,k=s=(tub,p,p)) + flatten(2).transpose(1,2)
+ *      (modeling_finetune.py:181-183,190) fused with "+ pos_embed" (:312-313).
+ * x [B,C,T,H,W] f32 contiguous.  cols [B*N, C*tub*p*p] bf16 is the tubelet patch matrix
+ * (token n = t'*H'*W' + h'*W' + w', k = ((c*tub+kt)*p+kh)*p+kw) -- kept for backward.
+ * w_bf16 [D,K], bias [D] f32 (nullable), pos [N,D] f32 (nullable), out [B*N,D] f32. */
+int tad_im2col_tubelets(const float* x, uint16_t* cols, int B, int C, int T, int H, int W, int tubelet,
+                        int patch, tad_stream_t stream);
+int tad_patch_embed_fwd(const float* x, const uint16_t* w_bf16, const float* bias, const float* pos,
+                        float* out, uint16_t* cols, int B, int C, int T, int H, int W, int tubelet,
+                        int patch, int D, tad_stream_t stream);
+/* dW [D,K] f32 (overwritten), db [D] f32 (overwritten, nullable) from dy [B*N,D] bf16 and cols. */
+size_t tad_patch_embed_bwd_workspace_bytes(int64_t M, int D, int K);
+int tad_patch_embed_bwd(const uint16_t* dy_bf16, const uint16_t* cols, float* dW, float* db, void* ws,
+                        size_t ws_bytes, int64_t M, int D, int K, tad_stream_t stream);
+
+/* ---- nn.LayerNorm(D, eps) (modeling_finetune.py:143,149,270; eps=1e-6 at :342) -------
+ * x [rows,D] f32; y [rows,D] in y_dtype; mean/rstd [rows] f32 saved for backward (nullable). */
+int tad_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_dtype,
+                      float* mean, float* rstd, int64_t rows, int D, float eps, tad_stream_t stream);
+/* dx = (dres ? dres : 0) + LN'(dy).  Optional outputs: dx_bf16 (copy of dx), colsum_dx [D]
+ * (sum over rows of dx: the bias gradient of the Linear that produced x's residual branch).
+ * dgamma/dbeta [D] are overwritten.  ws: tad_layernorm_bwd_workspace_bytes(rows, D). */
+size_t tad_layernorm_bwd_workspace_bytes(int64_t rows, int D);
+int tad_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* mean,
+                      const float* rstd, const float* dres, float* dx, uint16_t* dx_bf16, float* dgamma,
+                      float* dbeta, float* colsum_dx, void* ws, size_t ws_bytes, int64_t rows, int D,
+                      tad_stream_t stream);
+
+/* ---- Linear: F.linear(x, W, b) with fused epilogues ---------------------------------
+ * replaces qkv (modeling_finetune.py:88-92), proj (:104), fc1+GELU (:48-49), fc2 (:52) and the
+ * residual adds of Block.forward (:161-162, incl. gamma_1/2 and per-sample drop-path scale).
+ * x [M,K] bf16, w [N,K] bf16, bias [N] f32 (nullable), y [M,N] y_dtype.
+ * preact [M,N] bf16 (nullable): x W^T + b before GELU (saved for backward).
+ * residual [M,N] f32, gamma [N] f32 (nullable), rowscale f32 [ceil(M/rows_per_scale)] (nullable). */
+int tad_linear_fwd(const uint16_t* x, const uint16_t* w, const float* bias, void* y, int y_dtype,
+                   int epilogue, uint16_t* preact, const float* residual, const float* gamma,
+                   const float* rowscale, int rows_per_scale, int64_t M, int N, int K,
+                   tad_stream_t stream);
+/* Input gradient: dx [M,K] = (dy [M,N] @ W)  using wT [K,N] bf16.
+ * If gelu_preact [M,K] is given, dx *= gelu'(preact) (backward through the GELU that fed this Linear).
+ * colscale [N] / rowscale are applied to dy on the fly is NOT supported; scale dy beforehand. */
+int tad_linear_bwd_input(const uint16_t* dy, const uint16_t* wT, void* dx, int dx_dtype,
+                         const uint16_t* gelu_preact, int64_t M, int N, int K, tad_stream_t stream);
+/* Weight gradient: dW [N,K] f32 = dy^T [N,M] @ x [M,K]; db [N] f32 = column sums of dy (nullable).
+ * Outputs are overwritten (accumulate==0) or added to (accumulate!=0). */
+size_t tad_linear_bwd_weight_workspace_bytes(int64_t M, int N, int K);
+int tad_linear_bwd_weight(const uint16_t* dy, const uint16_t* x, float* dW, float* db, int accumulate,
+                          void* ws, size_t ws_bytes, int64_t M, int N, int K, tad_stream_t stream);
+
+/* ---- Space-time attention: softmax(q k^T * scale) v, non-causal, no mask --------------
+ * replaces Attention._naive_attn's q@k^T/softmax/attn@v (modeling_finetune.py:96-103) and
+ * FlashAttention.forward -> flash_attn_varlen_qkvpacked_func (flash_attention_class.py:47-50)
+ * with equal-length sequences (cu_seqlens = arange(0,(B+1)N,N)).
+ * qkv [B,N,3,H,d] bf16 packed (the qkv Linear's output, column order [3][H][d]); d must be 64.
+ * out [B,N,H,d] in out_dtype; lse [B,H,N] f32 = log(sum_j exp(scale * q.k_j)) (natural log). */
+int tad_attn_fwd(const uint16_t* qkv, void* out, int out_dtype, float* lse, int B, int N, int H, int d,
+                 float scale, tad_stream_t stream);
+/* dqkv [B,N,3,H,d] bf16 (fully overwritten).  delta [B,H,N] f32 scratch (rowsum(dout*out)). */
+int tad_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* lse,
+                 uint16_t* dqkv, float* delta, int B, int N, int H, int d, float scale,
+                 tad_stream_t stream);
+
+/* ---- token mean-pool x.mean(1) (modeling_finetune.py:325-326) -------------------------
+ * x [B,N,D] f32 -> y [B,D] f32.  ws: B*TAD_POOL_SPLIT*D floats. */
+#define TAD_POOL_SPLIT 8
+int tad_meanpool_fwd(const float* x, float* y, float* ws, int B, int N, int D, tad_stream_t stream);
+/* dx[b,n,:] = dy[b,:]/N  (f32, plus optional bf16 copy) */
+int tad_meanpool_bwd(const float* dy, float* dx, uint16_t* dx_bf16, int B, int N, int D,
+                     tad_stream_t stream);
+
+/* ---- small helpers used by the training step ------------------------------------------
+ * column sums of a bf16 [M,N] matrix into f32 [N] (bias gradients: q_bias/v_bias/fc1.bias). */
+size_t tad_colsum_workspace_bytes(int64_t M, int N);
+int tad_colsum_bf16(const uint16_t* a, float* out, int accumulate, void* ws, size_t ws_bytes, int64_t M,
+                    int N, tad_stream_t stream);
+/* y_bf16 = bf16(rowscale[m/rows_per_scale] * gamma[n] * x_f32)  (backward of the residual-branch scale) */
+int tad_scale_cast_bf16(const float* x, uint16_t* y, const float* gamma, const float* rowscale,
+                        int rows_per_scale, int64_t M, int N, tad_stream_t stream);
+/* sum of squares of an f32 vector, accumulated into *out (f32, device) -- get_grad_norm_ (utils.py:415-427) */
+int tad_sumsq_f32(const float* x, int64_t n, float* out, tad_stream_t stream);
+
+/* ---- device info ------------------------------------------------------------------------ */
+int tad_device_info(int* cu_count, int* clock_khz, int* lds_bytes_per_cu, char* name, int name_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TAD_MI355X_H */

@@ -1,0 +1,83 @@
+"""ctypes binding of libtad_mi355x.so (the C ABI declared in include/tad_mi355x.h).
+
+The product path has no CPU or PyTorch fallback: if the shared library is missing
+or a symbol cannot be resolved, loading raises and every op fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtad_mi355x.so")
+
+_vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/tad_mi355x.h one-to-one
+SIGNATURES = {
+    "tad_abi_version": (_i, []),
+    "tad_last_error_string": (C.c_char_p, []),
+    "tad_cast_f32_bf16": (_i, [_vp, _vp, _i64, _vp]),
+    "tad_transpose_cast_f32_bf16": (_i, [_vp, _vp, _i, _i, _vp]),
+    "tad_im2col_tubelets": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "tad_patch_embed_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "tad_patch_embed_bwd_workspace_bytes": (_sz, [_i64, _i, _i]),
+    "tad_patch_embed_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i64, _i, _i, _vp]),
+    "tad_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i64, _i, _f, _vp]),
+    "tad_layernorm_bwd_workspace_bytes": (_sz, [_i64, _i]),
+    "tad_layernorm_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i64, _i, _vp]),
+    "tad_linear_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp]),
+    "tad_linear_bwd_input": (_i, [_vp, _vp, _vp, _i, _vp, _i64, _i, _i, _vp]),
+    "tad_linear_bwd_weight_workspace_bytes": (_sz, [_i64, _i, _i]),
+    "tad_linear_bwd_weight": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _sz, _i64, _i, _i, _vp]),
+    "tad_attn_fwd": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _vp]),
+    "tad_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "tad_meanpool_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "tad_meanpool_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "tad_colsum_workspace_bytes": (_sz, [_i64, _i]),
+    "tad_colsum_bf16": (_i, [_vp, _vp, _i, _vp, _sz, _i64, _i, _vp]),
+    "tad_scale_cast_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp]),
+    "tad_sumsq_f32": (_i, [_vp, _i64, _vp, _vp]),
+    "tad_device_info": (_i, [C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.c_char_p, _i]),
+}
+
+TAD_F32, TAD_BF16 = 0, 1
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL = 0, 1, 2
+ABI_VERSION = 1
+POOL_SPLIT = 8
+
+_lib = None
+
+
+class TadError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load (once) and return the shared library; raise if it is absent or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TadError(
+            f"{LIB_PATH} not found: the HIP extension has not been built. Run `python -m simple_tad_amd.build` "
+            "(or __graft_entry__.build()). There is no CPU fallback for the MI355X path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # pragma: no cover
+            raise TadError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.tad_abi_version()
+    if v != ABI_VERSION:
+        raise TadError(f"ABI mismatch: library reports {v}, binding expects {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().tad_last_error_string()
+        raise TadError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,362 @@
+// Fused space-time attention backward (recompute, no N x N tensor), head_dim 64, gfx950.
+//
+// Three kernels, all deterministic (no atomics):
+//   1. attn_delta_kernel : delta[b,h,q] = sum_d dO[q,d] * O[q,d]
+//   2. attn_bwd_dq_kernel: one workgroup = 128 query rows, loops over 64-key tiles (structure of the forward kernel):
+//        S^T = K Q^T, dP^T = V dO^T (query on the lane -> lse/delta are per-lane scalars),
+//        dS^T = P^T o (dP^T - delta), dQ^T += K^T dS^T (dS^T accumulator registers are the MFMA B operand).
+//   3. attn_bwd_dkv_kernel: one workgroup = 128 keys (32 per wave, K/V fragments pinned in registers), loops over
+//        64-row query tiles: S = Q K^T and dP = dO V^T with the key on the lane and (-lse, -delta) preloaded as the
+//        initial accumulators, then dV^T += dO^T P and dK^T += Q^T dS with P / dS taken straight from the
+//        accumulator registers.
+// Summing dQ across key blocks would need ~1 GB of f32 atomics per layer at N=1568 (0.8 ms at the chip's 1.3 TB/s
+// atomic rate, more than the whole MFMA work), so dQ gets its own pass that recomputes S and dP (7 instead of 5
+// MFMA products, but no cross-workgroup reduction and bitwise-reproducible results).
+//
+// Tiles that are read both by rows (ds_read_b128) and transposed (ds_read_b64_tr_b16) use one LDS image with a
+// swizzle that is conflict-free for both (found by tools/lds_bank_sim.py).
+#include "common.h"
+
+namespace tad {
+
+constexpr int BHD = 64;
+constexpr float LOG2E = 1.44269504088896340736f;
+
+// 16-byte chunk swizzle for 128-byte rows, conflict-free for row reads (32 consecutive rows, chunk 2ks+h) and for
+// transposed reads (4 consecutive rows x 64 B)
+__device__ __forceinline__ int sw_dual(int row) {
+  return ((row >> 1) & 1) | (((row >> 2) & 1) << 1) | ((((row >> 1) ^ (row >> 3)) & 1) << 2);
+}
+
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+
+// transposed fragment: lane (x = lane&31 within a 32-wide column tile, h = lane>>5) gets, for j = 0..7, element
+// tile[rbase + 8*(j>>2) + 4*h + (j&3)][col0 + x]   (the k-order of an accumulator tile used as the other operand)
+__device__ __forceinline__ bf16x8 tr_frag_dual(const char* tile, int rbase, int col0, int lane) {
+  const int G = lane >> 4, li = lane & 15;
+  const int r0 = rbase + 4 * (G >> 1) + (li >> 2), r1 = r0 + 8;
+  const int col = col0 + 16 * (G & 1) + 4 * (li & 3);
+  const int ch = col >> 3, sub = (col & 7) * 2;
+  const char* a0 = tile + r0 * 128 + ((ch ^ sw_dual(r0)) << 4) + sub;
+  const char* a1 = tile + r1 * 128 + ((ch ^ sw_dual(r1)) << 4) + sub;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(a0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(a1));
+  const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+// row fragment: lane (row = lane&31, h = lane>>5) gets tile[row0 + row][16ks + 8h .. +7]
+__device__ __forceinline__ bf16x8 row_frag_dual(const char* tile, int row, int ks, int h5) {
+  return *reinterpret_cast<const bf16x8*>(tile + row * 128 + (((2 * ks + h5) ^ sw_dual(row)) << 4));
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f32x16& a, int s2) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (__bf16)a[8 * s2 + j];
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------ delta
+__global__ void attn_delta_kernel(const uint16_t* __restrict__ o, const uint16_t* __restrict__ dout, float* __restrict__ delta,
+                                  int B, int N, int H) {
+  // one 8-lane group per (b, q, h) row of 64 elements
+  const int64_t rows = (int64_t)B * N * H;
+  const int64_t gid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+  const int64_t row = gid >> 3;
+  const int sub = (int)(gid & 7);
+  float s = 0.f;
+  if (row < rows) {
+    const uint4 a = *reinterpret_cast<const uint4*>(o + row * BHD + sub * 8);
+    const uint4 g = *reinterpret_cast<const uint4*>(dout + row * BHD + sub * 8);
+    const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, gw[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      s += __uint_as_float(aw[i] << 16) * __uint_as_float(gw[i] << 16);
+      s += __uint_as_float(aw[i] & 0xffff0000u) * __uint_as_float(gw[i] & 0xffff0000u);
+    }
+  }
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  s += __shfl_xor(s, 4, 64);
+  if (row < rows && sub == 0) {
+    // row = (b*N + q)*H + h  ->  delta[b][h][q]
+    const int h = (int)(row % H);
+    const int64_t bq = row / H;
+    const int q = (int)(bq % N);
+    const int64_t b = bq / N;
+    delta[(b * H + h) * N + q] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ dQ
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
+                                                          const float* __restrict__ lse, const float* __restrict__ delta,
+                                                          uint16_t* __restrict__ dqkv, int N, int H, float scale) {
+  constexpr int TILE_BYTES = 64 * 128;
+  __shared__ __attribute__((aligned(1024))) char lds[2 * 2 * TILE_BYTES];  // [buf][K|V]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int ql = lane & 31, h5 = lane >> 5;
+  const int64_t tok = (int64_t)3 * H * BHD;
+  const uint16_t* base = qkv + (int64_t)b * N * tok + head * BHD;
+  const uint16_t* kbase = base + (int64_t)H * BHD;
+  const uint16_t* vbase = base + (int64_t)2 * H * BHD;
+  const float c = scale * LOG2E;
+
+  int qrow = q0 + ql;
+  const bool qvalid = qrow < N;
+  if (!qvalid) qrow = N - 1;
+  bf16x8 qf[4], dof[4];
+  {
+    const uint16_t* qp = base + (int64_t)qrow * tok + 8 * h5;
+    const uint16_t* dp = dout + (((int64_t)b * N + qrow) * H + head) * BHD + 8 * h5;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
+      dof[ks] = *reinterpret_cast<const bf16x8*>(dp + 16 * ks);
+    }
+  }
+  const float lse2 = lse[((int64_t)b * H + head) * N + qrow] * LOG2E;
+  const float dlt = delta[((int64_t)b * H + head) * N + qrow];
+
+  const int skey = tid >> 3, schunk = tid & 7;
+  uint4 kreg[2], vreg[2];
+  auto load_tile = [&](int kv0) {
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      int key = kv0 + skey + 32 * ps;
+      if (key > N - 1) key = N - 1;
+      kreg[ps] = *reinterpret_cast<const uint4*>(kbase + (int64_t)key * tok + schunk * 8);
+      vreg[ps] = *reinterpret_cast<const uint4*>(vbase + (int64_t)key * tok + schunk * 8);
+    }
+  };
+  auto write_tile = [&](int buf) {
+    char* kl = lds + buf * 2 * TILE_BYTES;
+    char* vl = kl + TILE_BYTES;
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int key = skey + 32 * ps;
+      *reinterpret_cast<uint4*>(kl + key * 128 + ((schunk ^ sw_dual(key)) << 4)) = kreg[ps];
+      *reinterpret_cast<uint4*>(vl + key * 128 + ((schunk ^ sw_dual(key)) << 4)) = vreg[ps];
+    }
+  };
+
+  f32x16 dq[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+
+  const int nt = (N + 63) / 64;
+  load_tile(0);
+  write_tile(0);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int kv0 = t * 64;
+    if (t + 1 < nt) load_tile(kv0 + 64);
+    const char* kl = lds + (t & 1) * 2 * TILE_BYTES;
+    const char* vl = kl + TILE_BYTES;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = -dlt; }
+      const int key = kt * 32 + ql;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_dual(kl, key, ks, h5), qf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_dual(vl, key, ks, h5), dof[ks], dp, 0, 0, 0);
+      }
+      // dS^T = P^T o (dP^T - delta); keys >= N contribute nothing
+      f32x16 ds;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kg = kv0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h5;
+        const float pv = (kg < N) ? fast_exp2(s[r] * c - lse2) : 0.f;
+        ds[r] = pv * dp[r];
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 dsf = pack8(ds, s2);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_dual(kl, kt * 32 + 16 * s2, dt * 32, lane), dsf, dq[dt], 0, 0, 0);
+      }
+    }
+    if (t + 1 < nt) write_tile((t + 1) & 1);
+    __syncthreads();
+  }
+
+  if (qvalid) {
+    uint16_t* op = dqkv + ((int64_t)b * N + qrow) * tok + head * BHD;  // q slot (index 0 of the "3" axis)
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int d = dt * 32 + 8 * r4 + 4 * h5;
+        uint2 pk;
+        pk.x = pack_bf16x2(dq[dt][4 * r4 + 0] * scale, dq[dt][4 * r4 + 1] * scale);
+        pk.y = pack_bf16x2(dq[dt][4 * r4 + 2] * scale, dq[dt][4 * r4 + 3] * scale);
+        *reinterpret_cast<uint2*>(op + d) = pk;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ dK, dV
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
+                                                           const float* __restrict__ lse, const float* __restrict__ delta,
+                                                           uint16_t* __restrict__ dqkv, int N, int H, float scale) {
+  constexpr int TILE_BYTES = 64 * 128;
+  constexpr int STAGE = 2 * TILE_BYTES + 512;  // Q tile, dO tile, 64 x (-lse/c), 64 x (-delta)
+  __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int key0 = blockIdx.x * 128 + wave * 32;
+  const int kl_ = lane & 31, h5 = lane >> 5;
+  const int64_t tok = (int64_t)3 * H * BHD;
+  const uint16_t* base = qkv + (int64_t)b * N * tok + head * BHD;
+  const uint16_t* kbase = base + (int64_t)H * BHD;
+  const uint16_t* vbase = base + (int64_t)2 * H * BHD;
+  const uint16_t* dobase = dout + ((int64_t)b * N * H + head) * BHD;  // row q at + q*H*64
+  const float* lsebase = lse + ((int64_t)b * H + head) * N;
+  const float* dltbase = delta + ((int64_t)b * H + head) * N;
+  const float c = scale * LOG2E;
+  const float inv_c = 1.f / c;
+
+  int krow = key0 + kl_;
+  const bool kvalid = krow < N;
+  if (!kvalid) krow = N - 1;
+  bf16x8 kfr[4], vfr[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    kfr[ks] = *reinterpret_cast<const bf16x8*>(kbase + (int64_t)krow * tok + 16 * ks + 8 * h5);
+    vfr[ks] = *reinterpret_cast<const bf16x8*>(vbase + (int64_t)krow * tok + 16 * ks + 8 * h5);
+  }
+
+  const int srow = tid >> 3, schunk = tid & 7;
+  uint4 qreg[2], doreg[2];
+  float sreg = 0.f;  // tid < 64: -lse*log2e/c of row tid ; 64 <= tid < 128: -delta of row tid-64
+  auto load_tile = [&](int q0) {
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      int q = q0 + srow + 32 * ps;
+      if (q > N - 1) q = N - 1;
+      qreg[ps] = *reinterpret_cast<const uint4*>(base + (int64_t)q * tok + schunk * 8);
+      doreg[ps] = *reinterpret_cast<const uint4*>(dobase + (int64_t)q * H * BHD + schunk * 8);
+    }
+    if (tid < 64) {
+      const int q = q0 + tid;
+      sreg = (q < N) ? -lsebase[q] * LOG2E * inv_c : -3.0e30f;  // rows >= N: exp2(c*(s-3e30)) = 0
+    } else if (tid < 128) {
+      const int q = q0 + tid - 64;
+      sreg = (q < N) ? -dltbase[q] : 0.f;
+    }
+  };
+  auto write_tile = [&](int buf) {
+    char* ql = lds + buf * STAGE;
+    char* dl = ql + TILE_BYTES;
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int r = srow + 32 * ps;
+      *reinterpret_cast<uint4*>(ql + r * 128 + ((schunk ^ sw_dual(r)) << 4)) = qreg[ps];
+      *reinterpret_cast<uint4*>(dl + r * 128 + ((schunk ^ sw_dual(r)) << 4)) = doreg[ps];
+    }
+    if (tid < 128) reinterpret_cast<float*>(ql + 2 * TILE_BYTES)[tid] = sreg;
+  };
+
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+
+  const int nt = (N + 63) / 64;
+  load_tile(0);
+  write_tile(0);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) load_tile((t + 1) * 64);
+    const char* ql = lds + (t & 1) * STAGE;
+    const char* dl = ql + TILE_BYTES;
+    const float* rowc = reinterpret_cast<const float*>(ql + 2 * TILE_BYTES);  // [0..63] -lse2/c, [64..127] -delta
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      // initial accumulators: per-row constants; accumulator register r <-> row (r&3) + 8*(r>>2) + 4*h5
+      f32x16 s, dp;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const float4 a = *reinterpret_cast<const float4*>(rowc + qt * 32 + 8 * r4 + 4 * h5);
+        const float4 d = *reinterpret_cast<const float4*>(rowc + 64 + qt * 32 + 8 * r4 + 4 * h5);
+        s[4 * r4 + 0] = a.x; s[4 * r4 + 1] = a.y; s[4 * r4 + 2] = a.z; s[4 * r4 + 3] = a.w;
+        dp[4 * r4 + 0] = d.x; dp[4 * r4 + 1] = d.y; dp[4 * r4 + 2] = d.z; dp[4 * r4 + 3] = d.w;
+      }
+      const int qrow = qt * 32 + kl_;  // A-operand row for the row reads (lane&31)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_dual(ql, qrow, ks, h5), kfr[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_dual(dl, qrow, ks, h5), vfr[ks], dp, 0, 0, 0);
+      }
+      f32x16 pm, ds;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        pm[r] = fast_exp2(s[r] * c);
+        ds[r] = pm[r] * dp[r];
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pf = pack8(pm, s2), dsf = pack8(ds, s2);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_dual(dl, qt * 32 + 16 * s2, dt * 32, lane), pf, dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_dual(ql, qt * 32 + 16 * s2, dt * 32, lane), dsf, dk[dt], 0, 0, 0);
+        }
+      }
+    }
+    if (t + 1 < nt) write_tile((t + 1) & 1);
+    __syncthreads();
+  }
+
+  if (kvalid) {
+    uint16_t* okp = dqkv + ((int64_t)b * N + krow) * tok + (int64_t)H * BHD + head * BHD;
+    uint16_t* ovp = okp + (int64_t)H * BHD;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int d = dt * 32 + 8 * r4 + 4 * h5;
+        uint2 pk, pv;
+        pk.x = pack_bf16x2(dk[dt][4 * r4 + 0] * scale, dk[dt][4 * r4 + 1] * scale);
+        pk.y = pack_bf16x2(dk[dt][4 * r4 + 2] * scale, dk[dt][4 * r4 + 3] * scale);
+        pv.x = pack_bf16x2(dv[dt][4 * r4 + 0], dv[dt][4 * r4 + 1]);
+        pv.y = pack_bf16x2(dv[dt][4 * r4 + 2], dv[dt][4 * r4 + 3]);
+        *reinterpret_cast<uint2*>(okp + d) = pk;
+        *reinterpret_cast<uint2*>(ovp + d) = pv;
+      }
+  }
+}
+
+}  // namespace tad
+
+using namespace tad;
+
+extern "C" int tad_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* lse, uint16_t* dqkv, float* delta,
+                            int B, int N, int H, int d, float scale, tad_stream_t stream) {
+  TAD_REQUIRE(qkv && out && dout && lse && dqkv && delta, "attn_bwd: null pointer");
+  TAD_REQUIRE(d == BHD, "attn_bwd: head_dim must be 64 (got %d)", d);
+  TAD_REQUIRE(B > 0 && N > 0 && H > 0 && H <= 65535 && B <= 65535, "attn_bwd: bad shape");
+  TAD_REQUIRE(scale > 0.f, "attn_bwd: scale must be positive");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t rows = (int64_t)B * N * H;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows * 8 + 255) / 256)), dim3(256), 0, st, out, dout, delta, B, N, H);
+  int rc = check_launch("attn_delta");
+  if (rc) return rc;
+  const dim3 grid((N + 127) / 128, H, B), block(256);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, block, 0, st, qkv, dout, lse, delta, dqkv, N, H, scale);
+  rc = check_launch("attn_bwd_dq");
+  if (rc) return rc;
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, block, 0, st, qkv, dout, lse, delta, dqkv, N, H, scale);
+  return check_launch("attn_bwd_dkv");
+}

@@ -1,0 +1,224 @@
+// Fused space-time attention forward (flash-style, non-causal, head_dim 64) for gfx950.
+//
+// qkv is the packed output of the qkv Linear: [B, N, 3, H, 64] bf16.  One workgroup = 4 waves = 128 query rows of one
+// (batch, head); each wave owns 32 query rows.  K/V tiles of 64 keys are staged global -> registers -> LDS
+// (double-buffered, loads for tile t+1 issued before the MFMA work on tile t, written after it), one barrier per tile.
+//
+// The score tile is computed *transposed*: S^T = K * Q^T with v_mfma_f32_32x32x16_bf16, so the query index sits on the
+// lane (lane & 31) and the keys on the accumulator registers.  The softmax row reductions are then in-lane max/add over
+// registers plus ONE exchange between the two 32-lane halves (v_permlane32_swap), and the P^T accumulator registers are,
+// after a pairwise bf16 pack, directly the B operand of the O^T += V^T * P^T MFMA (no LDS round trip for P).  V^T
+// fragments come from the row-major V tile with ds_read_b64_tr_b16.  Both LDS images are XOR-swizzled so all reads are
+// bank-conflict free (tools/lds_bank_sim.py).
+#include "common.h"
+
+namespace tad {
+
+constexpr int HD = 64;      // head dim
+constexpr int KV_TILE = 64; // keys per LDS tile
+constexpr int Q_WAVE = 32;  // query rows per wave
+constexpr int Q_BLOCK = 128;
+
+__device__ __forceinline__ int swk(int key) { return (key >> 1) & 7; }
+__device__ __forceinline__ int swv(int key) { return ((key >> 1) & 1) << 2; }
+
+__device__ __forceinline__ float half_swap_max(float x) {
+  // exchange between lane l and l^32, return max of both
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float half_swap_sum(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, void* __restrict__ out,
+                                                       float* __restrict__ lse, int N, int H, float scale) {
+  __shared__ __attribute__((aligned(1024))) char lds[2 * 2 * KV_TILE * HD * 2];  // [buf][K|V][64 keys][128 B]
+  constexpr int TILE_BYTES = KV_TILE * HD * 2;                                  // 8 KiB
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * Q_BLOCK + wave * Q_WAVE;
+  const int ql = lane & 31, h5 = lane >> 5;
+  const int64_t tok_stride = (int64_t)3 * H * HD;  // elements per token
+  const uint16_t* base = qkv + (int64_t)b * N * tok_stride + head * HD;
+  const uint16_t* kbase = base + (int64_t)H * HD;
+  const uint16_t* vbase = base + (int64_t)2 * H * HD;
+  const float c = scale * 1.44269504088896340736f;  // scale * log2(e)
+
+  // Q^T fragments (B operand): lane (q, h5) holds Q[q][16ks + 8h5 .. +7]
+  bf16x8 qf[4];
+  {
+    int qrow = q0 + ql;
+    if (qrow > N - 1) qrow = N - 1;  // clamped rows are computed but never stored
+    const uint16_t* qp = base + (int64_t)qrow * tok_stride + 8 * h5;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
+  }
+
+  // staging: thread -> key (tid>>3) + 32*pass, 16-byte chunk tid&7
+  const int skey = tid >> 3, schunk = tid & 7;
+  uint4 kreg[2], vreg[2];
+  auto load_tile = [&](int kv0) {
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      int key = kv0 + skey + 32 * ps;
+      if (key > N - 1) key = N - 1;
+      kreg[ps] = *reinterpret_cast<const uint4*>(kbase + (int64_t)key * tok_stride + schunk * 8);
+      vreg[ps] = *reinterpret_cast<const uint4*>(vbase + (int64_t)key * tok_stride + schunk * 8);
+    }
+  };
+  auto write_tile = [&](int buf) {
+    char* kl = lds + buf * 2 * TILE_BYTES;
+    char* vl = kl + TILE_BYTES;
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int key = skey + 32 * ps;
+      *reinterpret_cast<uint4*>(kl + key * 128 + ((schunk ^ swk(key)) << 4)) = kreg[ps];
+      *reinterpret_cast<uint4*>(vl + key * 128 + ((schunk ^ swv(key)) << 4)) = vreg[ps];
+    }
+  };
+
+  f32x16 o[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+
+  // V^T fragment addressing (transposed reads): 16-lane group G = lane>>4, lane li in group
+  const int G = lane >> 4, li = lane & 15;
+  const int v_q = li >> 2, v_p = li & 3;
+  const int v_h = G >> 1, v_dc = 16 * (G & 1) + 4 * v_p;  // d offset inside a 32-wide d tile
+
+  const int nt = (N + KV_TILE - 1) / KV_TILE;
+  load_tile(0);
+  write_tile(0);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int kv0 = t * KV_TILE;
+    if (t + 1 < nt) load_tile(kv0 + KV_TILE);
+    const char* kl = lds + (t & 1) * 2 * TILE_BYTES;
+    const char* vl = kl + TILE_BYTES;
+
+    // ---- S^T = K Q^T : two 32-key tiles
+    f32x16 s[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+      const int key = kt * 32 + ql;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kl + key * 128 + (((2 * ks + h5) ^ swk(key)) << 4));
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+      }
+    }
+    if (kv0 + KV_TILE > N) {  // ragged last tile: mask keys >= N
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kv0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h5;
+          if (key >= N) s[kt][r] = -1e30f;
+        }
+    }
+    // ---- online softmax (query on the lane)
+    float mloc = s[0][0];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[kt][r]);
+    const float m_new = fmaxf(m_run, half_swap_max(mloc));
+    const float alpha = fast_exp2((m_run - m_new) * c);
+    const float mc = m_new * c;
+    m_run = m_new;
+    float psum = 0.f;
+    bf16x8 pf[2][2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float pv = fast_exp2(s[kt][8 * s2 + j] * c - mc);
+          psum += pv;
+          pf[kt][s2][j] = (__bf16)pv;
+        }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int k0 = kt * 32 + 16 * s2 + 4 * v_h + v_q;  // first transposed read: keys k0-v_q .. +3 ; second: +8
+        const int k1 = k0 + 8;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const int col = dt * 32 + v_dc;
+          const int ch = col >> 3, sub = (col & 7) * 2;
+          const char* a0 = vl + k0 * 128 + ((ch ^ swv(k0)) << 4) + sub;
+          const char* a1 = vl + k1 * 128 + ((ch ^ swv(k1)) << 4) + sub;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(a0));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(a1));
+          typedef __attribute__((ext_vector_type(8))) short s16x8;
+          const s16x8 vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[kt][s2], o[dt], 0, 0, 0);
+        }
+      }
+
+    if (t + 1 < nt) write_tile((t + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue
+  const float l_tot = half_swap_sum(l_run);
+  const float inv = 1.f / l_tot;
+  const int qrow = q0 + ql;
+  if (qrow < N) {
+    const int64_t obase = (((int64_t)b * N + qrow) * H + head) * HD;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int d = dt * 32 + 8 * r4 + 4 * h5;
+        const float v0 = o[dt][4 * r4 + 0] * inv, v1 = o[dt][4 * r4 + 1] * inv, v2 = o[dt][4 * r4 + 2] * inv,
+                    v3 = o[dt][4 * r4 + 3] * inv;
+        if (OUT_BF16) {
+          uint2 pk;
+          pk.x = pack_bf16x2(v0, v1);
+          pk.y = pack_bf16x2(v2, v3);
+          *reinterpret_cast<uint2*>((uint16_t*)out + obase + d) = pk;
+        } else {
+          *reinterpret_cast<float4*>((float*)out + obase + d) = make_float4(v0, v1, v2, v3);
+        }
+      }
+    if (h5 == 0 && lse) lse[((int64_t)b * H + head) * N + qrow] = m_run * scale + __logf(l_tot);
+  }
+}
+
+}  // namespace tad
+
+using namespace tad;
+
+extern "C" int tad_attn_fwd(const uint16_t* qkv, void* out, int out_dtype, float* lse, int B, int N, int H, int d, float scale,
+                            tad_stream_t stream) {
+  TAD_REQUIRE(qkv && out, "attn_fwd: null pointer");
+  TAD_REQUIRE(d == HD, "attn_fwd: head_dim must be 64 (got %d)", d);
+  TAD_REQUIRE(B > 0 && N > 0 && H > 0 && H <= 65535 && B <= 65535, "attn_fwd: bad shape B=%d N=%d H=%d", B, N, H);
+  TAD_REQUIRE(out_dtype == TAD_F32 || out_dtype == TAD_BF16, "attn_fwd: bad out_dtype %d", out_dtype);
+  TAD_REQUIRE(scale > 0.f, "attn_fwd: scale must be positive");
+  const dim3 grid((N + Q_BLOCK - 1) / Q_BLOCK, H, B), block(256);
+  if (out_dtype == TAD_BF16)
+    hipLaunchKernelGGL((attn_fwd_kernel<true>), grid, block, 0, (hipStream_t)stream, qkv, out, lse, N, H, scale);
+  else
+    hipLaunchKernelGGL((attn_fwd_kernel<false>), grid, block, 0, (hipStream_t)stream, qkv, out, lse, N, H, scale);
+  return check_launch("attn_fwd");
+}

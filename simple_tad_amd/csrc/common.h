@@ -1,0 +1,78 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) kernels of libtad_mi355x.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/tad_mi355x.h"
+
+namespace tad {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(2))) int i32x2;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+constexpr int WAVE = 64;
+
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define TAD_REQUIRE(cond, ...)                \
+  do {                                        \
+    if (!(cond)) {                            \
+      tad::set_error(__VA_ARGS__);            \
+      return TAD_EINVAL;                      \
+    }                                         \
+  } while (0)
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even; plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 and keeps NaN a NaN
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(uint16_t, b);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  bf16x2 v;
+  v[0] = (__bf16)lo;
+  v[1] = (__bf16)hi;
+  return __builtin_bit_cast(uint32_t, v);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// raw v_exp_f32 (2^x); denormal results flush to zero, which is what the softmax wants
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// exact-erf GELU and its derivative (nn.GELU() default, modeling_finetune.py:38)
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// Bijective XCD-aware block remap (8 XCDs, blocks dealt round-robin): consecutive logical ids land on one XCD.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+}  // namespace tad

@@ -1,0 +1,312 @@
+// HBM-bound helper kernels: casts, tubelet im2col, mean-pool, column sums, sum of squares.
+// All are streaming kernels: 16-byte vector accesses, grid capped at ~8 blocks/CU with grid-stride loops.
+#include "common.h"
+
+namespace tad {
+
+static inline int capped_grid(int64_t work_items, int block) {
+  int64_t g = (work_items + block - 1) / block;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ---------------------------------------------------------------- cast f32 -> bf16
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int64_t n) {
+  const int64_t n8 = n >> 3;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+    const float4 a = reinterpret_cast<const float4*>(src)[2 * i];
+    const float4 b = reinterpret_cast<const float4*>(src)[2 * i + 1];
+    uint4 o;
+    o.x = pack_bf16x2(a.x, a.y);
+    o.y = pack_bf16x2(a.z, a.w);
+    o.z = pack_bf16x2(b.x, b.y);
+    o.w = pack_bf16x2(b.z, b.w);
+    reinterpret_cast<uint4*>(dst)[i] = o;
+  }
+  // tail
+  for (int64_t i = (n8 << 3) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    dst[i] = f32_to_bf16(src[i]);
+}
+
+// ---------------------------------------------------------------- transpose + cast: src [R,C] f32 -> dst [C,R] bf16
+// 64x64 tile through LDS (padded), coalesced on both sides.
+__global__ void transpose_cast_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int R, int C) {
+  __shared__ float tile[64][65];
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 256 threads: 4 rows per pass
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < R && c < C) ? src[(int64_t)r * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < C && r < R) dst[(int64_t)c * R + r] = f32_to_bf16(tile[tx][i]);
+  }
+}
+
+// ---------------------------------------------------------------- tubelet im2col
+// x [B,C,T,H,W] f32 -> cols [B*N, K] bf16, token n = (t'*H' + h')*W' + w', k = ((c*tub+kt)*p+kh)*p+kw.
+// One thread moves 8 consecutive w (32 B in, 16 B out); threads walk x in memory order -> coalesced reads.
+__global__ void im2col_tubelets_kernel(const float* __restrict__ x, uint16_t* __restrict__ cols, int B, int C,
+                                       int T, int H, int W, int tub, int p) {
+  const int W8 = W >> 3;
+  const int64_t total = (int64_t)B * C * T * H * W8;
+  const int Hp = H / p, Wp = W / p, Tp = T / tub;
+  const int K = C * tub * p * p;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    int64_t r = i;
+    const int w8 = (int)(r % W8); r /= W8;
+    const int h = (int)(r % H); r /= H;
+    const int t = (int)(r % T); r /= T;
+    const int c = (int)(r % C); r /= C;
+    const int b = (int)r;
+    const int w = w8 << 3;
+    const float4 a0 = reinterpret_cast<const float4*>(x)[2 * i];
+    const float4 a1 = reinterpret_cast<const float4*>(x)[2 * i + 1];
+    const int tp = t / tub, kt = t - tp * tub;
+    const int hp = h / p, kh = h - hp * p;
+    const int wp = w / p, kw = w - wp * p;
+    const int64_t n = ((int64_t)(b * Tp + tp) * Hp + hp) * Wp + wp;
+    const int k = ((c * tub + kt) * p + kh) * p + kw;
+    uint4 o;
+    o.x = pack_bf16x2(a0.x, a0.y);
+    o.y = pack_bf16x2(a0.z, a0.w);
+    o.z = pack_bf16x2(a1.x, a1.y);
+    o.w = pack_bf16x2(a1.z, a1.w);
+    *reinterpret_cast<uint4*>(cols + n * K + k) = o;
+  }
+}
+
+// ---------------------------------------------------------------- mean-pool
+// partial[b][s][D]: block (x = column chunk of 256, y = split s, z = b); 4 waves stride over the rows of the split.
+__global__ void meanpool_partial_kernel(const float* __restrict__ x, float* __restrict__ partial, int N, int D) {
+  __shared__ float4 red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col4 = blockIdx.x * 64 + lane;  // float4 column index
+  const int s = blockIdx.y, b = blockIdx.z;
+  const int D4 = D >> 2;
+  const int rows_per = (N + TAD_POOL_SPLIT - 1) / TAD_POOL_SPLIT;
+  const int n0 = s * rows_per, n1 = min(N, n0 + rows_per);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (col4 < D4) {
+    const float4* base = reinterpret_cast<const float4*>(x) + (int64_t)b * N * D4 + col4;
+    for (int n = n0 + wave; n < n1; n += 4) {
+      const float4 v = base[(int64_t)n * D4];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && col4 < D4) {
+    float4 t = red[0][lane];
+    for (int w = 1; w < 4; ++w) { t.x += red[w][lane].x; t.y += red[w][lane].y; t.z += red[w][lane].z; t.w += red[w][lane].w; }
+    reinterpret_cast<float4*>(partial)[((int64_t)b * TAD_POOL_SPLIT + s) * D4 + col4] = t;
+  }
+}
+__global__ void meanpool_final_kernel(const float* __restrict__ partial, float* __restrict__ y, int B, int N, int D) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * D) return;
+  const int b = i / D, j = i - b * D;
+  float s = 0.f;
+  for (int k = 0; k < TAD_POOL_SPLIT; ++k) s += partial[((int64_t)b * TAD_POOL_SPLIT + k) * D + j];
+  y[i] = s / (float)N;
+}
+__global__ void meanpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, uint16_t* __restrict__ dxb,
+                                    int B, int N, int D) {
+  const int D4 = D >> 2;
+  const int64_t total = (int64_t)B * N * D4;
+  const float inv = 1.f / (float)N;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c4 = (int)(i % D4);
+    const int b = (int)(i / ((int64_t)N * D4));
+    float4 v = reinterpret_cast<const float4*>(dy)[(int64_t)b * D4 + c4];
+    v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv;
+    if (dx) reinterpret_cast<float4*>(dx)[i] = v;
+    if (dxb) {
+      uint2 o;
+      o.x = pack_bf16x2(v.x, v.y);
+      o.y = pack_bf16x2(v.z, v.w);
+      reinterpret_cast<uint2*>(dxb)[i] = o;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- column sums of a bf16 matrix
+// stage 1: block (x: chunk of 512 columns, y: row split) -> partial [splits][N]; each thread owns 8 columns (16 B loads)
+// and blockDim.y... here: 256 threads = 64 lanes (8 cols each = 512 cols) x 4 waves over rows.
+__global__ void colsum_partial_kernel(const uint16_t* __restrict__ a, float* __restrict__ partial, int64_t M, int N,
+                                      int rows_per) {
+  __shared__ float red[4][64][8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = (blockIdx.x * 64 + lane) * 8;
+  const int64_t m0 = (int64_t)blockIdx.y * rows_per, m1 = min(M, m0 + rows_per);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c0 < N) {
+    for (int64_t m = m0 + wave; m < m1; m += 4) {
+      const uint4 v = *reinterpret_cast<const uint4*>(a + m * N + c0);
+      acc[0] += __uint_as_float(v.x << 16); acc[1] += __uint_as_float(v.x & 0xffff0000u);
+      acc[2] += __uint_as_float(v.y << 16); acc[3] += __uint_as_float(v.y & 0xffff0000u);
+      acc[4] += __uint_as_float(v.z << 16); acc[5] += __uint_as_float(v.z & 0xffff0000u);
+      acc[6] += __uint_as_float(v.w << 16); acc[7] += __uint_as_float(v.w & 0xffff0000u);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[wave][lane][j] = acc[j];
+  __syncthreads();
+  if (wave == 0 && c0 < N) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      partial[(int64_t)blockIdx.y * N + c0 + j] = red[0][lane][j] + red[1][lane][j] + red[2][lane][j] + red[3][lane][j];
+  }
+}
+// stage 2 (also used for LayerNorm dgamma/dbeta and split-K slabs): out[j] (+)= sum_s partial[s][j]
+__global__ void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, int splits,
+                                       int64_t n, int accumulate) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 s = reinterpret_cast<const float4*>(partial)[i];
+    for (int k = 1; k < splits; ++k) {
+      const float4 v = reinterpret_cast<const float4*>(partial + (int64_t)k * n)[i];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (accumulate) {
+      const float4 o = reinterpret_cast<float4*>(out)[i];
+      s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = s;
+  }
+  for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += partial[(int64_t)k * n + i];
+    out[i] = accumulate ? out[i] + s : s;
+  }
+}
+
+// ---------------------------------------------------------------- y = bf16(rowscale * gamma * x)
+__global__ void scale_cast_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, const float* __restrict__ gamma,
+                                  const float* __restrict__ rowscale, int rows_per_scale, int64_t M, int N) {
+  const int N4 = N >> 2;
+  const int64_t total = M * N4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t m = i / N4;
+    const int c4 = (int)(i - m * N4);
+    float4 v = reinterpret_cast<const float4*>(x)[i];
+    float s = rowscale ? rowscale[m / rows_per_scale] : 1.f;
+    if (gamma) {
+      const float4 g = reinterpret_cast<const float4*>(gamma)[c4];
+      v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w;
+    }
+    uint2 o;
+    o.x = pack_bf16x2(v.x * s, v.y * s);
+    o.y = pack_bf16x2(v.z * s, v.w * s);
+    reinterpret_cast<uint2*>(y)[i] = o;
+  }
+}
+
+// ---------------------------------------------------------------- sum of squares
+__global__ void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+  __shared__ float red[4];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) s += x[i] * x[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+// host-callable launcher shared with other translation units
+int launch_reduce_partials(const float* partial, float* out, int splits, int64_t n, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(capped_grid((n + 3) / 4, 256)), dim3(256), 0, st, partial, out, splits, n,
+                     accumulate);
+  return check_launch("reduce_partials");
+}
+
+}  // namespace tad
+
+using namespace tad;
+
+extern "C" {
+
+int tad_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, tad_stream_t stream) {
+  TAD_REQUIRE(src && dst && n >= 0, "cast: null pointer");
+  if (n == 0) return TAD_OK;
+  TAD_REQUIRE((((uintptr_t)src) & 15) == 0 && (((uintptr_t)dst) & 15) == 0, "cast: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(capped_grid((n + 7) / 8, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+  return check_launch("cast_f32_bf16");
+}
+
+int tad_transpose_cast_f32_bf16(const float* src, uint16_t* dst, int R, int C, tad_stream_t stream) {
+  TAD_REQUIRE(src && dst && R > 0 && C > 0, "transpose_cast: bad args");
+  hipLaunchKernelGGL(transpose_cast_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, (hipStream_t)stream, src, dst, R, C);
+  return check_launch("transpose_cast");
+}
+
+int tad_im2col_tubelets(const float* x, uint16_t* cols, int B, int C, int T, int H, int W, int tubelet, int patch,
+                        tad_stream_t stream) {
+  TAD_REQUIRE(x && cols, "im2col: null pointer");
+  TAD_REQUIRE(B > 0 && C > 0 && tubelet > 0 && patch > 0 && T % tubelet == 0 && H % patch == 0 && W % patch == 0,
+              "im2col: T/H/W must be multiples of tubelet/patch (got T=%d H=%d W=%d tub=%d p=%d)", T, H, W, tubelet, patch);
+  TAD_REQUIRE(patch % 8 == 0, "im2col: patch size must be a multiple of 8 (got %d)", patch);
+  const int64_t total = (int64_t)B * C * T * H * (W / 8);
+  hipLaunchKernelGGL(im2col_tubelets_kernel, dim3(capped_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, cols, B, C, T,
+                     H, W, tubelet, patch);
+  return check_launch("im2col_tubelets");
+}
+
+int tad_meanpool_fwd(const float* x, float* y, float* ws, int B, int N, int D, tad_stream_t stream) {
+  TAD_REQUIRE(x && y && ws && B > 0 && N > 0 && D > 0 && D % 4 == 0, "meanpool_fwd: bad args (D must be a multiple of 4)");
+  hipLaunchKernelGGL(meanpool_partial_kernel, dim3((D / 4 + 63) / 64, TAD_POOL_SPLIT, B), dim3(256), 0, (hipStream_t)stream, x, ws, N, D);
+  hipLaunchKernelGGL(meanpool_final_kernel, dim3((B * D + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, y, B, N, D);
+  return check_launch("meanpool_fwd");
+}
+
+int tad_meanpool_bwd(const float* dy, float* dx, uint16_t* dx_bf16, int B, int N, int D, tad_stream_t stream) {
+  TAD_REQUIRE(dy && (dx || dx_bf16) && B > 0 && N > 0 && D % 4 == 0, "meanpool_bwd: bad args");
+  hipLaunchKernelGGL(meanpool_bwd_kernel, dim3(capped_grid((int64_t)B * N * D / 4, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx,
+                     dx_bf16, B, N, D);
+  return check_launch("meanpool_bwd");
+}
+
+static inline int colsum_splits(int64_t M) {
+  int64_t s = (M + 255) / 256;
+  if (s > 128) s = 128;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+size_t tad_colsum_workspace_bytes(int64_t M, int N) { return (size_t)colsum_splits(M) * (size_t)N * sizeof(float); }
+
+int tad_colsum_bf16(const uint16_t* a, float* out, int accumulate, void* ws, size_t ws_bytes, int64_t M, int N,
+                    tad_stream_t stream) {
+  TAD_REQUIRE(a && out && ws && M > 0 && N > 0 && N % 8 == 0, "colsum: bad args (N must be a multiple of 8)");
+  const int splits = colsum_splits(M);
+  if (ws_bytes < (size_t)splits * N * sizeof(float)) { set_error("colsum: workspace too small"); return TAD_ENOSPACE; }
+  const int rows_per = (int)((M + splits - 1) / splits);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 511) / 512, splits), dim3(256), 0, (hipStream_t)stream, a, (float*)ws, M, N, rows_per);
+  return launch_reduce_partials((const float*)ws, out, splits, N, accumulate, (hipStream_t)stream);
+}
+
+int tad_scale_cast_bf16(const float* x, uint16_t* y, const float* gamma, const float* rowscale, int rows_per_scale, int64_t M,
+                        int N, tad_stream_t stream) {
+  TAD_REQUIRE(x && y && M > 0 && N > 0 && N % 4 == 0, "scale_cast: bad args");
+  TAD_REQUIRE(!rowscale || rows_per_scale > 0, "scale_cast: rows_per_scale must be > 0");
+  hipLaunchKernelGGL(scale_cast_kernel, dim3(capped_grid(M * N / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, y, gamma, rowscale,
+                     rows_per_scale, M, N);
+  return check_launch("scale_cast");
+}
+
+int tad_sumsq_f32(const float* x, int64_t n, float* out, tad_stream_t stream) {
+  TAD_REQUIRE(x && out && n >= 0, "sumsq: bad args");
+  if (n == 0) return TAD_OK;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(capped_grid(n, 256 * 8)), dim3(256), 0, (hipStream_t)stream, x, n, out);
+  return check_launch("sumsq");
+}
+
+}  // extern "C"

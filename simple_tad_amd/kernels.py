@@ -1,0 +1,275 @@
+"""Tensor-level wrappers over the C ABI: validate shapes on the host, pass raw device
+pointers + the current HIP stream.  No arithmetic happens in Python or in torch here.
+
+Every function requires CUDA(=HIP) tensors and raises otherwise -- there is no CPU path.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, TAD_BF16, TAD_F32, check
+
+_workspaces = {}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _req(t: torch.Tensor, dtype, name: str):
+    if not t.is_cuda:
+        raise _lib.TadError(f"{name}: expected a GPU tensor (the MI355X path has no CPU fallback), got {t.device}")
+    if t.dtype != dtype:
+        raise _lib.TadError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _lib.TadError(f"{name}: tensor must be contiguous")
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return TAD_F32
+    if t.dtype == torch.bfloat16:
+        return TAD_BF16
+    raise _lib.TadError(f"unsupported dtype {t.dtype}")
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """Grow-only scratch buffer per device.  All kernels run on the current stream in issue
+    order, so one buffer is shared by consecutive ops."""
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+# ----------------------------------------------------------------------------- casts
+def cast_bf16(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _req(x, torch.float32, "cast_bf16.x")
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    check(_lib.load().tad_cast_f32_bf16(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "tad_cast_f32_bf16")
+    return out
+
+
+def transpose_cast_bf16(w: torch.Tensor) -> torch.Tensor:
+    """w [R,C] f32 -> [C,R] bf16"""
+    _req(w, torch.float32, "transpose_cast.w")
+    R, Cc = w.shape
+    out = torch.empty((Cc, R), dtype=torch.bfloat16, device=w.device)
+    check(_lib.load().tad_transpose_cast_f32_bf16(w.data_ptr(), out.data_ptr(), R, Cc, _stream()), "tad_transpose_cast")
+    return out
+
+
+def scale_cast_bf16(x, gamma=None, rowscale=None, rows_per_scale=1):
+    _req(x, torch.float32, "scale_cast.x")
+    M, N = x.shape
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    check(_lib.load().tad_scale_cast_bf16(x.data_ptr(), out.data_ptr(), _p(gamma), _p(rowscale), int(rows_per_scale), M, N,
+                                          _stream()), "tad_scale_cast_bf16")
+    return out
+
+
+# ----------------------------------------------------------------------------- patch embed
+def im2col_tubelets(x: torch.Tensor, tubelet: int, patch: int) -> torch.Tensor:
+    _req(x, torch.float32, "im2col.x")
+    B, Cc, T, H, W = x.shape
+    ntok = (T // tubelet) * (H // patch) * (W // patch)
+    cols = torch.empty((B * ntok, Cc * tubelet * patch * patch), dtype=torch.bfloat16, device=x.device)
+    check(_lib.load().tad_im2col_tubelets(x.data_ptr(), cols.data_ptr(), B, Cc, T, H, W, tubelet, patch, _stream()),
+          "tad_im2col_tubelets")
+    return cols
+
+
+def patch_embed_fwd(x, w_bf16, bias, pos, tubelet: int, patch: int):
+    """x [B,C,T,H,W] f32, w_bf16 [D,K], bias [D] f32|None, pos [N,D] f32|None -> (out [B,N,D] f32, cols [B*N,K] bf16)"""
+    _req(x, torch.float32, "patch_embed.x")
+    _req(w_bf16, torch.bfloat16, "patch_embed.w")
+    B, Cc, T, H, W = x.shape
+    D, K = w_bf16.shape
+    if K != Cc * tubelet * patch * patch:
+        raise _lib.TadError(f"patch_embed: weight K={K} does not match C*tub*p*p={Cc * tubelet * patch * patch}")
+    ntok = (T // tubelet) * (H // patch) * (W // patch)
+    if pos is not None:
+        _req(pos, torch.float32, "patch_embed.pos")
+        if tuple(pos.shape) != (ntok, D):
+            raise _lib.TadError(f"patch_embed: pos_embed shape {tuple(pos.shape)} != {(ntok, D)}")
+    if bias is not None:
+        _req(bias, torch.float32, "patch_embed.bias")
+    cols = torch.empty((B * ntok, K), dtype=torch.bfloat16, device=x.device)
+    out = torch.empty((B, ntok, D), dtype=torch.float32, device=x.device)
+    check(_lib.load().tad_patch_embed_fwd(x.data_ptr(), w_bf16.data_ptr(), _p(bias), _p(pos), out.data_ptr(), cols.data_ptr(),
+                                          B, Cc, T, H, W, tubelet, patch, D, _stream()), "tad_patch_embed_fwd")
+    return out, cols
+
+
+# ----------------------------------------------------------------------------- layernorm
+def layernorm_fwd(x, gamma, beta, eps: float, out_dtype=torch.bfloat16, save_stats=True):
+    _req(x, torch.float32, "layernorm.x")
+    _req(gamma, torch.float32, "layernorm.gamma")
+    _req(beta, torch.float32, "layernorm.beta")
+    D = x.shape[-1]
+    rows = x.numel() // D
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
+    check(_lib.load().tad_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _dt(y), _p(mean), _p(rstd),
+                                        rows, D, float(eps), _stream()), "tad_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, want_bf16=False, want_colsum=False):
+    """returns dx f32, dx_bf16|None, dgamma, dbeta, colsum_dx|None"""
+    _req(x, torch.float32, "layernorm_bwd.x")
+    if dy.dtype not in (torch.float32, torch.bfloat16) or not dy.is_contiguous():
+        raise _lib.TadError("layernorm_bwd.dy: must be contiguous f32 or bf16")
+    D = x.shape[-1]
+    rows = x.numel() // D
+    if dres is not None:
+        _req(dres, torch.float32, "layernorm_bwd.dres")
+    dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    dxb = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    dg = torch.empty(D, dtype=torch.float32, device=x.device)
+    db = torch.empty(D, dtype=torch.float32, device=x.device)
+    cs = torch.empty(D, dtype=torch.float32, device=x.device) if want_colsum else None
+    lib = _lib.load()
+    nbytes = lib.tad_layernorm_bwd_workspace_bytes(rows, D)
+    ws = workspace(nbytes, x.device)
+    check(lib.tad_layernorm_bwd(dy.data_ptr(), _dt(dy), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(dres),
+                                dx.data_ptr(), _p(dxb), dg.data_ptr(), db.data_ptr(), _p(cs), ws.data_ptr(), ws.numel(), rows, D,
+                                _stream()), "tad_layernorm_bwd")
+    return dx, dxb, dg, db, cs
+
+
+# ----------------------------------------------------------------------------- linear
+def linear_fwd(x, w, bias=None, out_dtype=torch.bfloat16, epilogue=EPI_BIAS, want_preact=False, residual=None, gamma=None,
+               rowscale=None, rows_per_scale=1):
+    """x [M,K] bf16, w [N,K] bf16 -> y [M,N]; returns (y, preact|None)"""
+    _req(x, torch.bfloat16, "linear.x")
+    _req(w, torch.bfloat16, "linear.w")
+    M, K = x.shape
+    N, K2 = w.shape
+    if K != K2:
+        raise _lib.TadError(f"linear: x K={K} vs w K={K2}")
+    if bias is not None:
+        _req(bias, torch.float32, "linear.bias")
+        assert bias.numel() == N
+    if residual is not None:
+        _req(residual, torch.float32, "linear.residual")
+        assert tuple(residual.shape) == (M, N)
+    y = torch.empty((M, N), dtype=out_dtype, device=x.device)
+    pre = torch.empty((M, N), dtype=torch.bfloat16, device=x.device) if want_preact else None
+    check(_lib.load().tad_linear_fwd(x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), _dt(y), epilogue, _p(pre), _p(residual),
+                                     _p(gamma), _p(rowscale), int(rows_per_scale), M, N, K, _stream()), "tad_linear_fwd")
+    return y, pre
+
+
+def linear_bwd_input(dy, wT, out_dtype=torch.bfloat16, gelu_preact=None):
+    """dy [M,N] bf16, wT [K,N] bf16 -> dx [M,K]"""
+    _req(dy, torch.bfloat16, "linear_bwd_input.dy")
+    _req(wT, torch.bfloat16, "linear_bwd_input.wT")
+    M, N = dy.shape
+    K, N2 = wT.shape
+    assert N == N2, (N, N2)
+    if gelu_preact is not None:
+        _req(gelu_preact, torch.bfloat16, "linear_bwd_input.gelu_preact")
+        assert tuple(gelu_preact.shape) == (M, K)
+    dx = torch.empty((M, K), dtype=out_dtype, device=dy.device)
+    check(_lib.load().tad_linear_bwd_input(dy.data_ptr(), wT.data_ptr(), dx.data_ptr(), _dt(dx), _p(gelu_preact), M, N, K, _stream()),
+          "tad_linear_bwd_input")
+    return dx
+
+
+def linear_bwd_weight(dy, x, want_bias=True, dW=None, db=None, accumulate=False):
+    """dy [M,N] bf16, x [M,K] bf16 -> dW [N,K] f32, db [N] f32|None"""
+    _req(dy, torch.bfloat16, "linear_bwd_weight.dy")
+    _req(x, torch.bfloat16, "linear_bwd_weight.x")
+    M, N = dy.shape
+    M2, K = x.shape
+    assert M == M2
+    if dW is None:
+        dW = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+        accumulate = False
+    if want_bias and db is None:
+        db = torch.empty(N, dtype=torch.float32, device=dy.device)
+    lib = _lib.load()
+    ws = workspace(lib.tad_linear_bwd_weight_workspace_bytes(M, N, K), dy.device)
+    check(lib.tad_linear_bwd_weight(dy.data_ptr(), x.data_ptr(), dW.data_ptr(), _p(db) if want_bias else None, int(accumulate),
+                                    ws.data_ptr(), ws.numel(), M, N, K, _stream()), "tad_linear_bwd_weight")
+    return dW, (db if want_bias else None)
+
+
+def colsum_bf16(a, out=None):
+    _req(a, torch.bfloat16, "colsum.a")
+    M, N = a.shape
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=a.device)
+    lib = _lib.load()
+    ws = workspace(lib.tad_colsum_workspace_bytes(M, N), a.device)
+    check(lib.tad_colsum_bf16(a.data_ptr(), out.data_ptr(), 0, ws.data_ptr(), ws.numel(), M, N, _stream()), "tad_colsum_bf16")
+    return out
+
+
+# ----------------------------------------------------------------------------- attention
+def attn_fwd(qkv, B: int, N: int, H: int, scale: float, out_dtype=torch.bfloat16, want_lse=True):
+    """qkv [B*N, 3*H*64] bf16 (packed [B,N,3,H,64]) -> out [B*N, H*64], lse [B,H,N] f32"""
+    _req(qkv, torch.bfloat16, "attn.qkv")
+    if qkv.numel() != B * N * 3 * H * 64:
+        raise _lib.TadError(f"attn_fwd: qkv has {qkv.numel()} elements, expected {B * N * 3 * H * 64}")
+    out = torch.empty((B * N, H * 64), dtype=out_dtype, device=qkv.device)
+    lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device) if want_lse else None
+    check(_lib.load().tad_attn_fwd(qkv.data_ptr(), out.data_ptr(), _dt(out), _p(lse), B, N, H, 64, float(scale), _stream()),
+          "tad_attn_fwd")
+    return out, lse
+
+
+def attn_bwd(qkv, out, dout, lse, B: int, N: int, H: int, scale: float):
+    for t, n in ((qkv, "qkv"), (out, "out"), (dout, "dout")):
+        _req(t, torch.bfloat16, "attn_bwd." + n)
+    _req(lse, torch.float32, "attn_bwd.lse")
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
+    check(_lib.load().tad_attn_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), delta.data_ptr(),
+                                   B, N, H, 64, float(scale), _stream()), "tad_attn_bwd")
+    return dqkv
+
+
+# ----------------------------------------------------------------------------- mean-pool
+def meanpool_fwd(x):
+    _req(x, torch.float32, "meanpool.x")
+    B, N, D = x.shape
+    y = torch.empty((B, D), dtype=torch.float32, device=x.device)
+    ws = workspace(B * _lib.POOL_SPLIT * D * 4, x.device)
+    check(_lib.load().tad_meanpool_fwd(x.data_ptr(), y.data_ptr(), ws.data_ptr(), B, N, D, _stream()), "tad_meanpool_fwd")
+    return y
+
+
+def meanpool_bwd(dy, N: int, want_bf16=False):
+    _req(dy, torch.float32, "meanpool_bwd.dy")
+    B, D = dy.shape
+    dx = torch.empty((B, N, D), dtype=torch.float32, device=dy.device)
+    dxb = torch.empty((B, N, D), dtype=torch.bfloat16, device=dy.device) if want_bf16 else None
+    check(_lib.load().tad_meanpool_bwd(dy.data_ptr(), dx.data_ptr(), _p(dxb), B, N, D, _stream()), "tad_meanpool_bwd")
+    return dx, dxb
+
+
+def sumsq(x, out):
+    _req(x, torch.float32, "sumsq.x")
+    check(_lib.load().tad_sumsq_f32(x.data_ptr(), x.numel(), out.data_ptr(), _stream()), "tad_sumsq_f32")
+    return out
+
+
+def device_info():
+    import ctypes as C
+    cu, clk, ldsb = C.c_int(), C.c_int(), C.c_int()
+    name = C.create_string_buffer(64)
+    check(_lib.load().tad_device_info(C.byref(cu), C.byref(clk), C.byref(ldsb), name, 64), "tad_device_info")
+    return {"cu_count": cu.value, "clock_khz": clk.value, "lds_bytes_per_cu": ldsb.value, "arch": name.value.decode()}
