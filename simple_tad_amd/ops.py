@@ -1,0 +1,263 @@
+"""torch.autograd glue over the HIP kernels.  Each Function mirrors one reference operator
+(modeling_finetune.py) and calls only `simple_tad_amd.kernels` (the C ABI) for arithmetic on
+activations; torch is used for memory, streams, autograd bookkeeping and a few O(B) / O(D)
+scalar-sized tensors (bias concatenation, drop-path masks).
+
+Data flow of one fused Block (training), M = B*N rows:
+    x0 f32 --LN1--> xn1 bf16 --qkv GEMM(+bias)--> qkv bf16 [M,3D] --flash attn--> ao bf16 [M,D]
+       --proj GEMM (+bias, +residual x0)--> x1 f32 --LN2--> xn2 bf16
+       --fc1 GEMM (+bias, GELU; pre-activation kept)--> a bf16 [M,4D] --fc2 GEMM (+bias, +residual x1)--> x2 f32
+The residual stream stays f32 (as under torch autocast); GEMM / attention operands are bf16 with f32 accumulation.
+"""
+from __future__ import annotations
+
+import weakref
+from typing import Optional
+
+import torch
+
+from . import kernels as K
+from ._lib import EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, TadError
+
+# --------------------------------------------------------------------------- bf16 weight cache
+_wcache = {}  # id(param) -> {"ref": weakref, "key": (version, data_ptr), "n": bf16, "t": bf16 transposed}
+
+
+def _cached(p: torch.Tensor, kind: str):
+    """bf16 copy ('n': same layout [N,K]; 't': transposed [K,N]) of an f32 weight, invalidated when the parameter is
+    modified in place (optimizer step bumps ._version), re-allocated, or garbage-collected."""
+    pid = id(p)
+    ent = _wcache.get(pid)
+    key = (p._version, p.data_ptr())
+    if ent is None or ent["ref"]() is not p or ent["key"] != key:
+        ent = {"ref": weakref.ref(p, lambda _r, pid=pid: _wcache.pop(pid, None)), "key": key}
+        _wcache[pid] = ent
+    if kind not in ent:
+        w2 = p.detach().reshape(p.shape[0], -1)
+        if not w2.is_contiguous():
+            w2 = w2.contiguous()
+        ent[kind] = K.cast_bf16(w2) if kind == "n" else K.transpose_cast_bf16(w2)
+    return ent[kind]
+
+
+def w_bf16(p):
+    return _cached(p, "n")
+
+
+def wT_bf16(p):
+    return _cached(p, "t")
+
+
+def _f32c(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    t = t.detach()
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _need_gpu(x: torch.Tensor, what: str):
+    if not x.is_cuda:
+        raise TadError(f"{what}: input is on {x.device}; the MI355X path runs HIP kernels only (no CPU fallback). "
+                       "Move the model and inputs to a GPU.")
+
+
+def _qkv_bias(q_bias, v_bias):
+    if q_bias is None:
+        return None
+    return torch.cat((q_bias.detach(), torch.zeros_like(v_bias), v_bias.detach())).float().contiguous()
+
+
+# --------------------------------------------------------------------------- LayerNorm
+class LayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm(D, eps) on f32 rows -> f32 (modeling_finetune.py:143,149,270)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        _need_gpu(x, "LayerNorm")
+        xc = _f32c(x)
+        w, b = _f32c(weight), _f32c(bias)
+        y, mean, rstd = K.layernorm_fwd(xc.reshape(-1, xc.shape[-1]), w, b, eps, out_dtype=torch.float32)
+        ctx.save_for_backward(xc, w, mean, rstd)
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, w, mean, rstd = ctx.saved_tensors
+        D = xc.shape[-1]
+        dx, _, dg, db, _ = K.layernorm_bwd(_f32c(dy).reshape(-1, D), xc.reshape(-1, D), w, mean, rstd)
+        return dx.reshape(xc.shape), dg, db, None
+
+
+# --------------------------------------------------------------------------- PatchEmbed (+ pos_embed)
+class PatchEmbedFn(torch.autograd.Function):
+    """Conv3d(k=s=(tub,p,p)) + flatten/transpose (+ sinusoid pos_embed) (modeling_finetune.py:181-190, 312-313)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, pos, tubelet, patch):
+        _need_gpu(x, "PatchEmbed")
+        xc = _f32c(x)
+        out, cols = K.patch_embed_fwd(xc, w_bf16(weight), _f32c(bias), _f32c(pos), tubelet, patch)
+        ctx.save_for_backward(cols)
+        ctx.wshape = weight.shape
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (cols,) = ctx.saved_tensors
+        D = dy.shape[-1]
+        dyb = K.cast_bf16(_f32c(dy).reshape(-1, D))
+        dW, db = K.linear_bwd_weight(dyb, cols, want_bias=ctx.has_bias)
+        return None, dW.reshape(ctx.wshape), db, None, None, None
+
+
+# --------------------------------------------------------------------------- attention / mlp cores (2-D tensors)
+def _attn_fwd_core(xn, qkv_w, q_bias, v_bias, B, N, H, scale, train):
+    qkv, _ = K.linear_fwd(xn, w_bf16(qkv_w), _qkv_bias(q_bias, v_bias), out_dtype=torch.bfloat16)
+    ao, lse = K.attn_fwd(qkv, B, N, H, scale, out_dtype=torch.bfloat16, want_lse=train)
+    return qkv, ao, lse
+
+
+def _attn_bwd_core(d_ao, xn, qkv, ao, lse, qkv_w, has_qkv_bias, B, N, H, scale, dx_dtype):
+    """returns dxn, dWqkv, dq_bias, dv_bias"""
+    D = xn.shape[1]
+    dqkv = K.attn_bwd(qkv, ao, d_ao, lse, B, N, H, scale)
+    dxn = K.linear_bwd_input(dqkv, wT_bf16(qkv_w), out_dtype=dx_dtype)
+    dWqkv, dbqkv = K.linear_bwd_weight(dqkv, xn, want_bias=has_qkv_bias)
+    if has_qkv_bias:
+        AH = dbqkv.numel() // 3
+        return dxn, dWqkv, dbqkv[:AH].clone(), dbqkv[2 * AH:].clone()
+    return dxn, dWqkv, None, None
+
+
+class AttentionFn(torch.autograd.Function):
+    """Attention.forward (modeling_finetune.py:86-134): qkv Linear, scaled-dot-product space-time attention, proj."""
+
+    @staticmethod
+    def forward(ctx, x, qkv_w, q_bias, v_bias, proj_w, proj_b, H, scale):
+        _need_gpu(x, "Attention")
+        B, N, C = x.shape
+        train = any(ctx.needs_input_grad)
+        xb = K.cast_bf16(_f32c(x).reshape(B * N, C))
+        qkv, ao, lse = _attn_fwd_core(xb, qkv_w, q_bias, v_bias, B, N, H, scale, train)
+        y, _ = K.linear_fwd(ao, w_bf16(proj_w), _f32c(proj_b), out_dtype=torch.float32)
+        if train:
+            ctx.save_for_backward(xb, qkv, ao, lse, qkv_w, proj_w)
+        ctx.meta = (B, N, H, scale, q_bias is not None, proj_b is not None)
+        return y.reshape(B, N, -1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, qkv, ao, lse, qkv_w, proj_w = ctx.saved_tensors
+        B, N, H, scale, has_qb, has_pb = ctx.meta
+        dyb = K.cast_bf16(_f32c(dy).reshape(B * N, -1))
+        d_ao = K.linear_bwd_input(dyb, wT_bf16(proj_w))
+        dWp, dbp = K.linear_bwd_weight(dyb, ao, want_bias=has_pb)
+        dx, dWqkv, dqb, dvb = _attn_bwd_core(d_ao, xb, qkv, ao, lse, qkv_w, has_qb, B, N, H, scale, torch.float32)
+        return dx.reshape(B, N, -1), dWqkv, dqb, dvb, dWp, dbp, None, None
+
+
+class MlpFn(torch.autograd.Function):
+    """Mlp.forward (modeling_finetune.py:47-54): fc2(GELU_erf(fc1(x)))."""
+
+    @staticmethod
+    def forward(ctx, x, fc1_w, fc1_b, fc2_w, fc2_b):
+        _need_gpu(x, "Mlp")
+        shp = x.shape
+        train = any(ctx.needs_input_grad)
+        xb = K.cast_bf16(_f32c(x).reshape(-1, shp[-1]))
+        a, h = K.linear_fwd(xb, w_bf16(fc1_w), _f32c(fc1_b), out_dtype=torch.bfloat16, epilogue=EPI_BIAS_GELU, want_preact=train)
+        y, _ = K.linear_fwd(a, w_bf16(fc2_w), _f32c(fc2_b), out_dtype=torch.float32)
+        if train:
+            ctx.save_for_backward(xb, h, a, fc1_w, fc2_w)
+        ctx.meta = (shp, fc1_b is not None, fc2_b is not None)
+        return y.reshape(*shp[:-1], -1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, h, a, fc1_w, fc2_w = ctx.saved_tensors
+        shp, has_b1, has_b2 = ctx.meta
+        dyb = K.cast_bf16(_f32c(dy).reshape(-1, dy.shape[-1]))
+        dh = K.linear_bwd_input(dyb, wT_bf16(fc2_w), gelu_preact=h)
+        dW2, db2 = K.linear_bwd_weight(dyb, a, want_bias=has_b2)
+        dx = K.linear_bwd_input(dh, wT_bf16(fc1_w), out_dtype=torch.float32)
+        dW1, db1 = K.linear_bwd_weight(dh, xb, want_bias=has_b1)
+        return dx.reshape(shp), dW1, db1, dW2, db2
+
+
+# --------------------------------------------------------------------------- fused Block
+class BlockFn(torch.autograd.Function):
+    """Block.forward without layer-scale (modeling_finetune.py:159-163):
+         x = x + dp1 * attn(norm1(x));  x = x + dp2 * mlp(norm2(x))
+    dp1/dp2 are optional per-sample drop-path scales [B] (mask / keep_prob) or None."""
+
+    @staticmethod
+    def forward(ctx, x, n1w, n1b, qkv_w, q_bias, v_bias, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, dp1, dp2, H, scale,
+                eps):
+        _need_gpu(x, "Block")
+        B, N, D = x.shape
+        M = B * N
+        train = any(ctx.needs_input_grad)
+        x0 = _f32c(x).reshape(M, D)
+        g1, b1, g2, b2 = _f32c(n1w), _f32c(n1b), _f32c(n2w), _f32c(n2b)
+        xn1, mean1, rstd1 = K.layernorm_fwd(x0, g1, b1, eps, save_stats=train)
+        qkv, ao, lse = _attn_fwd_core(xn1, qkv_w, q_bias, v_bias, B, N, H, scale, train)
+        x1, _ = K.linear_fwd(ao, w_bf16(proj_w), _f32c(proj_b), out_dtype=torch.float32, epilogue=EPI_BIAS_RESIDUAL, residual=x0,
+                             rowscale=_f32c(dp1), rows_per_scale=N)
+        xn2, mean2, rstd2 = K.layernorm_fwd(x1, g2, b2, eps, save_stats=train)
+        a, h = K.linear_fwd(xn2, w_bf16(fc1_w), _f32c(fc1_b), out_dtype=torch.bfloat16, epilogue=EPI_BIAS_GELU, want_preact=train)
+        x2, _ = K.linear_fwd(a, w_bf16(fc2_w), _f32c(fc2_b), out_dtype=torch.float32, epilogue=EPI_BIAS_RESIDUAL, residual=x1,
+                             rowscale=_f32c(dp2), rows_per_scale=N)
+        if train:
+            ctx.save_for_backward(x0, g1, mean1, rstd1, xn1, qkv, ao, lse, x1, g2, mean2, rstd2, xn2, h, a, qkv_w, proj_w, fc1_w, fc2_w,
+                                  dp1 if dp1 is None else _f32c(dp1), dp2 if dp2 is None else _f32c(dp2))
+        ctx.meta = (B, N, D, H, scale, q_bias is not None)
+        return x2.reshape(B, N, D)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x0, g1, mean1, rstd1, xn1, qkv, ao, lse, x1, g2, mean2, rstd2, xn2, h, a, qkv_w, proj_w, fc1_w, fc2_w, dp1,
+         dp2) = ctx.saved_tensors
+        B, N, D, H, scale, has_qb = ctx.meta
+        M = B * N
+        g = _f32c(g).reshape(M, D)
+        # ---- MLP branch
+        gb = K.cast_bf16(g) if dp2 is None else K.scale_cast_bf16(g, None, dp2, N)
+        dh = K.linear_bwd_input(gb, wT_bf16(fc2_w), gelu_preact=h)
+        dW2, db2 = K.linear_bwd_weight(gb, a)
+        dxn2 = K.linear_bwd_input(dh, wT_bf16(fc1_w))
+        dW1, db1 = K.linear_bwd_weight(dh, xn2)
+        gmid, gmid_b, dg2, dbeta2, cs = K.layernorm_bwd(dxn2, x1, g2, mean2, rstd2, dres=g, want_bf16=(dp1 is None),
+                                                       want_colsum=(dp1 is None))
+        # ---- attention branch
+        if dp1 is None:
+            gpb, dbp = gmid_b, cs  # proj bias grad = column sums of the residual-stream grad
+        else:
+            gpb = K.scale_cast_bf16(gmid, None, dp1, N)
+            dbp = None
+        d_ao = K.linear_bwd_input(gpb, wT_bf16(proj_w))
+        dWp, dbp2 = K.linear_bwd_weight(gpb, ao, want_bias=(dbp is None))
+        if dbp is None:
+            dbp = dbp2
+        dxn1, dWqkv, dqb, dvb = _attn_bwd_core(d_ao, xn1, qkv, ao, lse, qkv_w, has_qb, B, N, H, scale, torch.bfloat16)
+        gin, _, dg1, dbeta1, _ = K.layernorm_bwd(dxn1, x0, g1, mean1, rstd1, dres=gmid)
+        return (gin.reshape(B, N, D), dg1, dbeta1, dWqkv, dqb, dvb, dWp, dbp, dg2, dbeta2, dW1, db1, dW2, db2, None, None, None, None,
+                None)
+
+
+# --------------------------------------------------------------------------- mean-pool
+class MeanPoolFn(torch.autograd.Function):
+    """x.mean(1) over tokens (modeling_finetune.py:325-326)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _need_gpu(x, "mean-pool")
+        ctx.n = x.shape[1]
+        return K.meanpool_fwd(_f32c(x))
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx, _ = K.meanpool_bwd(_f32c(dy), ctx.n)
+        return dx
