@@ -122,26 +122,27 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
   const float dlt = delta[((int64_t)b * H + head) * N + qrow];
 
   const int skey = tid >> 3, schunk = tid & 7;
-  uint4 kreg[2], vreg[2];
-  auto load_tile = [&](int kv0) {
-#pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-      int key = kv0 + skey + 32 * ps;
-      if (key > N - 1) key = N - 1;
-      kreg[ps] = *reinterpret_cast<const uint4*>(kbase + (int64_t)key * tok + schunk * 8);
-      vreg[ps] = *reinterpret_cast<const uint4*>(vbase + (int64_t)key * tok + schunk * 8);
-    }
-  };
-  auto write_tile = [&](int buf) {
-    char* kl = lds + buf * 2 * TILE_BYTES;
-    char* vl = kl + TILE_BYTES;
-#pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-      const int key = skey + 32 * ps;
-      *reinterpret_cast<uint4*>(kl + key * 128 + ((schunk ^ sw_dual(key)) << 4)) = kreg[ps];
-      *reinterpret_cast<uint4*>(vl + key * 128 + ((schunk ^ sw_dual(key)) << 4)) = vreg[ps];
-    }
-  };
+  uint4 kreg0, kreg1, vreg0, vreg1;  // named registers, unconditional clamped loads (see attn_fwd.hip)
+#define LOAD_KV(kv0)                                                                         \
+  {                                                                                          \
+    int key0_ = (kv0) + skey, key1_ = (kv0) + skey + 32;                                     \
+    key0_ = key0_ > N - 1 ? N - 1 : key0_;                                                   \
+    key1_ = key1_ > N - 1 ? N - 1 : key1_;                                                   \
+    kreg0 = *reinterpret_cast<const uint4*>(kbase + (int64_t)key0_ * tok + schunk * 8);      \
+    kreg1 = *reinterpret_cast<const uint4*>(kbase + (int64_t)key1_ * tok + schunk * 8);      \
+    vreg0 = *reinterpret_cast<const uint4*>(vbase + (int64_t)key0_ * tok + schunk * 8);      \
+    vreg1 = *reinterpret_cast<const uint4*>(vbase + (int64_t)key1_ * tok + schunk * 8);      \
+  }
+  const int w0 = skey * 128 + ((schunk ^ sw_dual(skey)) << 4), w1 = (skey + 32) * 128 + ((schunk ^ sw_dual(skey + 32)) << 4);
+#define WRITE_KV(buf)                                           \
+  {                                                             \
+    char* kl_ = lds + (buf) * 2 * TILE_BYTES;                   \
+    char* vl_ = kl_ + TILE_BYTES;                               \
+    *reinterpret_cast<uint4*>(kl_ + w0) = kreg0;                \
+    *reinterpret_cast<uint4*>(kl_ + w1) = kreg1;                \
+    *reinterpret_cast<uint4*>(vl_ + w0) = vreg0;                \
+    *reinterpret_cast<uint4*>(vl_ + w1) = vreg1;                \
+  }
 
   f32x16 dq[2];
 #pragma unroll
@@ -150,12 +151,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
     for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
 
   const int nt = (N + 63) / 64;
-  load_tile(0);
-  write_tile(0);
+  LOAD_KV(0);
+  WRITE_KV(0);
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
     const int kv0 = t * 64;
-    if (t + 1 < nt) load_tile(kv0 + 64);
+    LOAD_KV(kv0 + 64);
     const char* kl = lds + (t & 1) * 2 * TILE_BYTES;
     const char* vl = kl + TILE_BYTES;
 #pragma unroll
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
           dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_dual(kl, kt * 32 + 16 * s2, dt * 32, lane), dsf, dq[dt], 0, 0, 0);
       }
     }
-    if (t + 1 < nt) write_tile((t + 1) & 1);
+    WRITE_KV((t + 1) & 1);
     __syncthreads();
   }
 
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
                                                            uint16_t* __restrict__ dqkv, int N, int H, float scale) {
   constexpr int TILE_BYTES = 64 * 128;
@@ -237,35 +238,36 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const uint16_t* __res
   }
 
   const int srow = tid >> 3, schunk = tid & 7;
-  uint4 qreg[2], doreg[2];
+  uint4 qreg0, qreg1, doreg0, doreg1;
   float sreg = 0.f;  // tid < 64: -lse*log2e/c of row tid ; 64 <= tid < 128: -delta of row tid-64
-  auto load_tile = [&](int q0) {
-#pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-      int q = q0 + srow + 32 * ps;
-      if (q > N - 1) q = N - 1;
-      qreg[ps] = *reinterpret_cast<const uint4*>(base + (int64_t)q * tok + schunk * 8);
-      doreg[ps] = *reinterpret_cast<const uint4*>(dobase + (int64_t)q * H * BHD + schunk * 8);
-    }
-    if (tid < 64) {
-      const int q = q0 + tid;
-      sreg = (q < N) ? -lsebase[q] * LOG2E * inv_c : -3.0e30f;  // rows >= N: exp2(c*(s-3e30)) = 0
-    } else if (tid < 128) {
-      const int q = q0 + tid - 64;
-      sreg = (q < N) ? -dltbase[q] : 0.f;
-    }
-  };
-  auto write_tile = [&](int buf) {
-    char* ql = lds + buf * STAGE;
-    char* dl = ql + TILE_BYTES;
-#pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-      const int r = srow + 32 * ps;
-      *reinterpret_cast<uint4*>(ql + r * 128 + ((schunk ^ sw_dual(r)) << 4)) = qreg[ps];
-      *reinterpret_cast<uint4*>(dl + r * 128 + ((schunk ^ sw_dual(r)) << 4)) = doreg[ps];
-    }
-    if (tid < 128) reinterpret_cast<float*>(ql + 2 * TILE_BYTES)[tid] = sreg;
-  };
+#define LOAD_QDO(q0)                                                                                       \
+  {                                                                                                        \
+    int r0_ = (q0) + srow, r1_ = (q0) + srow + 32;                                                         \
+    r0_ = r0_ > N - 1 ? N - 1 : r0_;                                                                       \
+    r1_ = r1_ > N - 1 ? N - 1 : r1_;                                                                       \
+    qreg0 = *reinterpret_cast<const uint4*>(base + (int64_t)r0_ * tok + schunk * 8);                       \
+    qreg1 = *reinterpret_cast<const uint4*>(base + (int64_t)r1_ * tok + schunk * 8);                       \
+    doreg0 = *reinterpret_cast<const uint4*>(dobase + (int64_t)r0_ * H * BHD + schunk * 8);                \
+    doreg1 = *reinterpret_cast<const uint4*>(dobase + (int64_t)r1_ * H * BHD + schunk * 8);                \
+    {                                                                                                      \
+      const int qq_ = (q0) + (tid & 63);                                                                   \
+      const int qc_ = qq_ > N - 1 ? N - 1 : qq_;                                                           \
+      const float lv_ = lsebase[qc_], dv_ = dltbase[qc_];                                                  \
+      /* rows >= N: exp2(c*(s-3e30)) = 0 and delta = 0 */                                                  \
+      sreg = (tid < 64) ? (qq_ < N ? -lv_ * LOG2E * inv_c : -3.0e30f) : (qq_ < N ? -dv_ : 0.f);            \
+    }                                                                                                      \
+  }
+  const int w0 = srow * 128 + ((schunk ^ sw_dual(srow)) << 4), w1 = (srow + 32) * 128 + ((schunk ^ sw_dual(srow + 32)) << 4);
+#define WRITE_QDO(buf)                                                              \
+  {                                                                                 \
+    char* ql_ = lds + (buf) * STAGE;                                                \
+    char* dl_ = ql_ + TILE_BYTES;                                                   \
+    *reinterpret_cast<uint4*>(ql_ + w0) = qreg0;                                    \
+    *reinterpret_cast<uint4*>(ql_ + w1) = qreg1;                                    \
+    *reinterpret_cast<uint4*>(dl_ + w0) = doreg0;                                   \
+    *reinterpret_cast<uint4*>(dl_ + w1) = doreg1;                                   \
+    if (tid < 128) reinterpret_cast<float*>(ql_ + 2 * TILE_BYTES)[tid] = sreg;      \
+  }
 
   f32x16 dk[2], dv[2];
 #pragma unroll
@@ -274,11 +276,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const uint16_t* __res
     for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
 
   const int nt = (N + 63) / 64;
-  load_tile(0);
-  write_tile(0);
+  LOAD_QDO(0);
+  WRITE_QDO(0);
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
-    if (t + 1 < nt) load_tile((t + 1) * 64);
+    LOAD_QDO((t + 1) * 64);
     const char* ql = lds + (t & 1) * STAGE;
     const char* dl = ql + TILE_BYTES;
     const float* rowc = reinterpret_cast<const float*>(ql + 2 * TILE_BYTES);  // [0..63] -lse2/c, [64..127] -delta
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const uint16_t* __res
         }
       }
     }
-    if (t + 1 < nt) write_tile((t + 1) & 1);
+    WRITE_QDO((t + 1) & 1);
     __syncthreads();
   }
 

@@ -18,6 +18,7 @@ constexpr int HD = 64;      // head dim
 constexpr int KV_TILE = 64; // keys per LDS tile
 constexpr int Q_WAVE = 32;  // query rows per wave
 constexpr int Q_BLOCK = 128;
+constexpr float RESCALE_THR = 8.0f;
 
 __device__ __forceinline__ int swk(int key) { return (key >> 1) & 7; }
 __device__ __forceinline__ int swv(int key) { return ((key >> 1) & 1) << 2; }
@@ -58,28 +59,32 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
   }
 
-  // staging: thread -> key (tid>>3) + 32*pass, 16-byte chunk tid&7
+  // staging: thread -> key (tid>>3) + 32*pass, 16-byte chunk tid&7.  Plain named registers (no arrays / lambdas: those were
+  // demoted to scratch memory by the compiler) and unconditional loads (the tile index is clamped, the last prefetch is a
+  // harmless reload of the final tile).
   const int skey = tid >> 3, schunk = tid & 7;
-  uint4 kreg[2], vreg[2];
-  auto load_tile = [&](int kv0) {
-#pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-      int key = kv0 + skey + 32 * ps;
-      if (key > N - 1) key = N - 1;
-      kreg[ps] = *reinterpret_cast<const uint4*>(kbase + (int64_t)key * tok_stride + schunk * 8);
-      vreg[ps] = *reinterpret_cast<const uint4*>(vbase + (int64_t)key * tok_stride + schunk * 8);
-    }
-  };
-  auto write_tile = [&](int buf) {
-    char* kl = lds + buf * 2 * TILE_BYTES;
-    char* vl = kl + TILE_BYTES;
-#pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-      const int key = skey + 32 * ps;
-      *reinterpret_cast<uint4*>(kl + key * 128 + ((schunk ^ swk(key)) << 4)) = kreg[ps];
-      *reinterpret_cast<uint4*>(vl + key * 128 + ((schunk ^ swv(key)) << 4)) = vreg[ps];
-    }
-  };
+  uint4 kreg0, kreg1, vreg0, vreg1;
+#define LOAD_TILE(kv0)                                                                              \
+  {                                                                                                 \
+    int key0_ = (kv0) + skey, key1_ = (kv0) + skey + 32;                                            \
+    key0_ = key0_ > N - 1 ? N - 1 : key0_;                                                          \
+    key1_ = key1_ > N - 1 ? N - 1 : key1_;                                                          \
+    kreg0 = *reinterpret_cast<const uint4*>(kbase + (int64_t)key0_ * tok_stride + schunk * 8);      \
+    kreg1 = *reinterpret_cast<const uint4*>(kbase + (int64_t)key1_ * tok_stride + schunk * 8);      \
+    vreg0 = *reinterpret_cast<const uint4*>(vbase + (int64_t)key0_ * tok_stride + schunk * 8);      \
+    vreg1 = *reinterpret_cast<const uint4*>(vbase + (int64_t)key1_ * tok_stride + schunk * 8);      \
+  }
+  const int kw0 = skey * 128 + ((schunk ^ swk(skey)) << 4), kw1 = (skey + 32) * 128 + ((schunk ^ swk(skey + 32)) << 4);
+  const int vw0 = skey * 128 + ((schunk ^ swv(skey)) << 4), vw1 = (skey + 32) * 128 + ((schunk ^ swv(skey + 32)) << 4);
+#define WRITE_TILE(buf)                                                  \
+  {                                                                      \
+    char* kl_ = lds + (buf) * 2 * TILE_BYTES;                            \
+    char* vl_ = kl_ + TILE_BYTES;                                        \
+    *reinterpret_cast<uint4*>(kl_ + kw0) = kreg0;                        \
+    *reinterpret_cast<uint4*>(kl_ + kw1) = kreg1;                        \
+    *reinterpret_cast<uint4*>(vl_ + vw0) = vreg0;                        \
+    *reinterpret_cast<uint4*>(vl_ + vw1) = vreg1;                        \
+  }
 
   f32x16 o[2];
 #pragma unroll
@@ -94,12 +99,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
   const int v_h = G >> 1, v_dc = 16 * (G & 1) + 4 * v_p;  // d offset inside a 32-wide d tile
 
   const int nt = (N + KV_TILE - 1) / KV_TILE;
-  load_tile(0);
-  write_tile(0);
+  LOAD_TILE(0);
+  WRITE_TILE(0);
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
     const int kv0 = t * KV_TILE;
-    if (t + 1 < nt) load_tile(kv0 + KV_TILE);
+    LOAD_TILE(kv0 + KV_TILE);
     const char* kl = lds + (t & 1) * 2 * TILE_BYTES;
     const char* vl = kl + TILE_BYTES;
 
@@ -131,10 +136,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[kt][r]);
-    const float m_new = fmaxf(m_run, half_swap_max(mloc));
-    const float alpha = fast_exp2((m_run - m_new) * c);
-    const float mc = m_new * c;
-    m_run = m_new;
+    // deferred rescale: keep the old running max while the tile max exceeds it by less than RESCALE_THR (log2 units), so P can
+    // reach 2^THR instead of 1 -- harmless in f32 / bf16 (relative precision is scale-free) and it removes the O-wide multiply
+    // from almost every tile.  The decision precedes the exponentiation of this tile (textbook order).
+    const float m_tile = half_swap_max(mloc);
+    if (__any((m_tile - m_run) * c > RESCALE_THR)) {
+      const float m_new = fmaxf(m_run, m_tile);
+      const float alpha = fast_exp2((m_run - m_new) * c);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    }
+    const float mc = m_run * c;
     float psum = 0.f;
     bf16x8 pf[2][2];
 #pragma unroll
@@ -147,11 +163,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
           psum += pv;
           pf[kt][s2][j] = (__bf16)pv;
         }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    l_run += psum;
 
     // ---- O^T += V^T P^T
 #pragma unroll
@@ -174,7 +186,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
         }
       }
 
-    if (t + 1 < nt) write_tile((t + 1) & 1);
+    WRITE_TILE((t + 1) & 1);
     __syncthreads();
   }
 

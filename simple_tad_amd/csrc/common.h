@@ -59,12 +59,28 @@ __device__ __forceinline__ float wave_max(float v) {
 // raw v_exp_f32 (2^x); denormal results flush to zero, which is what the softmax wants
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-// exact-erf GELU and its derivative (nn.GELU() default, modeling_finetune.py:38)
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf-form GELU (nn.GELU() default, modeling_finetune.py:38) and its derivative.  erf by Abramowitz-Stegun 7.1.26
+// (|abs error| <= 1.5e-7, i.e. f32 rounding level) with one v_rcp and one v_exp: libm's erff costs ~40 VALU instructions
+// per element, which made the GELU epilogue as long as the whole K loop of the fc1 GEMM.
+__device__ __forceinline__ void erf_parts(float x, float& half_erfc_abs, float& e) {
+  // for z = |x|/sqrt(2): returns 0.5*(1 - erf(z)) = 0.5*poly(t)*exp(-z^2) and e = exp(-x^2/2)
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  e = fast_exp2(-0.72134752044448170368f * x * x);  // exp(-x^2/2) = 2^(-x^2 * log2(e)/2)
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  half_erfc_abs = 0.5f * poly * e;
+}
+__device__ __forceinline__ float gelu_erf(float x) {
+  float h, e;
+  erf_parts(x, h, e);
+  const float cdf = x >= 0.f ? 1.0f - h : h;  // Phi(x) = 0.5*(1 + erf(x/sqrt 2))
+  return x * cdf;
+}
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  float h, e;
+  erf_parts(x, h, e);
+  const float cdf = x >= 0.f ? 1.0f - h : h;
+  return fmaf(x * 0.39894228040143267794f, e, cdf);  // Phi(x) + x * phi(x)
 }
 
 // Bijective XCD-aware block remap (8 XCDs, blocks dealt round-robin): consecutive logical ids land on one XCD.

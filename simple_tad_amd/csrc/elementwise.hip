@@ -188,6 +188,49 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partial, float*
   }
 }
 
+
+// Same reduction for the "many partial rows, few columns" case (LayerNorm dgamma/dbeta over ~1000 blocks, column sums):
+// one 1024-thread block per 256 columns; the 16 waves stride over the partial rows, 4 loads in flight each, then combine
+// through LDS.  blockIdx.y selects one of up to 3 (partial, out) pairs laid out [q][splits][n] so one launch serves all.
+__global__ __launch_bounds__(1024) void reduce_cols_kernel(const float* __restrict__ partial, float* out0, float* out1, float* out2,
+                                                           int splits, int n, int accumulate) {
+  __shared__ float4 red[16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = blockIdx.y;
+  float* out = q == 0 ? out0 : (q == 1 ? out1 : out2);
+  const float* base = partial + (int64_t)q * splits * n;
+  const int c4 = blockIdx.x * 64 + lane;
+  const int n4 = n >> 2;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c4 < n4) {
+    int s = wave;
+    for (; s + 48 < splits; s += 64) {
+      const float4 a = reinterpret_cast<const float4*>(base + (int64_t)s * n)[c4];
+      const float4 b = reinterpret_cast<const float4*>(base + (int64_t)(s + 16) * n)[c4];
+      const float4 c = reinterpret_cast<const float4*>(base + (int64_t)(s + 32) * n)[c4];
+      const float4 d = reinterpret_cast<const float4*>(base + (int64_t)(s + 48) * n)[c4];
+      acc.x += (a.x + b.x) + (c.x + d.x); acc.y += (a.y + b.y) + (c.y + d.y);
+      acc.z += (a.z + b.z) + (c.z + d.z); acc.w += (a.w + b.w) + (c.w + d.w);
+    }
+    for (; s < splits; s += 16) {
+      const float4 a = reinterpret_cast<const float4*>(base + (int64_t)s * n)[c4];
+      acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+    }
+  }
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && c4 < n4) {
+    float4 t = red[0][lane];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) { t.x += red[w][lane].x; t.y += red[w][lane].y; t.z += red[w][lane].z; t.w += red[w][lane].w; }
+    if (accumulate) {
+      const float4 o = reinterpret_cast<float4*>(out)[c4];
+      t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+    }
+    reinterpret_cast<float4*>(out)[c4] = t;
+  }
+}
+
 // ---------------------------------------------------------------- y = bf16(rowscale * gamma * x)
 __global__ void scale_cast_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, const float* __restrict__ gamma,
                                   const float* __restrict__ rowscale, int rows_per_scale, int64_t M, int N) {
@@ -223,7 +266,15 @@ __global__ void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __re
 }
 
 // host-callable launcher shared with other translation units
+// up to three outputs reduced from partial[q][splits][n] in one launch (n % 4 == 0)
+int launch_reduce_cols(const float* partial, float* out0, float* out1, float* out2, int nq, int splits, int n, int accumulate,
+                       hipStream_t st) {
+  hipLaunchKernelGGL(reduce_cols_kernel, dim3((n / 4 + 63) / 64, nq), dim3(1024), 0, st, partial, out0, out1, out2, splits, n, accumulate);
+  return check_launch("reduce_cols");
+}
+
 int launch_reduce_partials(const float* partial, float* out, int splits, int64_t n, int accumulate, hipStream_t st) {
+  if (n <= 16384 && splits >= 16 && (n & 3) == 0) return launch_reduce_cols(partial, out, nullptr, nullptr, 1, splits, (int)n, accumulate, st);
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(capped_grid((n + 3) / 4, 256)), dim3(256), 0, st, partial, out, splits, n,
                      accumulate);
   return check_launch("reduce_partials");

@@ -13,6 +13,7 @@
 // lanes, so that each lane ends up holding 4*NREP *consecutive* output columns of one output row: the epilogue
 // (bias / GELU / residual / layer-scale / drop-path scale / GELU-backward) runs on registers and stores 16-byte
 // vectors straight to HBM without an LDS round trip.
+#include <stdlib.h>
 #include "common.h"
 
 namespace tad {
@@ -55,15 +56,30 @@ __device__ __forceinline__ void stage_tile(const void* gbase, int gbytes, char* 
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(tile + (i * NW + wave) * 1024), 16, off[i] + add, 0, 0, 0);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+// wait until at most `stages_in_flight` later stages (LOADS DMA instructions each, per wave) are still outstanding
+template <int LOADS>
+__device__ __forceinline__ void wait_stage(int stages_in_flight) {
+  static_assert(2 * LOADS <= 63, "vmcnt immediate is 6 bits");
+  if (stages_in_flight >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
+  else if (stages_in_flight == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void block_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const GemmNT p) {
   constexpr int NW = WAVES_M * WAVES_N;
+  constexpr int LOADS = BM / (8 * NW) + BN / (8 * NW);
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   constexpr int MREP = WTM / 16, NREP = WTN / 16;
   constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES;
   constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
   static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split into 8-row DMA pieces per wave");
-  __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE_BYTES];
+  __shared__ __attribute__((aligned(1024))) char lds[STAGES * STAGE_BYTES];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -106,12 +122,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const Ge
     a_rd[i] = row * ROW_BYTES;
     a_sw[i] = sw_nt(row);
   }
-  // B-operand rows (output cols n), permuted: fragment lane c of n-rep j holds W row (c>>2)*(4*NREP) + 4j + (c&3)
+  // B-operand rows (output cols n), permuted so that the 4 lanes (kq = 0..3) that share an output row write one contiguous
+  // 64-byte segment per store instruction:
+  //   f32 output : fragment j, lane c -> W row 16j + 4*(c>>2) + (c&3)            (lane kq holds cols 16j + 4kq .. +3 : 16 B)
+  //   bf16 output: fragment j, lane c -> W row 32*(j>>1) + 8*(c>>2) + 4*(j&1) + (c&3)  (pair (j,j+1): cols 32(j>>1) + 8kq .. +7 : 16 B)
+  static_assert(NREP % 2 == 0, "bf16 epilogue pairs n-fragments");
   uint32_t b_rd[NREP];
   int b_sw[NREP];
 #pragma unroll
   for (int j = 0; j < NREP; ++j) {
-    const int row = wn * WTN + (c >> 2) * (4 * NREP) + j * 4 + (c & 3);
+    const int rl = p.c_bf16 ? (32 * (j >> 1) + 8 * (c >> 2) + 4 * (j & 1) + (c & 3)) : (16 * j + 4 * (c >> 2) + (c & 3));
+    const int row = wn * WTN + rl;
     b_rd[j] = row * ROW_BYTES;
     b_sw[j] = sw_nt(row);
   }
@@ -123,79 +144,143 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const Ge
     for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.K / BK;
-  STAGE_NT(0, 0);
+#pragma unroll
+  for (int st = 0; st < STAGES - 1; ++st)
+    if (st < nk) { STAGE_NT(st, st); }
+  int rd = 0, wr = STAGES - 1;
   for (int kt = 0; kt < nk; ++kt) {
-    __syncthreads();  // drains this wave's DMA (vmcnt(0)) and makes tile kt visible; all waves are done with tile kt-1
-    if (kt + 1 < nk) { STAGE_NT((kt + 1) & 1, kt + 1); }
-    const char* sa = lds + (kt & 1) * STAGE_BYTES;
+    // tile kt has landed once all but the younger stages' DMAs of this wave are done; the barrier then (a) publishes every
+    // wave's part of tile kt and (b) proves all waves finished reading tile kt-1, whose buffer the next DMA overwrites
+    wait_stage<LOADS>(min(STAGES - 2, nk - 1 - kt));
+    block_barrier();
+    const char* sa = lds + rd * STAGE_BYTES;
     const char* sb = sa + A_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[MREP], bfr[NREP];
-#pragma unroll
-      for (int j = 0; j < NREP; ++j)
-        bfr[j] = *reinterpret_cast<const bf16x8*>(sb + b_rd[j] + (((4 * ks + kq) ^ b_sw[j]) << 4));
-#pragma unroll
-      for (int i = 0; i < MREP; ++i)
-        af[i] = *reinterpret_cast<const bf16x8*>(sa + a_rd[i] + (((4 * ks + kq) ^ a_sw[i]) << 4));
-#pragma unroll
-      for (int i = 0; i < MREP; ++i)
-#pragma unroll
-        for (int j = 0; j < NREP; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-    }
+    const bool more = kt + STAGES - 1 < nk;
+    const int wr_now = wr, kt_next = kt + STAGES - 1;
+    rd = (rd + 1 == STAGES) ? 0 : rd + 1;
+    wr = (wr + 1 == STAGES) ? 0 : wr + 1;
+#define KSTEP_NT(ks)                                                                                   \
+  {                                                                                                    \
+    bf16x8 af[MREP], bfr[NREP];                                                                        \
+    _Pragma("unroll") for (int j = 0; j < NREP; ++j)                                                   \
+        bfr[j] = *reinterpret_cast<const bf16x8*>(sb + b_rd[j] + (((4 * (ks) + kq) ^ b_sw[j]) << 4));  \
+    _Pragma("unroll") for (int i = 0; i < MREP; ++i)                                                   \
+        af[i] = *reinterpret_cast<const bf16x8*>(sa + a_rd[i] + (((4 * (ks) + kq) ^ a_sw[i]) << 4));   \
+    _Pragma("unroll") for (int i = 0; i < MREP; ++i)                                                   \
+        _Pragma("unroll") for (int j = 0; j < NREP; ++j)                                               \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);    \
+  }
+    // Issuing a tile's LDS-DMA pieces blocks the issuing wave for ~100 cycles per piece.  The two waves that share a SIMD
+    // (wave w and w + NW/2) therefore issue them at different times: the older half before its first k-step, the younger
+    // half between its two k-steps, so the SIMD's matrix pipe always has one wave feeding it.
+    const bool late = wave >= NW / 2;  // wave-uniform (scalar branches); the MFMA code is shared by both halves
+    if (more && !late) { STAGE_NT(wr_now, kt_next); }
+    KSTEP_NT(0);
+    if (more && late) { STAGE_NT(wr_now, kt_next); }
+    KSTEP_NT(1);
   }
 
-  // ---- epilogue: lane holds rows m = m0 + wm*WTM + 16i + (lane&15), columns nb + 4j + r, nb = n0 + wn*WTN + (lane>>4)*4*NREP
-  const int nb = n0 + wn * WTN + kq * (4 * NREP);
+  // ---- epilogue on registers.  Lane (c = lane&15, kq = lane>>4) holds output row m = m0 + wm*WTM + 16i + c and, per n-fragment j,
+  // 4 consecutive columns (see the permutation above).  bf16 outputs are stored 16 bytes (two fragments) at a time.
+  const int nwave = n0 + wn * WTN;
 #pragma unroll
   for (int i = 0; i < MREP; ++i) {
     const int m = m0 + wm * WTM + i * 16 + c;
     if (m >= p.M) continue;
     const float rsc = p.rowscale ? p.rowscale[m / p.rows_per_scale] : 1.f;
     const int64_t rrow = p.res_mod > 0 ? (m % p.res_mod) : m;
+    if (!p.c_bf16) {
 #pragma unroll
-    for (int j = 0; j < NREP; ++j) {
-      const int n = nb + 4 * j;
-      if (n >= p.N) continue;
-      f32x4 v = acc[i][j];
-      if (p.bias) {
-        const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+      for (int j = 0; j < NREP; ++j) {
+        const int n = nwave + 16 * j + 4 * kq;
+        if (n >= p.N) continue;
+        f32x4 v = acc[i][j];
+        if (p.bias) {
+          const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+          v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        }
+        if (p.epi == EPI_GELU) {
+          if (p.preact) {
+            uint2 h;
+            h.x = pack_bf16x2(v[0], v[1]);
+            h.y = pack_bf16x2(v[2], v[3]);
+            *reinterpret_cast<uint2*>(p.preact + (int64_t)m * p.N + n) = h;
+          }
+          v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
+        } else if (p.epi == EPI_DGELU) {
+          const uint2 h = *reinterpret_cast<const uint2*>(p.dgelu_h + (int64_t)m * p.N + n);
+          v[0] *= gelu_erf_grad(__uint_as_float(h.x << 16));
+          v[1] *= gelu_erf_grad(__uint_as_float(h.x & 0xffff0000u));
+          v[2] *= gelu_erf_grad(__uint_as_float(h.y << 16));
+          v[3] *= gelu_erf_grad(__uint_as_float(h.y & 0xffff0000u));
+        } else if (p.epi == EPI_RESIDUAL) {
+          if (p.gamma) {
+            const float4 g = *reinterpret_cast<const float4*>(p.gamma + n);
+            v[0] *= g.x; v[1] *= g.y; v[2] *= g.z; v[3] *= g.w;
+          }
+          if (p.rowscale) { v[0] *= rsc; v[1] *= rsc; v[2] *= rsc; v[3] *= rsc; }
+          if (p.residual) {
+            const float4 r = *reinterpret_cast<const float4*>(p.residual + rrow * p.N + n);
+            v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+          }
+        }
+        *reinterpret_cast<float4*>((float*)p.C + (int64_t)m * p.N + n) = make_float4(v[0], v[1], v[2], v[3]);
       }
-      const int64_t o = (int64_t)m * p.N + n;
-      if (p.epi == EPI_GELU) {
-        if (p.preact) {
-          uint2 h;
-          h.x = pack_bf16x2(v[0], v[1]);
-          h.y = pack_bf16x2(v[2], v[3]);
-          *reinterpret_cast<uint2*>(p.preact + o) = h;
+    } else {
+#pragma unroll
+      for (int jp = 0; jp < NREP / 2; ++jp) {
+        const int n = nwave + 32 * jp + 8 * kq;
+        if (n >= p.N) continue;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = acc[i][2 * jp][e]; v[4 + e] = acc[i][2 * jp + 1][e]; }
+        const bool full = (n + 8 <= p.N);  // N % 4 == 0: either 8 or 4 valid columns
+        if (p.bias) {
+          const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n);
+          v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+          if (full) {
+            const float4 b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+            v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+          }
         }
-        v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
-      } else if (p.epi == EPI_DGELU) {
-        const uint2 h = *reinterpret_cast<const uint2*>(p.dgelu_h + o);
-        v[0] *= gelu_erf_grad(__uint_as_float(h.x << 16));
-        v[1] *= gelu_erf_grad(__uint_as_float(h.x & 0xffff0000u));
-        v[2] *= gelu_erf_grad(__uint_as_float(h.y << 16));
-        v[3] *= gelu_erf_grad(__uint_as_float(h.y & 0xffff0000u));
-      } else if (p.epi == EPI_RESIDUAL) {
-        if (p.gamma) {
-          const float4 g = *reinterpret_cast<const float4*>(p.gamma + n);
-          v[0] *= g.x; v[1] *= g.y; v[2] *= g.z; v[3] *= g.w;
+        const int64_t o = (int64_t)m * p.N + n;
+        if (p.epi == EPI_GELU) {
+          if (p.preact) {
+            uint4 h;
+            h.x = pack_bf16x2(v[0], v[1]); h.y = pack_bf16x2(v[2], v[3]); h.z = pack_bf16x2(v[4], v[5]); h.w = pack_bf16x2(v[6], v[7]);
+            if (full) *reinterpret_cast<uint4*>(p.preact + o) = h;
+            else *reinterpret_cast<uint2*>(p.preact + o) = make_uint2(h.x, h.y);
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+        } else if (p.epi == EPI_DGELU) {
+          uint4 h = make_uint4(0, 0, 0, 0);
+          if (full) h = *reinterpret_cast<const uint4*>(p.dgelu_h + o);
+          else { const uint2 t = *reinterpret_cast<const uint2*>(p.dgelu_h + o); h.x = t.x; h.y = t.y; }
+          const uint32_t hw[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[2 * e] *= gelu_erf_grad(__uint_as_float(hw[e] << 16));
+            v[2 * e + 1] *= gelu_erf_grad(__uint_as_float(hw[e] & 0xffff0000u));
+          }
+        } else if (p.epi == EPI_RESIDUAL) {
+          if (p.gamma) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (e < 4 || full) v[e] *= p.gamma[n + e];
+          }
+          if (p.rowscale) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= rsc;
+          }
+          if (p.residual) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (e < 4 || full) v[e] += p.residual[rrow * p.N + n + e];
+          }
         }
-        if (p.rowscale) { v[0] *= rsc; v[1] *= rsc; v[2] *= rsc; v[3] *= rsc; }
-        if (p.residual) {
-          const float4 r = *reinterpret_cast<const float4*>(p.residual + rrow * p.N + n);
-          v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
-        }
-      }
-      if (p.c_bf16) {
-        uint2 ob;
-        ob.x = pack_bf16x2(v[0], v[1]);
-        ob.y = pack_bf16x2(v[2], v[3]);
-        *reinterpret_cast<uint2*>((uint16_t*)p.C + o) = ob;
-      } else {
-        *reinterpret_cast<float4*>((float*)p.C + o) = make_float4(v[0], v[1], v[2], v[3]);
+        uint4 ob;
+        ob.x = pack_bf16x2(v[0], v[1]); ob.y = pack_bf16x2(v[2], v[3]); ob.z = pack_bf16x2(v[4], v[5]); ob.w = pack_bf16x2(v[6], v[7]);
+        if (full) *reinterpret_cast<uint4*>((uint16_t*)p.C + o) = ob;
+        else *reinterpret_cast<uint2*>((uint16_t*)p.C + o) = make_uint2(ob.x, ob.y);
       }
     }
   }
@@ -230,7 +315,7 @@ __device__ __forceinline__ bf16x8 tr_frag_tn(const char* base, int rowbytes, int
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(const GemmTN p) {
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
@@ -242,17 +327,23 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(const Ge
   constexpr int P_LPR = PROW / 16, Q_LPR = QROW / 16;  // lanes (16-B chunks) per row
   static_assert(P_BYTES % (1024 * NW) == 0 && Q_BYTES % (1024 * NW) == 0, "tile must split into 1-KiB DMA pieces per wave");
   static_assert(P_LPR <= 64 && Q_LPR <= 64 && PROW >= 256 && QROW >= 256, "row length");
-  __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE_BYTES];
+  constexpr int LOADS = P_PIECES + Q_PIECES;
+  __shared__ __attribute__((aligned(1024))) char lds[STAGES * STAGE_BYTES];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
+  // linear id = split * tiles + tile, remapped so that one XCD runs (mostly) one split: the workgroups that stream the same
+  // rows of dy / x then share them through that XCD's L2 instead of each fetching them from HBM
   const int tiles_k = (p.K + BN - 1) / BN;
-  const int tn_ = blockIdx.x / tiles_k, tk_ = blockIdx.x - tn_ * tiles_k;
+  const int tiles = tiles_k * ((p.N + BM - 1) / BM);
+  const int lin = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = lin / tiles;
+  const int tile = lin - split * tiles;
+  const int tn_ = tile / tiles_k, tk_ = tile - tn_ * tiles_k;
   const int n0 = tn_ * BM, k0 = tk_ * BN;
-  const int split = blockIdx.y;
   const int mr0 = split * p.rows_per_split;
   const int nt = p.rows_per_split / BK;
 
@@ -293,25 +384,33 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(const Ge
     for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 
-  STAGE_TN(0, 0);
+#pragma unroll
+  for (int st = 0; st < STAGES - 1; ++st)
+    if (st < nt) { STAGE_TN(st, st); }
+  int rd = 0, wr = STAGES - 1;
   for (int t = 0; t < nt; ++t) {
-    __syncthreads();
-    if (t + 1 < nt) { STAGE_TN((t + 1) & 1, t + 1); }
-    const char* sp = lds + (t & 1) * STAGE_BYTES;
+    wait_stage<LOADS>(min(STAGES - 2, nt - 1 - t));
+    block_barrier();
+    const char* sp = lds + rd * STAGE_BYTES;
     const char* sq = sp + P_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 pf[MREP], qf[NREP];
-#pragma unroll
-      for (int j = 0; j < NREP; ++j) qf[j] = tr_frag_tn(sq, QROW, ks, wn * WTN + 16 * j, lane);
-#pragma unroll
-      for (int i = 0; i < MREP; ++i) pf[i] = tr_frag_tn(sp, PROW, ks, wm * WTM + 16 * i, lane);
-#pragma unroll
-      for (int i = 0; i < MREP; ++i)
-#pragma unroll
-        for (int j = 0; j < NREP; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[i], qf[j], acc[i][j], 0, 0, 0);
-    }
+    const bool more = t + STAGES - 1 < nt;
+    const int wr_now = wr, t_next = t + STAGES - 1;
+    rd = (rd + 1 == STAGES) ? 0 : rd + 1;
+    wr = (wr + 1 == STAGES) ? 0 : wr + 1;
+#define KSTEP_TN(ks)                                                                                        \
+  {                                                                                                         \
+    bf16x8 pf[MREP], qf[NREP];                                                                              \
+    _Pragma("unroll") for (int j = 0; j < NREP; ++j) qf[j] = tr_frag_tn(sq, QROW, (ks), wn * WTN + 16 * j, lane);  \
+    _Pragma("unroll") for (int i = 0; i < MREP; ++i) pf[i] = tr_frag_tn(sp, PROW, (ks), wm * WTM + 16 * i, lane);  \
+    _Pragma("unroll") for (int i = 0; i < MREP; ++i)                                                        \
+        _Pragma("unroll") for (int j = 0; j < NREP; ++j)                                                    \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[i], qf[j], acc[i][j], 0, 0, 0);          \
+  }
+    const bool late = wave >= NW / 2;  // stagger the DMA issue of the two waves that share a SIMD (see gemm_nt_kernel)
+    if (more && !late) { STAGE_TN(wr_now, t_next); }
+    KSTEP_TN(0);
+    if (more && late) { STAGE_TN(wr_now, t_next); }
+    KSTEP_TN(1);
   }
 
   // D[row = n][col = k]: lane col = lane&15, rows 4*(lane>>4) + r
@@ -330,10 +429,42 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(const Ge
 }
 
 // ------------------------------------------------------------------------------------------------------------
+static int env_int(const char* name) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : 0;
+}
+
+// Tile configurations.  NT: 1 = 256x256 (2x4 waves) 2 stages; 2 = 128x128 (2x2) 2 stages, 2 workgroups/CU;
+// 3 = 256x128 (4x2) 3 stages; 4 = 128x256 (2x4) 3 stages; 5 = 256x128 2 stages.  0 = auto.
+int launch_gemm_nt(const GemmNT& p, hipStream_t st) {
+  if (!(p.M > 0 && p.N > 0 && p.K > 0)) { set_error("gemm_nt: empty problem"); return TAD_EINVAL; }
+  if (p.K % BK) { set_error("gemm_nt: K=%d must be a multiple of %d", p.K, BK); return TAD_EINVAL; }
+  if (p.N % 4) { set_error("gemm_nt: N=%d must be a multiple of 4", p.N); return TAD_EINVAL; }
+  if ((int64_t)p.M * p.K * 2 >= (1ll << 32) || (int64_t)p.N * p.K * 2 >= (1ll << 32)) { set_error("gemm_nt: operand exceeds 4 GiB"); return TAD_EINVAL; }
+  static const int forced = env_int("TAD_GEMM_NT_VARIANT");
+  int v = forced;
+  if (v == 0) v = (p.M >= 2048 && p.N >= 128) ? 3 : 2;
+  auto tiles = [&](int bm, int bn) { return ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+  switch (v) {
+    case 1: hipLaunchKernelGGL((gemm_nt_kernel<256, 256, 2, 4, 2>), dim3(tiles(256, 256)), dim3(512), 0, st, p); break;
+    case 3: hipLaunchKernelGGL((gemm_nt_kernel<256, 128, 4, 2, 3>), dim3(tiles(256, 128)), dim3(512), 0, st, p); break;
+    case 4: hipLaunchKernelGGL((gemm_nt_kernel<128, 256, 2, 4, 3>), dim3(tiles(128, 256)), dim3(512), 0, st, p); break;
+    case 5: hipLaunchKernelGGL((gemm_nt_kernel<256, 128, 4, 2, 2>), dim3(tiles(256, 128)), dim3(512), 0, st, p); break;
+    default: hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 2, 2, 2>), dim3(tiles(128, 128)), dim3(256), 0, st, p); break;
+  }
+  return check_launch("gemm_nt");
+}
+
+// TN: 1 = 256x256 (2x4) 2 stages; 3 = 256x128 (4x2) 3 stages.  Splits over the reduction dim target ~1 workgroup per CU.
+static int tn_variant() {
+  static const int forced = env_int("TAD_GEMM_TN_VARIANT");
+  return forced ? forced : 1;
+}
 static int tn_plan(int64_t Mr, int N, int K, int* splits, int* rows_per_split) {
-  const int tiles = ((N + 255) / 256) * ((K + 255) / 256);
+  const int bn = tn_variant() == 1 ? 256 : 128;
+  const int tiles = ((N + 255) / 256) * ((K + bn - 1) / bn);
   const int64_t ktiles = (Mr + BK - 1) / BK;
-  int s = (256 + tiles - 1) / tiles;  // aim for ~256 workgroups (one per CU)
+  int s = (256 + tiles - 1) / tiles;
   if (s > ktiles) s = (int)ktiles;
   if (s < 1) s = 1;
   const int64_t per = (ktiles + s - 1) / s;
@@ -341,22 +472,6 @@ static int tn_plan(int64_t Mr, int N, int K, int* splits, int* rows_per_split) {
   *splits = s;
   *rows_per_split = (int)(per * BK);
   return tiles;
-}
-
-int launch_gemm_nt(const GemmNT& p, hipStream_t st) {
-  if (!(p.M > 0 && p.N > 0 && p.K > 0)) { set_error("gemm_nt: empty problem"); return TAD_EINVAL; }
-  if (p.K % BK) { set_error("gemm_nt: K=%d must be a multiple of %d", p.K, BK); return TAD_EINVAL; }
-  if (p.N % 4) { set_error("gemm_nt: N=%d must be a multiple of 4", p.N); return TAD_EINVAL; }
-  if ((int64_t)p.M * p.K * 2 >= (1ll << 32) || (int64_t)p.N * p.K * 2 >= (1ll << 32) ) { set_error("gemm_nt: operand exceeds 4 GiB"); return TAD_EINVAL; }
-  const bool big = (p.N % 256 == 0 || p.N >= 1024) && p.M >= 2048;
-  if (big) {
-    const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
-    hipLaunchKernelGGL((gemm_nt_kernel<256, 256, 2, 4>), dim3(tiles), dim3(512), 0, st, p);
-  } else {
-    const int tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128);
-    hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 2, 2>), dim3(tiles), dim3(256), 0, st, p);
-  }
-  return check_launch("gemm_nt");
 }
 
 size_t gemm_tn_workspace_bytes(int64_t Mr, int N, int K) {
@@ -375,7 +490,10 @@ int launch_gemm_tn(const uint16_t* P, const uint16_t* Q, float* out, int accumul
   int splits;
   const int tiles = tn_plan(Mr, N, K, &splits, &p.rows_per_split);
   if (ws_bytes < (size_t)splits * N * K * sizeof(float)) { set_error("gemm_tn: workspace too small"); return TAD_ENOSPACE; }
-  hipLaunchKernelGGL((gemm_tn_kernel<256, 256, 2, 4>), dim3(tiles, splits), dim3(512), 0, st, p);
+  if (tn_variant() == 1)
+    hipLaunchKernelGGL((gemm_tn_kernel<256, 256, 2, 4, 2>), dim3(tiles * splits), dim3(512), 0, st, p);
+  else
+    hipLaunchKernelGGL((gemm_tn_kernel<256, 128, 4, 2, 3>), dim3(tiles * splits), dim3(512), 0, st, p);
   int rc = check_launch("gemm_tn");
   if (rc) return rc;
   return launch_reduce_partials(p.slab, out, splits, (int64_t)N * K, accumulate, st);

@@ -9,6 +9,8 @@ namespace tad {
 constexpr int LN_MAX_V = 8;  // float4 per lane -> D <= 64*4*8 = 2048
 
 int launch_reduce_partials(const float* partial, float* out, int splits, int64_t n, int accumulate, hipStream_t st);
+int launch_reduce_cols(const float* partial, float* out0, float* out1, float* out2, int nq, int splits, int n, int accumulate,
+                       hipStream_t st);
 
 template <int NV, bool OUT_BF16>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
@@ -241,11 +243,7 @@ int tad_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float*
 #undef LN_BWD
   int rc = check_launch("layernorm_bwd");
   if (rc) return rc;
-  rc = launch_reduce_partials(partial, dgamma, blocks, D, 0, st);
-  if (rc) return rc;
-  rc = launch_reduce_partials(partial + (int64_t)blocks * D, dbeta, blocks, D, 0, st);
-  if (rc) return rc;
-  if (colsum_dx) rc = launch_reduce_partials(partial + (int64_t)2 * blocks * D, colsum_dx, blocks, D, 0, st);
+  rc = launch_reduce_cols(partial, dgamma, dbeta, colsum_dx, colsum_dx ? 3 : 2, blocks, D, 0, st);
   return rc;
 }
 

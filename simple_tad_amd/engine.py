@@ -1,0 +1,207 @@
+"""Thin counterparts of the training-runtime pieces the fine-tune hot loop needs
+(reference: engine_for_finetuning.py:24-140, utils.py:386-447, optim_factory.py:24-127).
+
+Same step ordering as ``engine_for_finetuning.train_one_epoch``: per-step lr/wd assignment from the
+schedule tables, forward, loss, ``loss.item()`` finiteness check, backward, gradient norm / clipping,
+optimizer step, ``zero_grad``, device synchronise, meters.  Differences, by design: bf16 MFMA kernels
+need no loss scaling (the scaler keeps the reference's interface and reports ``scale == 1.0``), and the
+gradient all-reduce is the bucketed RCCL exchange of ``parallel.DataParallel``.
+"""
+from __future__ import annotations
+
+import json
+import math
+import sys
+from typing import Iterable, Optional
+
+import numpy as np
+import torch
+
+from . import kernels as K
+from .parallel import DataParallel
+
+
+def cosine_scheduler(base_value, final_value, epochs, niter_per_ep, warmup_epochs=0, start_warmup_value=0, warmup_steps=-1):
+    """utils.cosine_scheduler (utils.py:430-447): linear warm-up then half-cosine, one value per iteration."""
+    warmup_iters = warmup_steps if warmup_steps > 0 else warmup_epochs * niter_per_ep
+    warm = np.linspace(start_warmup_value, base_value, warmup_iters) if warmup_epochs > 0 else np.array([])
+    n = epochs * niter_per_ep - warmup_iters
+    cos = np.array([final_value + 0.5 * (base_value - final_value) * (1 + math.cos(math.pi * i / n)) for i in range(n)])
+    schedule = np.concatenate((warm, cos))
+    assert len(schedule) == epochs * niter_per_ep
+    return schedule
+
+
+def get_num_layer_for_vit(var_name, num_max_layer):
+    """optim_factory.py:24-35"""
+    if var_name in ("cls_token", "mask_token", "pos_embed") or var_name.startswith("patch_embed"):
+        return 0
+    if var_name.startswith("rel_pos_bias"):
+        return num_max_layer - 1
+    if var_name.startswith("blocks"):
+        return int(var_name.split('.')[1]) + 1
+    return num_max_layer - 1
+
+
+class LayerDecayValueAssigner:
+    """optim_factory.py:38-46; values = [decay ** (L + 1 - i) for i in range(L + 2)] (run_class_finetuning.py:430-434)"""
+
+    def __init__(self, values):
+        self.values = values
+
+    @classmethod
+    def from_decay(cls, layer_decay: float, num_layers: int):
+        return cls([layer_decay ** (num_layers + 1 - i) for i in range(num_layers + 2)])
+
+    def get_scale(self, layer_id):
+        return self.values[layer_id]
+
+    def get_layer_id(self, var_name):
+        return get_num_layer_for_vit(var_name, len(self.values))
+
+
+def get_parameter_groups(model, weight_decay=1e-5, skip_list=(), get_num_layer=None, get_layer_scale=None, verbose=False):
+    """optim_factory.get_parameter_groups (optim_factory.py:49-88): 1-D / .bias / skip-listed -> no decay; optional
+    per-layer groups carrying ``lr_scale``."""
+    names, groups = {}, {}
+    for name, param in model.named_parameters():
+        if not param.requires_grad:
+            continue
+        if len(param.shape) == 1 or name.endswith(".bias") or name in skip_list:
+            group_name, wd = "no_decay", 0.
+        else:
+            group_name, wd = "decay", weight_decay
+        layer_id = None
+        if get_num_layer is not None:
+            layer_id = get_num_layer(name)
+            group_name = "layer_%d_%s" % (layer_id, group_name)
+        if group_name not in groups:
+            scale = get_layer_scale(layer_id) if get_layer_scale is not None else 1.
+            names[group_name] = {"weight_decay": wd, "params": [], "lr_scale": scale}
+            groups[group_name] = {"weight_decay": wd, "params": [], "lr_scale": scale}
+        groups[group_name]["params"].append(param)
+        names[group_name]["params"].append(name)
+    if verbose:
+        print("Param groups = %s" % json.dumps(names, indent=2))
+    return list(groups.values())
+
+
+def create_optimizer(model, lr, weight_decay=0.05, betas=(0.9, 0.999), eps=1e-8, layer_decay: Optional[float] = None,
+                     skip_list=None):
+    """AdamW over the reference's parameter groups (optim_factory.create_optimizer with opt='adamw',
+    optim_factory.py:91-127); the rest of the reference's optimizer zoo is out of scope."""
+    inner = model.module if isinstance(model, DataParallel) else model
+    skip = set(skip_list) if skip_list is not None else (inner.no_weight_decay() if hasattr(inner, "no_weight_decay") else set())
+    assigner = LayerDecayValueAssigner.from_decay(layer_decay, inner.get_num_layers()) if layer_decay and layer_decay < 1.0 else None
+    groups = get_parameter_groups(inner, weight_decay, skip, assigner.get_layer_id if assigner else None,
+                                  assigner.get_scale if assigner else None)
+    fused = all(p.is_cuda for g in groups for p in g["params"])
+    return torch.optim.AdamW(groups, lr=lr, betas=betas, eps=eps, weight_decay=0.0, fused=fused)
+
+
+def get_grad_norm_(parameters, norm_type: float = 2.0) -> torch.Tensor:
+    """utils.get_grad_norm_ (utils.py:415-427) for norm_type 2: norm(stack(norm(g))) == sqrt(sum ||g||^2).
+    On GPU the sum of squares runs through tad_sumsq_f32 (one pass over the gradients)."""
+    if isinstance(parameters, torch.Tensor):
+        parameters = [parameters]
+    grads = [p.grad for p in parameters if p.grad is not None]
+    if not grads:
+        return torch.tensor(0.)
+    assert float(norm_type) == 2.0, "only the L2 norm is used by the reference's engines"
+    if grads[0].is_cuda:
+        acc = torch.zeros(1, dtype=torch.float32, device=grads[0].device)
+        for g in grads:
+            K.sumsq(g.detach().reshape(-1) if g.is_contiguous() else g.detach().contiguous().reshape(-1), acc)
+        return acc.sqrt()[0]
+    return torch.norm(torch.stack([torch.norm(g.detach(), 2.0) for g in grads]), 2.0)
+
+
+class NativeScalerWithGradNormCount:
+    """Interface of utils.NativeScalerWithGradNormCount (utils.py:386-412).  bf16 kernels need no loss scaling, so
+    scale == 1.0 always; backward -> (all-reduce wait) -> clip or norm -> optimizer.step."""
+    state_dict_key = "amp_scaler"
+
+    def __init__(self, model: Optional[torch.nn.Module] = None):
+        self.model = model
+
+    def __call__(self, loss, optimizer, clip_grad=None, parameters=None, create_graph=False, update_grad=True):
+        dp = self.model if isinstance(self.model, DataParallel) else None
+        if dp is not None:
+            dp.require_sync = bool(update_grad)  # gradient accumulation: exchange only on the last micro-step
+        loss.backward(create_graph=create_graph)
+        if not update_grad:
+            return None
+        if dp is not None:
+            dp.finish()
+        if clip_grad is not None and clip_grad > 0:
+            assert parameters is not None
+            norm = torch.nn.utils.clip_grad_norm_(parameters, clip_grad)
+        else:
+            if dp is not None:
+                acc = torch.zeros(1, dtype=torch.float32, device=dp.flat_grad.device)
+                norm = (K.sumsq(dp.flat_grad, acc).sqrt()[0] if dp.flat_grad.is_cuda else dp.flat_grad.norm())
+            else:
+                norm = get_grad_norm_(parameters)
+        optimizer.step()
+        return norm
+
+    def state_dict(self):
+        return {"scale": 1.0}
+
+    def load_state_dict(self, state_dict):
+        pass
+
+
+def train_class_batch(model, samples, target, criterion):
+    """engine_for_finetuning.py:13-16"""
+    outputs = model(samples)
+    loss = criterion(outputs, target)
+    return loss, outputs
+
+
+def train_one_epoch(model: torch.nn.Module, criterion, data_loader: Iterable, optimizer, device, epoch: int, loss_scaler,
+                    max_norm: float = 0, start_steps=0, lr_schedule_values=None, wd_schedule_values=None,
+                    num_training_steps_per_epoch=None, update_freq=1, log=None):
+    """engine_for_finetuning.train_one_epoch (engine_for_finetuning.py:24-140) without mixup / EMA / DeepSpeed branches.
+    The loader yields (samples [B,3,T,H,W], targets [B], *rest)."""
+    model.train(True)
+    dp = model if isinstance(model, DataParallel) else None
+    zero = (dp.zero_grad if dp is not None else lambda: optimizer.zero_grad(set_to_none=False))
+    zero()
+    stats = {"loss": [], "class_acc": [], "grad_norm": [], "lr": [], "min_lr": [], "loss_scale": []}
+    params = [p for p in model.parameters() if p.requires_grad]
+    for data_iter_step, batch in enumerate(data_loader):
+        samples, targets = batch[0], batch[1]
+        step = data_iter_step // update_freq
+        if num_training_steps_per_epoch is not None and step >= num_training_steps_per_epoch:
+            continue
+        it = start_steps + step
+        if (lr_schedule_values is not None or wd_schedule_values is not None) and data_iter_step % update_freq == 0:
+            for group in optimizer.param_groups:
+                if lr_schedule_values is not None:
+                    group["lr"] = lr_schedule_values[it] * group.get("lr_scale", 1.0)
+                if wd_schedule_values is not None and group["weight_decay"] > 0:
+                    group["weight_decay"] = wd_schedule_values[it]
+        samples = samples.to(device, non_blocking=True)
+        targets = targets.to(device, non_blocking=True)
+        loss, output = train_class_batch(model, samples, targets, criterion)
+        loss_value = loss.item()
+        if not math.isfinite(loss_value):
+            print("Loss is {}, stopping training".format(loss_value))
+            sys.exit(1)
+        loss = loss / update_freq
+        last = (data_iter_step + 1) % update_freq == 0
+        grad_norm = loss_scaler(loss, optimizer, clip_grad=max_norm if max_norm else None, parameters=params, update_grad=last)
+        if last:
+            zero()
+        if device.type == "cuda":
+            torch.cuda.synchronize()
+        stats["loss"].append(loss_value)
+        stats["class_acc"].append((output.max(-1)[-1] == targets).float().mean().item())
+        stats["grad_norm"].append(None if grad_norm is None else float(grad_norm))
+        stats["loss_scale"].append(loss_scaler.state_dict()["scale"])
+        stats["lr"].append(max(g["lr"] for g in optimizer.param_groups))
+        stats["min_lr"].append(min(g["lr"] for g in optimizer.param_groups))
+        if log is not None:
+            log(epoch, data_iter_step, stats)
+    return stats

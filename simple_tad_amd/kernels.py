@@ -15,6 +15,57 @@ from ._lib import EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, TAD_BF16, TAD_F32,
 _workspaces = {}
 
 
+class LaunchProfiler:
+    """Optional per-launch timing with HIP events on the launching stream (used by bench.py for the live roofline figure).
+    ``record(kernel, flops, bytes)`` brackets one C-ABI call; ``summary()`` synchronises and aggregates per kernel class."""
+
+    def __init__(self):
+        self.items = []
+
+    def begin(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream())
+        return e
+
+    def end(self, start, kernel, flops, nbytes):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream())
+        self.items.append((kernel, start, e, flops, nbytes))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for kernel, s, e, flops, nbytes in self.items:
+            d = out.setdefault(kernel, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            d["launches"] += 1
+            d["ms"] += s.elapsed_time(e)
+            d["flops"] += flops
+            d["bytes"] += nbytes
+        return out
+
+
+_prof = None
+
+
+def set_profiler(p):
+    global _prof
+    _prof = p
+
+
+class _timed:
+    __slots__ = ("k", "f", "b", "s")
+
+    def __init__(self, kernel, flops=0.0, nbytes=0.0):
+        self.k, self.f, self.b = kernel, flops, nbytes
+
+    def __enter__(self):
+        self.s = _prof.begin() if _prof is not None else None
+
+    def __exit__(self, *a):
+        if self.s is not None:
+            _prof.end(self.s, self.k, self.f, self.b)
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -56,7 +107,8 @@ def cast_bf16(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tens
     _req(x, torch.float32, "cast_bf16.x")
     if out is None:
         out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
-    check(_lib.load().tad_cast_f32_bf16(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "tad_cast_f32_bf16")
+    with _timed("cast", 0.0, 6.0 * x.numel()):
+        check(_lib.load().tad_cast_f32_bf16(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "tad_cast_f32_bf16")
     return out
 
 
@@ -73,8 +125,9 @@ def scale_cast_bf16(x, gamma=None, rowscale=None, rows_per_scale=1):
     _req(x, torch.float32, "scale_cast.x")
     M, N = x.shape
     out = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
-    check(_lib.load().tad_scale_cast_bf16(x.data_ptr(), out.data_ptr(), _p(gamma), _p(rowscale), int(rows_per_scale), M, N,
-                                          _stream()), "tad_scale_cast_bf16")
+    with _timed("cast", 0.0, 6.0 * M * N):
+        check(_lib.load().tad_scale_cast_bf16(x.data_ptr(), out.data_ptr(), _p(gamma), _p(rowscale), int(rows_per_scale), M, N,
+                                              _stream()), "tad_scale_cast_bf16")
     return out
 
 
@@ -106,8 +159,9 @@ def patch_embed_fwd(x, w_bf16, bias, pos, tubelet: int, patch: int):
         _req(bias, torch.float32, "patch_embed.bias")
     cols = torch.empty((B * ntok, K), dtype=torch.bfloat16, device=x.device)
     out = torch.empty((B, ntok, D), dtype=torch.float32, device=x.device)
-    check(_lib.load().tad_patch_embed_fwd(x.data_ptr(), w_bf16.data_ptr(), _p(bias), _p(pos), out.data_ptr(), cols.data_ptr(),
-                                          B, Cc, T, H, W, tubelet, patch, D, _stream()), "tad_patch_embed_fwd")
+    with _timed("patch_embed_fwd", 2.0 * B * ntok * D * K, 4.0 * x.numel() + 2.0 * 2 * B * ntok * K + 4.0 * B * ntok * D):
+        check(_lib.load().tad_patch_embed_fwd(x.data_ptr(), w_bf16.data_ptr(), _p(bias), _p(pos), out.data_ptr(), cols.data_ptr(),
+                                              B, Cc, T, H, W, tubelet, patch, D, _stream()), "tad_patch_embed_fwd")
     return out, cols
 
 
@@ -121,8 +175,9 @@ def layernorm_fwd(x, gamma, beta, eps: float, out_dtype=torch.bfloat16, save_sta
     y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
     mean = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
-    check(_lib.load().tad_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _dt(y), _p(mean), _p(rstd),
-                                        rows, D, float(eps), _stream()), "tad_layernorm_fwd")
+    with _timed("layernorm_fwd", 0.0, rows * D * (4.0 + y.element_size())):
+        check(_lib.load().tad_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _dt(y), _p(mean), _p(rstd),
+                                            rows, D, float(eps), _stream()), "tad_layernorm_fwd")
     return y, mean, rstd
 
 
@@ -143,9 +198,10 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, want_bf16=False, want_col
     lib = _lib.load()
     nbytes = lib.tad_layernorm_bwd_workspace_bytes(rows, D)
     ws = workspace(nbytes, x.device)
-    check(lib.tad_layernorm_bwd(dy.data_ptr(), _dt(dy), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(dres),
-                                dx.data_ptr(), _p(dxb), dg.data_ptr(), db.data_ptr(), _p(cs), ws.data_ptr(), ws.numel(), rows, D,
-                                _stream()), "tad_layernorm_bwd")
+    with _timed("layernorm_bwd", 0.0, rows * D * (dy.element_size() + 4.0 + 4.0 + (4.0 if dres is not None else 0.0) + (2.0 if want_bf16 else 0.0))):
+        check(lib.tad_layernorm_bwd(dy.data_ptr(), _dt(dy), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(dres),
+                                    dx.data_ptr(), _p(dxb), dg.data_ptr(), db.data_ptr(), _p(cs), ws.data_ptr(), ws.numel(), rows, D,
+                                    _stream()), "tad_layernorm_bwd")
     return dx, dxb, dg, db, cs
 
 
@@ -167,8 +223,9 @@ def linear_fwd(x, w, bias=None, out_dtype=torch.bfloat16, epilogue=EPI_BIAS, wan
         assert tuple(residual.shape) == (M, N)
     y = torch.empty((M, N), dtype=out_dtype, device=x.device)
     pre = torch.empty((M, N), dtype=torch.bfloat16, device=x.device) if want_preact else None
-    check(_lib.load().tad_linear_fwd(x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), _dt(y), epilogue, _p(pre), _p(residual),
-                                     _p(gamma), _p(rowscale), int(rows_per_scale), M, N, K, _stream()), "tad_linear_fwd")
+    with _timed("gemm_nt", 2.0 * M * N * K, 2.0 * (M * K + N * K) + y.element_size() * M * N):
+        check(_lib.load().tad_linear_fwd(x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), _dt(y), epilogue, _p(pre), _p(residual),
+                                         _p(gamma), _p(rowscale), int(rows_per_scale), M, N, K, _stream()), "tad_linear_fwd")
     return y, pre
 
 
@@ -183,8 +240,9 @@ def linear_bwd_input(dy, wT, out_dtype=torch.bfloat16, gelu_preact=None):
         _req(gelu_preact, torch.bfloat16, "linear_bwd_input.gelu_preact")
         assert tuple(gelu_preact.shape) == (M, K)
     dx = torch.empty((M, K), dtype=out_dtype, device=dy.device)
-    check(_lib.load().tad_linear_bwd_input(dy.data_ptr(), wT.data_ptr(), dx.data_ptr(), _dt(dx), _p(gelu_preact), M, N, K, _stream()),
-          "tad_linear_bwd_input")
+    with _timed("gemm_nt", 2.0 * M * N * K, 2.0 * (M * N + N * K) + dx.element_size() * M * K):
+        check(_lib.load().tad_linear_bwd_input(dy.data_ptr(), wT.data_ptr(), dx.data_ptr(), _dt(dx), _p(gelu_preact), M, N, K, _stream()),
+              "tad_linear_bwd_input")
     return dx
 
 
@@ -202,8 +260,9 @@ def linear_bwd_weight(dy, x, want_bias=True, dW=None, db=None, accumulate=False)
         db = torch.empty(N, dtype=torch.float32, device=dy.device)
     lib = _lib.load()
     ws = workspace(lib.tad_linear_bwd_weight_workspace_bytes(M, N, K), dy.device)
-    check(lib.tad_linear_bwd_weight(dy.data_ptr(), x.data_ptr(), dW.data_ptr(), _p(db) if want_bias else None, int(accumulate),
-                                    ws.data_ptr(), ws.numel(), M, N, K, _stream()), "tad_linear_bwd_weight")
+    with _timed("gemm_tn", 2.0 * M * N * K, 2.0 * (M * N + M * K) + 4.0 * N * K):
+        check(lib.tad_linear_bwd_weight(dy.data_ptr(), x.data_ptr(), dW.data_ptr(), _p(db) if want_bias else None, int(accumulate),
+                                        ws.data_ptr(), ws.numel(), M, N, K, _stream()), "tad_linear_bwd_weight")
     return dW, (db if want_bias else None)
 
 
@@ -214,7 +273,8 @@ def colsum_bf16(a, out=None):
         out = torch.empty(N, dtype=torch.float32, device=a.device)
     lib = _lib.load()
     ws = workspace(lib.tad_colsum_workspace_bytes(M, N), a.device)
-    check(lib.tad_colsum_bf16(a.data_ptr(), out.data_ptr(), 0, ws.data_ptr(), ws.numel(), M, N, _stream()), "tad_colsum_bf16")
+    with _timed("colsum", 0.0, 2.0 * M * N):
+        check(lib.tad_colsum_bf16(a.data_ptr(), out.data_ptr(), 0, ws.data_ptr(), ws.numel(), M, N, _stream()), "tad_colsum_bf16")
     return out
 
 
@@ -226,8 +286,9 @@ def attn_fwd(qkv, B: int, N: int, H: int, scale: float, out_dtype=torch.bfloat16
         raise _lib.TadError(f"attn_fwd: qkv has {qkv.numel()} elements, expected {B * N * 3 * H * 64}")
     out = torch.empty((B * N, H * 64), dtype=out_dtype, device=qkv.device)
     lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device) if want_lse else None
-    check(_lib.load().tad_attn_fwd(qkv.data_ptr(), out.data_ptr(), _dt(out), _p(lse), B, N, H, 64, float(scale), _stream()),
-          "tad_attn_fwd")
+    with _timed("attn_fwd", 4.0 * B * H * N * N * 64, 2.0 * 4 * B * N * H * 64):
+        check(_lib.load().tad_attn_fwd(qkv.data_ptr(), out.data_ptr(), _dt(out), _p(lse), B, N, H, 64, float(scale), _stream()),
+              "tad_attn_fwd")
     return out, lse
 
 
@@ -237,8 +298,9 @@ def attn_bwd(qkv, out, dout, lse, B: int, N: int, H: int, scale: float):
     _req(lse, torch.float32, "attn_bwd.lse")
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
-    check(_lib.load().tad_attn_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), delta.data_ptr(),
-                                   B, N, H, 64, float(scale), _stream()), "tad_attn_bwd")
+    with _timed("attn_bwd", 8.0 * B * H * N * N * 64, 2.0 * 8 * B * N * H * 64):
+        check(_lib.load().tad_attn_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), delta.data_ptr(),
+                                       B, N, H, 64, float(scale), _stream()), "tad_attn_bwd")
     return dqkv
 
 

@@ -1,0 +1,143 @@
+"""Data-parallel gradient exchange for the fine-tuning step: one process per GPU, model replicated,
+clip batch sharded, ONE exchange per optimizer step = all-reduce(mean) of the gradients.
+
+Replaces the reference's ``torch.nn.parallel.DistributedDataParallel`` wrap
+(run_class_finetuning.py:446-448, run_frame_finetuning.py:539-541) and ``utils.init_distributed_mode``
+(utils.py:283-333).  Transport is RCCL over xGMI through ``torch.distributed`` (backend "nccl" on ROCm);
+on CPU the same code runs over gloo (tests).
+
+Design for xGMI (point-to-point links, ring collectives are per-link bound):
+  * all gradients live in ONE flat f32 buffer laid out in reverse registration order (head first, patch-embed
+    last), i.e. roughly the order in which backward produces them; ``p.grad`` are views into it;
+  * the buffer is cut into a few large buckets (default 64 MiB: one to two transformer blocks) so each
+    all-reduce is bandwidth- rather than latency-bound;
+  * a bucket's all-reduce is launched asynchronously from a post-accumulate-grad hook as soon as its last
+    gradient has been written, so communication overlaps the rest of backward; ``finish()`` waits for all of
+    them before the optimizer step.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+def init_distributed_mode(backend: Optional[str] = None):
+    """utils.init_distributed_mode (utils.py:283-333): read RANK / WORLD_SIZE / LOCAL_RANK (torchrun / srun / OMPI),
+    bind the GPU, create the process group.  Returns (distributed, rank, world_size, local_rank)."""
+    env = os.environ
+    if "OMPI_COMM_WORLD_RANK" in env and "RANK" not in env:
+        env["RANK"] = env["OMPI_COMM_WORLD_RANK"]
+        env["WORLD_SIZE"] = env["OMPI_COMM_WORLD_SIZE"]
+        env["LOCAL_RANK"] = env["OMPI_COMM_WORLD_LOCAL_RANK"]
+    if "RANK" not in env or "WORLD_SIZE" not in env or int(env["WORLD_SIZE"]) <= 1:
+        return False, 0, 1, int(env.get("LOCAL_RANK", 0))
+    rank, world, local = int(env["RANK"]), int(env["WORLD_SIZE"]), int(env.get("LOCAL_RANK", 0))
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("MASTER_PORT", "29500")
+    if not dist.is_initialized():
+        if backend == "nccl":
+            dist.init_process_group(backend=backend, init_method="env://", world_size=world, rank=rank,
+                                    device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend, init_method="env://", world_size=world, rank=rank)
+    dist.barrier()
+    return True, rank, world, local
+
+
+class DataParallel(nn.Module):
+    """Replicated-model data parallelism with bucketed, overlapped gradient all-reduce."""
+
+    def __init__(self, module: nn.Module, bucket_mb: float = 64.0, process_group=None, broadcast: bool = True):
+        super().__init__()
+        self.module = module
+        self.pg = process_group
+        self.world = dist.get_world_size(self.pg) if dist.is_initialized() else 1
+        params = [p for p in module.parameters() if p.requires_grad]
+        assert params, "no trainable parameters"
+        dev, dt = params[0].device, params[0].dtype
+        assert all(p.device == dev and p.dtype == dt for p in params), "parameters must share device and dtype"
+        if broadcast and self.world > 1:  # C2: replicas start identical
+            flat = torch.cat([p.detach().reshape(-1) for p in module.parameters()])
+            dist.broadcast(flat, src=0, group=self.pg)
+            off = 0
+            with torch.no_grad():
+                for p in module.parameters():
+                    p.copy_(flat[off:off + p.numel()].view_as(p))
+                    off += p.numel()
+        # flat gradient buffer, reverse registration order, every tensor 16-byte aligned
+        order = list(reversed(params))
+        offs, total = [], 0
+        for p in order:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        self.flat_grad = torch.zeros(total, dtype=dt, device=dev)
+        self._views = {}
+        for p, o in zip(order, offs):
+            self._views[id(p)] = self.flat_grad[o:o + p.numel()].view_as(p)
+            p.grad = self._views[id(p)]
+        # buckets = contiguous ranges of the flat buffer
+        limit = int(bucket_mb * (1 << 20) / self.flat_grad.element_size())
+        self.buckets: List[dict] = []
+        start, count = 0, 0
+        for i, (p, o) in enumerate(zip(order, offs)):
+            end = o + (p.numel() + 3) // 4 * 4
+            count += 1
+            if end - start >= limit or i == len(order) - 1:
+                self.buckets.append({"lo": start, "hi": end, "n": count, "ready": 0})
+                start, count = end, 0
+        self._bucket_of = {}
+        bi = 0
+        for p, o in zip(order, offs):
+            while o >= self.buckets[bi]["hi"]:
+                bi += 1
+            self._bucket_of[id(p)] = bi
+        self._works = []
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in order]
+        self.require_sync = True
+
+    # -- hook: runs on the autograd thread right after p.grad has been accumulated
+    def _on_grad(self, p):
+        view = self._views[id(p)]
+        if p.grad is not view and p.grad.data_ptr() != view.data_ptr():
+            # someone called optimizer.zero_grad(set_to_none=True): autograd allocated a fresh tensor -> re-home it
+            view.copy_(p.grad)
+            p.grad = view
+        if self.world == 1 or not self.require_sync:
+            return
+        b = self.buckets[self._bucket_of[id(p)]]
+        b["ready"] += 1
+        if b["ready"] == b["n"]:
+            b["ready"] = 0
+            view = self.flat_grad[b["lo"]:b["hi"]]
+            view.div_(self.world)  # mean; pre-division keeps the sum in range and works for gloo (no AVG op)
+            self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    def finish(self):
+        """Wait for every in-flight bucket (call after backward, before the optimizer step)."""
+        for w in self._works:
+            w.wait()
+        self._works.clear()
+        for b in self.buckets:  # a parameter that received no gradient this step leaves its bucket incomplete
+            if b["ready"]:
+                b["ready"] = 0
+                view = self.flat_grad[b["lo"]:b["hi"]]
+                view.div_(self.world)
+                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def zero_grad(self, set_to_none: bool = False):
+        """Gradients are views into the flat buffer and must stay allocated: zero in place."""
+        self.flat_grad.zero_()
+
+    def grad_sumsq_buffer(self):
+        return self.flat_grad
