@@ -8,7 +8,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtad_mi355x.so")
 SOURCES = ["capi.hip", "elementwise.hip", "layernorm.hip", "gemm.hip", "attn_fwd.hip", "attn_bwd.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result",
+         # keep MFMA accumulators in the (unified) VGPR file: without it the compiler parks them in AGPRs and pays a
+         # v_accvgpr_read/write per element around every softmax / epilogue
+         "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 
 
 def _hipcc():

@@ -171,13 +171,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_dual(vl, key, ks, h5), dof[ks], dp, 0, 0, 0);
       }
       // dS^T = P^T o (dP^T - delta); keys >= N contribute nothing
+      if (kv0 + 64 > N) {  // ragged last tile only: keys >= N get P = 0
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kg = kv0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h5;
+          if (kg >= N) s[r] = -1e30f;
+        }
+      }
       f32x16 ds;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kg = kv0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h5;
-        const float pv = (kg < N) ? fast_exp2(s[r] * c - lse2) : 0.f;
-        ds[r] = pv * dp[r];
-      }
+      for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(s[r] * c - lse2) * dp[r];
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const bf16x8 dsf = pack8(ds, s2);

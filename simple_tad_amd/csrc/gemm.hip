@@ -37,6 +37,7 @@ struct GemmNT {
   int c_bf16;
   int epi;
   int M, N, K;
+  int debug;  // ablation (TAD_GEMM_DEBUG, timing only, wrong results): 1 = no DMA inside the K loop, 2 = no MFMA, 4 = no epilogue
 };
 
 constexpr int BK = 64;             // K-tile depth (bf16 elements) -> 128-byte LDS rows
@@ -70,46 +71,66 @@ __device__ __forceinline__ void block_barrier() {
   asm volatile("" ::: "memory");
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const GemmNT p) {
+// swizzle of the 16-byte chunk index for 64-byte LDS rows (K-tile depth 32): conflict-free for the same fragment reads
+__device__ __forceinline__ int sw_nt32(int row) { return ((row >> 3) & 1) << 1; }
+template <int BKT>
+__device__ __forceinline__ int sw_rows(int row) { return BKT == 64 ? sw_nt(row) : sw_nt32(row); }
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int BKT, int MIN_WAVES, int EPI, bool OUT_BF16>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kernel(const GemmNT p) {
   constexpr int NW = WAVES_M * WAVES_N;
-  constexpr int LOADS = BM / (8 * NW) + BN / (8 * NW);
+  constexpr int ROWB = BKT * 2;               // bytes per LDS row
+  constexpr int RPP = 1024 / ROWB;            // rows per 1-KiB DMA piece
+  constexpr int CPR = ROWB / 16;              // 16-byte chunks per row
+  constexpr int KSTEPS = BKT / 32;
+  constexpr int LOADS = BM / (RPP * NW) + BN / (RPP * NW);
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   constexpr int MREP = WTM / 16, NREP = WTN / 16;
-  constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES;
+  constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
   constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
-  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split into 8-row DMA pieces per wave");
-  __shared__ __attribute__((aligned(1024))) char lds[STAGES * STAGE_BYTES];
+  static_assert(BM % (RPP * NW) == 0 && BN % (RPP * NW) == 0, "tile rows must split into whole DMA pieces per wave");
+  constexpr int EPI_BYTES = (BM < 128 ? BM : 128) * (BN * 4 + 16);  // one epilogue chunk: 128 rows of f32, padded stride
+  constexpr int LDS_BYTES = STAGES * STAGE_BYTES > EPI_BYTES ? STAGES * STAGE_BYTES : EPI_BYTES;
+  __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
+  // Tile order: the XCD remap gives each XCD (private 4 MiB L2) a contiguous range of logical tile ids; inside that range the
+  // ids sweep GROUP_M row-panels for one column-panel before moving to the next column-panel, so the ~32 workgroups that are
+  // resident on an XCD at any time touch only GROUP_M A-panels and ~32/GROUP_M W-panels (both stay L2-resident).
+  constexpr int GROUP_M = 8;
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
   const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int per_group = GROUP_M * tiles_n;
+  const int grp = tile / per_group;
+  const int first_m = grp * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int in_grp = tile - grp * per_group;
+  const int tm = first_m + in_grp % gsz, tn = in_grp / gsz;
   const int m0 = tm * BM, n0 = tn * BN;
 
     const int a_bytes = (int)((int64_t)p.M * p.K * 2), b_bytes = (int)((int64_t)p.N * p.K * 2);
 
-  // ---- DMA addressing: one wave-instruction fills 8 LDS rows (1 KiB); lane -> (row lane>>3, physical chunk lane&7)
-  const int drow = lane >> 3, dchunk = lane & 7;
-  uint32_t a_off[BM / (8 * NW)], b_off[BN / (8 * NW)];
+  // ---- DMA addressing: one wave-instruction fills RPP LDS rows (1 KiB); lane -> (row lane/CPR, physical chunk lane%CPR)
+  const int drow = lane / CPR, dchunk = lane % CPR;
+  uint32_t a_off[BM / (RPP * NW)], b_off[BN / (RPP * NW)];
 #pragma unroll
-  for (int i = 0; i < BM / (8 * NW); ++i) {
-    const int row = (i * NW + wave) * 8 + drow;
-    a_off[i] = (uint32_t)(m0 + row) * (uint32_t)(p.K * 2) + (uint32_t)((dchunk ^ sw_nt(row)) * 16);
+  for (int i = 0; i < BM / (RPP * NW); ++i) {
+    const int row = (i * NW + wave) * RPP + drow;
+    a_off[i] = (uint32_t)(m0 + row) * (uint32_t)(p.K * 2) + (uint32_t)((dchunk ^ sw_rows<BKT>(row)) * 16);
   }
 #pragma unroll
-  for (int i = 0; i < BN / (8 * NW); ++i) {
-    const int row = (i * NW + wave) * 8 + drow;
-    b_off[i] = (uint32_t)(n0 + row) * (uint32_t)(p.K * 2) + (uint32_t)((dchunk ^ sw_nt(row)) * 16);
+  for (int i = 0; i < BN / (RPP * NW); ++i) {
+    const int row = (i * NW + wave) * RPP + drow;
+    b_off[i] = (uint32_t)(n0 + row) * (uint32_t)(p.K * 2) + (uint32_t)((dchunk ^ sw_rows<BKT>(row)) * 16);
   }
 #define STAGE_NT(buf, kt) \
-  stage_tile<BM / (8 * NW), NW>(p.A, a_bytes, lds + (buf) * STAGE_BYTES, a_off, (uint32_t)(kt) * ROW_BYTES, wave); \
-  stage_tile<BN / (8 * NW), NW>(p.B, b_bytes, lds + (buf) * STAGE_BYTES + A_BYTES, b_off, (uint32_t)(kt) * ROW_BYTES, wave)
+  stage_tile<BM / (RPP * NW), NW>(p.A, a_bytes, lds + (buf) * STAGE_BYTES, a_off, (uint32_t)(kt) * ROWB, wave); \
+  stage_tile<BN / (RPP * NW), NW>(p.B, b_bytes, lds + (buf) * STAGE_BYTES + A_BYTES, b_off, (uint32_t)(kt) * ROWB, wave)
 
   // ---- fragment addressing
   const int c = lane & 15, kq = lane >> 4;
@@ -119,8 +140,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const Ge
 #pragma unroll
   for (int i = 0; i < MREP; ++i) {
     const int row = wm * WTM + i * 16 + c;
-    a_rd[i] = row * ROW_BYTES;
-    a_sw[i] = sw_nt(row);
+    a_rd[i] = row * ROWB;
+    a_sw[i] = sw_rows<BKT>(row);
   }
   // B-operand rows (output cols n), permuted so that the 4 lanes (kq = 0..3) that share an output row write one contiguous
   // 64-byte segment per store instruction:
@@ -131,19 +152,27 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const Ge
   int b_sw[NREP];
 #pragma unroll
   for (int j = 0; j < NREP; ++j) {
-    const int rl = p.c_bf16 ? (32 * (j >> 1) + 8 * (c >> 2) + 4 * (j & 1) + (c & 3)) : (16 * j + 4 * (c >> 2) + (c & 3));
+    const int rl = OUT_BF16 ? (32 * (j >> 1) + 8 * (c >> 2) + 4 * (j & 1) + (c & 3)) : (16 * j + 4 * (c >> 2) + (c & 3));
     const int row = wn * WTN + rl;
-    b_rd[j] = row * ROW_BYTES;
-    b_sw[j] = sw_nt(row);
+    b_rd[j] = row * ROWB;
+    b_sw[j] = sw_rows<BKT>(row);
   }
 
+  // accumulators start from the bias (a per-column constant = per (j, kq, r) constant in this layout): no bias add later
   f32x4 acc[MREP][NREP];
 #pragma unroll
-  for (int i = 0; i < MREP; ++i)
+  for (int j = 0; j < NREP; ++j) {
+    const int nc = n0 + wn * WTN + (OUT_BF16 ? (32 * (j >> 1) + 8 * kq + 4 * (j & 1)) : (16 * j + 4 * kq));
+    f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (EPI != EPI_DGELU && p.bias && nc < p.N) {
+      const float4 t = *reinterpret_cast<const float4*>(p.bias + nc);
+      b4 = f32x4{t.x, t.y, t.z, t.w};
+    }
 #pragma unroll
-    for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < MREP; ++i) acc[i][j] = b4;
+  }
 
-  const int nk = p.K / BK;
+  const int nk = p.K / BKT;
 #pragma unroll
   for (int st = 0; st < STAGES - 1; ++st)
     if (st < nk) { STAGE_NT(st, st); }
@@ -163,126 +192,145 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const Ge
   {                                                                                                    \
     bf16x8 af[MREP], bfr[NREP];                                                                        \
     _Pragma("unroll") for (int j = 0; j < NREP; ++j)                                                   \
-        bfr[j] = *reinterpret_cast<const bf16x8*>(sb + b_rd[j] + (((4 * (ks) + kq) ^ b_sw[j]) << 4));  \
+        bfr[j] = *reinterpret_cast<const bf16x8*>(sb + b_rd[j] + ((((KSTEPS > 1 ? 4 * (ks) : 0) + kq) ^ b_sw[j]) << 4));  \
     _Pragma("unroll") for (int i = 0; i < MREP; ++i)                                                   \
-        af[i] = *reinterpret_cast<const bf16x8*>(sa + a_rd[i] + (((4 * (ks) + kq) ^ a_sw[i]) << 4));   \
-    _Pragma("unroll") for (int i = 0; i < MREP; ++i)                                                   \
-        _Pragma("unroll") for (int j = 0; j < NREP; ++j)                                               \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);    \
+        af[i] = *reinterpret_cast<const bf16x8*>(sa + a_rd[i] + ((((KSTEPS > 1 ? 4 * (ks) : 0) + kq) ^ a_sw[i]) << 4));   \
+    if (!(p.debug & 2)) {                                                                              \
+      _Pragma("unroll") for (int i = 0; i < MREP; ++i)                                                 \
+          _Pragma("unroll") for (int j = 0; j < NREP; ++j)                                             \
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);  \
+    } else {                                                                                           \
+      _Pragma("unroll") for (int i = 0; i < MREP; ++i) asm volatile("" ::"v"(af[i]));                  \
+      _Pragma("unroll") for (int j = 0; j < NREP; ++j) asm volatile("" ::"v"(bfr[j]));                 \
+    }                                                                                                  \
   }
     // Issuing a tile's LDS-DMA pieces blocks the issuing wave for ~100 cycles per piece.  The two waves that share a SIMD
     // (wave w and w + NW/2) therefore issue them at different times: the older half before its first k-step, the younger
     // half between its two k-steps, so the SIMD's matrix pipe always has one wave feeding it.
     const bool late = wave >= NW / 2;  // wave-uniform (scalar branches); the MFMA code is shared by both halves
-    if (more && !late) { STAGE_NT(wr_now, kt_next); }
-    KSTEP_NT(0);
-    if (more && late) { STAGE_NT(wr_now, kt_next); }
-    KSTEP_NT(1);
+    const bool dma = more && !(p.debug & 1);
+    if (KSTEPS == 2) {
+      if (dma && !late) { STAGE_NT(wr_now, kt_next); }
+      KSTEP_NT(0);
+      if (dma && late) { STAGE_NT(wr_now, kt_next); }
+      KSTEP_NT(1);
+    } else {
+      if (dma) { STAGE_NT(wr_now, kt_next); }
+      KSTEP_NT(0);
+    }
   }
 
-  // ---- epilogue on registers.  Lane (c = lane&15, kq = lane>>4) holds output row m = m0 + wm*WTM + 16i + c and, per n-fragment j,
-  // 4 consecutive columns (see the permutation above).  bf16 outputs are stored 16 bytes (two fragments) at a time.
-  const int nwave = n0 + wn * WTN;
+  // ---- epilogue through LDS.  Straight from the MFMA layout a global access would touch 16 rows x 64 bytes per instruction;
+  // the accumulators are transposed through the (now idle) LDS in chunks of CROWS rows so that every global load / store of
+  // a wave covers whole contiguous rows (512 B - 1 KiB runs).  The epilogue is VALU-bound (128 outputs per lane), so the
+  // variant (EPI, OUT_BF16) is a template parameter, offsets are 32-bit, and loads are issued BATCH rows ahead because the CU
+  // has only NW waves to cover HBM latency.
+  if ((p.debug & 4) && p.M > 1) return;
+  constexpr int CROWS = BM < 128 ? BM : 128;         // tile rows per chunk
+  constexpr int MREP_C = CROWS / (16 * WAVES_M);     // m-fragments each wave contributes to a chunk
+  constexpr int NCHUNK = MREP / MREP_C;
+  constexpr int CSTRIDE = BN * 4 + 16;               // padded row stride (bytes): conflict-free 16-byte writes
+  constexpr int CPL = OUT_BF16 ? 8 : 4;              // columns per lane in the row pass (16-byte stores)
+  constexpr int LPR = BN / CPL, RPI = 64 / LPR;      // lanes per row, rows per wave-instruction
+  constexpr int NR = CROWS / (NW * RPI);             // row-instructions per wave per chunk
+  constexpr int BATCH = NR < 8 ? NR : 8;
+  static_assert(MREP % MREP_C == 0 && MREP_C >= 1 && CROWS % (NW * RPI) == 0 && NR % BATCH == 0, "chunking");
+  const int col = CPL * (lane % LPR);
+  const int n = n0 + col;
+  const bool nvalid = n < p.N;
+  const bool full = (n + CPL <= p.N);  // N % 4 == 0: a bf16 lane has either 8 or 4 valid columns
+  float gam[CPL];
 #pragma unroll
-  for (int i = 0; i < MREP; ++i) {
-    const int m = m0 + wm * WTM + i * 16 + c;
-    if (m >= p.M) continue;
-    const float rsc = p.rowscale ? p.rowscale[m / p.rows_per_scale] : 1.f;
-    const int64_t rrow = p.res_mod > 0 ? (m % p.res_mod) : m;
-    if (!p.c_bf16) {
+  for (int e = 0; e < CPL; ++e) gam[e] = (EPI == EPI_RESIDUAL && p.gamma && nvalid && (e < 4 || full)) ? p.gamma[n + e] : 1.f;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < NCHUNK; ++q) {
+    // (1) every wave drops its MREP_C x NREP fragments of this chunk
+#pragma unroll
+    for (int ii = 0; ii < MREP_C; ++ii) {
+      const int lr = wm * (16 * MREP_C) + ii * 16 + c;
 #pragma unroll
       for (int j = 0; j < NREP; ++j) {
-        const int n = nwave + 16 * j + 4 * kq;
-        if (n >= p.N) continue;
-        f32x4 v = acc[i][j];
-        if (p.bias) {
-          const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-          v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-        }
-        if (p.epi == EPI_GELU) {
-          if (p.preact) {
-            uint2 h;
-            h.x = pack_bf16x2(v[0], v[1]);
-            h.y = pack_bf16x2(v[2], v[3]);
-            *reinterpret_cast<uint2*>(p.preact + (int64_t)m * p.N + n) = h;
-          }
-          v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
-        } else if (p.epi == EPI_DGELU) {
-          const uint2 h = *reinterpret_cast<const uint2*>(p.dgelu_h + (int64_t)m * p.N + n);
-          v[0] *= gelu_erf_grad(__uint_as_float(h.x << 16));
-          v[1] *= gelu_erf_grad(__uint_as_float(h.x & 0xffff0000u));
-          v[2] *= gelu_erf_grad(__uint_as_float(h.y << 16));
-          v[3] *= gelu_erf_grad(__uint_as_float(h.y & 0xffff0000u));
-        } else if (p.epi == EPI_RESIDUAL) {
-          if (p.gamma) {
-            const float4 g = *reinterpret_cast<const float4*>(p.gamma + n);
-            v[0] *= g.x; v[1] *= g.y; v[2] *= g.z; v[3] *= g.w;
-          }
-          if (p.rowscale) { v[0] *= rsc; v[1] *= rsc; v[2] *= rsc; v[3] *= rsc; }
-          if (p.residual) {
-            const float4 r = *reinterpret_cast<const float4*>(p.residual + rrow * p.N + n);
-            v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
-          }
-        }
-        *reinterpret_cast<float4*>((float*)p.C + (int64_t)m * p.N + n) = make_float4(v[0], v[1], v[2], v[3]);
-      }
-    } else {
-#pragma unroll
-      for (int jp = 0; jp < NREP / 2; ++jp) {
-        const int n = nwave + 32 * jp + 8 * kq;
-        if (n >= p.N) continue;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = acc[i][2 * jp][e]; v[4 + e] = acc[i][2 * jp + 1][e]; }
-        const bool full = (n + 8 <= p.N);  // N % 4 == 0: either 8 or 4 valid columns
-        if (p.bias) {
-          const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n);
-          v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-          if (full) {
-            const float4 b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
-            v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-          }
-        }
-        const int64_t o = (int64_t)m * p.N + n;
-        if (p.epi == EPI_GELU) {
-          if (p.preact) {
-            uint4 h;
-            h.x = pack_bf16x2(v[0], v[1]); h.y = pack_bf16x2(v[2], v[3]); h.z = pack_bf16x2(v[4], v[5]); h.w = pack_bf16x2(v[6], v[7]);
-            if (full) *reinterpret_cast<uint4*>(p.preact + o) = h;
-            else *reinterpret_cast<uint2*>(p.preact + o) = make_uint2(h.x, h.y);
-          }
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
-        } else if (p.epi == EPI_DGELU) {
-          uint4 h = make_uint4(0, 0, 0, 0);
-          if (full) h = *reinterpret_cast<const uint4*>(p.dgelu_h + o);
-          else { const uint2 t = *reinterpret_cast<const uint2*>(p.dgelu_h + o); h.x = t.x; h.y = t.y; }
-          const uint32_t hw[4] = {h.x, h.y, h.z, h.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[2 * e] *= gelu_erf_grad(__uint_as_float(hw[e] << 16));
-            v[2 * e + 1] *= gelu_erf_grad(__uint_as_float(hw[e] & 0xffff0000u));
-          }
-        } else if (p.epi == EPI_RESIDUAL) {
-          if (p.gamma) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) if (e < 4 || full) v[e] *= p.gamma[n + e];
-          }
-          if (p.rowscale) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= rsc;
-          }
-          if (p.residual) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) if (e < 4 || full) v[e] += p.residual[rrow * p.N + n + e];
-          }
-        }
-        uint4 ob;
-        ob.x = pack_bf16x2(v[0], v[1]); ob.y = pack_bf16x2(v[2], v[3]); ob.z = pack_bf16x2(v[4], v[5]); ob.w = pack_bf16x2(v[6], v[7]);
-        if (full) *reinterpret_cast<uint4*>((uint16_t*)p.C + o) = ob;
-        else *reinterpret_cast<uint2*>((uint16_t*)p.C + o) = make_uint2(ob.x, ob.y);
+        const int cc = wn * WTN + (OUT_BF16 ? (32 * (j >> 1) + 8 * kq + 4 * (j & 1)) : (16 * j + 4 * kq));
+        *reinterpret_cast<f32x4*>(lds + lr * CSTRIDE + cc * 4) = acc[q * MREP_C + ii][j];
       }
     }
+    __syncthreads();
+    // (2) row-contiguous pass: local row lr <-> tile row (lr / (16*MREP_C))*WTM + 16*MREP_C*q + lr % (16*MREP_C)
+#pragma unroll
+    for (int r0 = 0; r0 < NR; r0 += BATCH) {
+      float v[BATCH][CPL];
+      float4 res[BATCH][CPL / 4];
+      uint4 hh[BATCH];
+      int off[BATCH];  // element offset m*N + n, or -1
+#pragma unroll
+      for (int b = 0; b < BATCH; ++b) {
+        const int lr = ((r0 + b) * NW + wave) * RPI + lane / LPR;
+        const int m = m0 + (lr / (16 * MREP_C)) * WTM + 16 * MREP_C * q + lr % (16 * MREP_C);
+        off[b] = (m < p.M && nvalid) ? m * p.N + n : -1;
+#pragma unroll
+        for (int e4 = 0; e4 < CPL / 4; ++e4) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(lds + lr * CSTRIDE + col * 4 + 16 * e4);
+          v[b][4 * e4 + 0] = t[0]; v[b][4 * e4 + 1] = t[1]; v[b][4 * e4 + 2] = t[2]; v[b][4 * e4 + 3] = t[3];
+          res[b][e4] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        hh[b] = make_uint4(0, 0, 0, 0);
+        if (off[b] >= 0) {
+          if (EPI == EPI_RESIDUAL && p.residual) {
+            const int ro = p.res_mod > 0 ? (m % p.res_mod) * p.N + n : off[b];
+            res[b][0] = *reinterpret_cast<const float4*>(p.residual + ro);
+            if (CPL == 8 && full) res[b][CPL / 4 - 1] = *reinterpret_cast<const float4*>(p.residual + ro + 4);
+          } else if (EPI == EPI_DGELU) {
+            if (CPL == 8 && full) hh[b] = *reinterpret_cast<const uint4*>(p.dgelu_h + off[b]);
+            else { const uint2 t = *reinterpret_cast<const uint2*>(p.dgelu_h + off[b]); hh[b].x = t.x; hh[b].y = t.y; }
+          }
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < BATCH; ++b) {
+        if (off[b] < 0) continue;
+        const int o = off[b];
+        if (EPI == EPI_GELU) {
+          if (p.preact) {
+            if (CPL == 8 && full) {
+              *reinterpret_cast<uint4*>(p.preact + o) = make_uint4(pack_bf16x2(v[b][0], v[b][1]), pack_bf16x2(v[b][2], v[b][3]),
+                                                                  pack_bf16x2(v[b][CPL - 4], v[b][CPL - 3]), pack_bf16x2(v[b][CPL - 2], v[b][CPL - 1]));
+            } else {
+              *reinterpret_cast<uint2*>(p.preact + o) = make_uint2(pack_bf16x2(v[b][0], v[b][1]), pack_bf16x2(v[b][2], v[b][3]));
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < CPL; ++e) v[b][e] = gelu_erf(v[b][e]);
+        } else if (EPI == EPI_DGELU) {
+          const uint32_t hw[4] = {hh[b].x, hh[b].y, hh[b].z, hh[b].w};
+#pragma unroll
+          for (int e = 0; e < CPL / 2; ++e) {
+            v[b][2 * e] *= gelu_erf_grad(__uint_as_float(hw[e] << 16));
+            v[b][2 * e + 1] *= gelu_erf_grad(__uint_as_float(hw[e] & 0xffff0000u));
+          }
+        } else if (EPI == EPI_RESIDUAL) {
+          if (p.gamma || p.rowscale) {
+            const float rsc = p.rowscale ? p.rowscale[(o / p.N) / p.rows_per_scale] : 1.f;
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) v[b][e] *= gam[e] * rsc;
+          }
+#pragma unroll
+          for (int e4 = 0; e4 < CPL / 4; ++e4) {
+            v[b][4 * e4 + 0] += res[b][e4].x; v[b][4 * e4 + 1] += res[b][e4].y;
+            v[b][4 * e4 + 2] += res[b][e4].z; v[b][4 * e4 + 3] += res[b][e4].w;
+          }
+        }
+        if (OUT_BF16) {
+          uint16_t* cp = (uint16_t*)p.C + o;
+          if (full) *reinterpret_cast<uint4*>(cp) = make_uint4(pack_bf16x2(v[b][0], v[b][1]), pack_bf16x2(v[b][2], v[b][3]),
+                                                             pack_bf16x2(v[b][CPL - 4], v[b][CPL - 3]), pack_bf16x2(v[b][CPL - 2], v[b][CPL - 1]));
+          else *reinterpret_cast<uint2*>(cp) = make_uint2(pack_bf16x2(v[b][0], v[b][1]), pack_bf16x2(v[b][2], v[b][3]));
+        } else {
+          *reinterpret_cast<float4*>((float*)p.C + o) = make_float4(v[b][0], v[b][1], v[b][2], v[b][3]);
+        }
+      }
+    }
+    if (q + 1 < NCHUNK) __syncthreads();
   }
 }
 
@@ -292,6 +340,7 @@ struct GemmTN {
   const uint16_t* P;  // [Mr, N]  (dy)
   const uint16_t* Q;  // [Mr, K]  (x)
   float* slab;        // [splits][N][K]
+  float* bias_slab;   // [splits][N] column sums of P (bias gradient), or null
   int Mr, N, K;
   int rows_per_split;  // multiple of 64
 };
@@ -377,6 +426,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(const Ge
   // transposed fragment reads: 16-lane group g = lane>>4 covers reduction rows 8g..8g+7 of a 32-deep k-step;
   // lane i = lane&15 of the group supplies row (i>>2) (+4 for the second read), columns c0 + 4*(i&3) .. +3
   const int g = lane >> 4, li = lane & 15;
+  // bias gradient = column sums of P = P^T * ones: one extra MFMA per row fragment against an all-ones B operand, done only by
+  // the workgroups of the first K column-panel and, inside them, by the waves of the first wave column
+  const bool do_bias = (p.bias_slab != nullptr) && (tk_ == 0) && (wn == 0);
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+  f32x4 bacc[MREP];
+#pragma unroll
+  for (int i = 0; i < MREP; ++i) bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 acc[MREP][NREP];
 #pragma unroll
   for (int i = 0; i < MREP; ++i)
@@ -405,6 +463,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(const Ge
     _Pragma("unroll") for (int i = 0; i < MREP; ++i)                                                        \
         _Pragma("unroll") for (int j = 0; j < NREP; ++j)                                                    \
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[i], qf[j], acc[i][j], 0, 0, 0);          \
+    if (do_bias) {                                                                                          \
+      _Pragma("unroll") for (int i = 0; i < MREP; ++i)                                                      \
+          bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[i], ones, bacc[i], 0, 0, 0);                 \
+    }                                                                                                       \
   }
     const bool late = wave >= NW / 2;  // stagger the DMA issue of the two waves that share a SIMD (see gemm_nt_kernel)
     if (more && !late) { STAGE_TN(wr_now, t_next); }
@@ -413,6 +475,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(const Ge
     KSTEP_TN(1);
   }
 
+  if (do_bias && li == 0) {
+    float* bo = p.bias_slab + (int64_t)split * p.N;
+#pragma unroll
+    for (int i = 0; i < MREP; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wm * WTM + 16 * i + 4 * g + r;
+        if (n < p.N) bo[n] = bacc[i][r];
+      }
+  }
   // D[row = n][col = k]: lane col = lane&15, rows 4*(lane>>4) + r
   float* out = p.slab + (int64_t)split * p.N * p.K;
 #pragma unroll
@@ -435,23 +507,42 @@ static int env_int(const char* name) {
 }
 
 // Tile configurations.  NT: 1 = 256x256 (2x4 waves) 2 stages; 2 = 128x128 (2x2) 2 stages, 2 workgroups/CU;
-// 3 = 256x128 (4x2) 3 stages; 4 = 128x256 (2x4) 3 stages; 5 = 256x128 2 stages.  0 = auto.
+// 3 = 256x128 (4x2) 3 stages.  0 = auto.  The epilogue kind and output type are compile-time (the epilogue is VALU-bound).
+template <int EPI, bool OUT_BF16>
+static void launch_nt_variant(int v, const GemmNT& p, hipStream_t st) {
+  auto tiles = [&](int bm, int bn) { return ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+  switch (v) {
+    case 1: hipLaunchKernelGGL((gemm_nt_kernel<256, 256, 2, 4, 2, 64, 1, EPI, OUT_BF16>), dim3(tiles(256, 256)), dim3(512), 0, st, p); break;
+    case 3: hipLaunchKernelGGL((gemm_nt_kernel<256, 128, 4, 2, 3, 64, 1, EPI, OUT_BF16>), dim3(tiles(256, 128)), dim3(512), 0, st, p); break;
+    default: hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 2, 2, 2, 64, 1, EPI, OUT_BF16>), dim3(tiles(128, 128)), dim3(256), 0, st, p); break;
+  }
+}
+
 int launch_gemm_nt(const GemmNT& p, hipStream_t st) {
   if (!(p.M > 0 && p.N > 0 && p.K > 0)) { set_error("gemm_nt: empty problem"); return TAD_EINVAL; }
   if (p.K % BK) { set_error("gemm_nt: K=%d must be a multiple of %d", p.K, BK); return TAD_EINVAL; }
   if (p.N % 4) { set_error("gemm_nt: N=%d must be a multiple of 4", p.N); return TAD_EINVAL; }
   if ((int64_t)p.M * p.K * 2 >= (1ll << 32) || (int64_t)p.N * p.K * 2 >= (1ll << 32)) { set_error("gemm_nt: operand exceeds 4 GiB"); return TAD_EINVAL; }
+  if ((int64_t)(p.M + 256) * p.N >= (1ll << 31)) { set_error("gemm_nt: output exceeds 2^31 elements"); return TAD_EINVAL; }
   static const int forced = env_int("TAD_GEMM_NT_VARIANT");
+  static const int debug = env_int("TAD_GEMM_DEBUG");
+  const_cast<GemmNT&>(p).debug = debug;
   int v = forced;
-  if (v == 0) v = (p.M >= 2048 && p.N >= 128) ? 3 : 2;
-  auto tiles = [&](int bm, int bn) { return ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
-  switch (v) {
-    case 1: hipLaunchKernelGGL((gemm_nt_kernel<256, 256, 2, 4, 2>), dim3(tiles(256, 256)), dim3(512), 0, st, p); break;
-    case 3: hipLaunchKernelGGL((gemm_nt_kernel<256, 128, 4, 2, 3>), dim3(tiles(256, 128)), dim3(512), 0, st, p); break;
-    case 4: hipLaunchKernelGGL((gemm_nt_kernel<128, 256, 2, 4, 3>), dim3(tiles(128, 256)), dim3(512), 0, st, p); break;
-    case 5: hipLaunchKernelGGL((gemm_nt_kernel<256, 128, 4, 2, 2>), dim3(tiles(256, 128)), dim3(512), 0, st, p); break;
-    default: hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 2, 2, 2>), dim3(tiles(128, 128)), dim3(256), 0, st, p); break;
+  // measured on MI355X (tools/bench_kernels.py): 256x256 wins when N has many column panels, 256x128 for N <= 1024
+  if (v == 0) v = (p.M < 2048 || p.N < 128) ? 2 : ((p.N >= 1536 && p.N % 256 == 0) ? 1 : 3);
+#define NT_CASE(E)                                                       \
+  case E:                                                                \
+    if (p.c_bf16) launch_nt_variant<E, true>(v, p, st);                  \
+    else launch_nt_variant<E, false>(v, p, st);                          \
+    break;
+  switch (p.epi) {
+    NT_CASE(EPI_PLAIN)
+    NT_CASE(EPI_GELU)
+    NT_CASE(EPI_RESIDUAL)
+    NT_CASE(EPI_DGELU)
+    default: set_error("gemm_nt: bad epilogue %d", p.epi); return TAD_EINVAL;
   }
+#undef NT_CASE
   return check_launch("gemm_nt");
 }
 
@@ -477,11 +568,11 @@ static int tn_plan(int64_t Mr, int N, int K, int* splits, int* rows_per_split) {
 size_t gemm_tn_workspace_bytes(int64_t Mr, int N, int K) {
   int s, r;
   tn_plan(Mr, N, K, &s, &r);
-  return (size_t)s * (size_t)N * (size_t)K * sizeof(float);
+  return (size_t)s * ((size_t)N * (size_t)K + (size_t)N) * sizeof(float);
 }
 
-int launch_gemm_tn(const uint16_t* P, const uint16_t* Q, float* out, int accumulate, void* ws, size_t ws_bytes, int64_t Mr, int N,
-                   int K, hipStream_t st) {
+int launch_gemm_tn(const uint16_t* P, const uint16_t* Q, float* out, float* bias_out, int accumulate, void* ws, size_t ws_bytes,
+                   int64_t Mr, int N, int K, hipStream_t st) {
   if (!(Mr > 0 && N > 0 && K > 0)) { set_error("gemm_tn: empty problem"); return TAD_EINVAL; }
   if (N % 8 || K % 8) { set_error("gemm_tn: N=%d and K=%d must be multiples of 8", N, K); return TAD_EINVAL; }
   if (Mr * (int64_t)N * 2 >= (1ll << 32) || Mr * (int64_t)K * 2 >= (1ll << 32)) { set_error("gemm_tn: operand exceeds 4 GiB"); return TAD_EINVAL; }
@@ -489,14 +580,17 @@ int launch_gemm_tn(const uint16_t* P, const uint16_t* Q, float* out, int accumul
   p.P = P; p.Q = Q; p.slab = (float*)ws; p.Mr = (int)Mr; p.N = N; p.K = K;
   int splits;
   const int tiles = tn_plan(Mr, N, K, &splits, &p.rows_per_split);
-  if (ws_bytes < (size_t)splits * N * K * sizeof(float)) { set_error("gemm_tn: workspace too small"); return TAD_ENOSPACE; }
+  if (ws_bytes < (size_t)splits * ((size_t)N * K + N) * sizeof(float)) { set_error("gemm_tn: workspace too small"); return TAD_ENOSPACE; }
+  p.bias_slab = bias_out ? p.slab + (size_t)splits * N * K : nullptr;
   if (tn_variant() == 1)
     hipLaunchKernelGGL((gemm_tn_kernel<256, 256, 2, 4, 2>), dim3(tiles * splits), dim3(512), 0, st, p);
   else
     hipLaunchKernelGGL((gemm_tn_kernel<256, 128, 4, 2, 3>), dim3(tiles * splits), dim3(512), 0, st, p);
   int rc = check_launch("gemm_tn");
   if (rc) return rc;
-  return launch_reduce_partials(p.slab, out, splits, (int64_t)N * K, accumulate, st);
+  rc = launch_reduce_partials(p.slab, out, splits, (int64_t)N * K, accumulate, st);
+  if (rc || !bias_out) return rc;
+  return launch_reduce_partials(p.bias_slab, bias_out, splits, N, accumulate, st);
 }
 
 }  // namespace tad
@@ -538,18 +632,13 @@ int tad_linear_bwd_input(const uint16_t* dy, const uint16_t* wT, void* dx, int d
 }
 
 size_t tad_linear_bwd_weight_workspace_bytes(int64_t M, int N, int K) {
-  const size_t a = gemm_tn_workspace_bytes(M, N, K);
-  const size_t b = tad_colsum_workspace_bytes(M, N);
-  return a > b ? a : b;
+  return gemm_tn_workspace_bytes(M, N, K);
 }
 
 int tad_linear_bwd_weight(const uint16_t* dy, const uint16_t* x, float* dW, float* db, int accumulate, void* ws, size_t ws_bytes,
                           int64_t M, int N, int K, tad_stream_t stream) {
   TAD_REQUIRE(dy && x && dW && ws, "linear_bwd_weight: null pointer");
-  int rc = launch_gemm_tn(dy, x, dW, accumulate, ws, ws_bytes, M, N, K, (hipStream_t)stream);
-  if (rc) return rc;
-  if (db) rc = tad_colsum_bf16(dy, db, accumulate, ws, ws_bytes, M, N, stream);
-  return rc;
+  return launch_gemm_tn(dy, x, dW, db, accumulate, ws, ws_bytes, M, N, K, (hipStream_t)stream);
 }
 
 // ---- PatchEmbed = im2col + NT GEMM with bias and broadcast pos_embed in the epilogue

@@ -19,8 +19,9 @@ class LaunchProfiler:
     """Optional per-launch timing with HIP events on the launching stream (used by bench.py for the live roofline figure).
     ``record(kernel, flops, bytes)`` brackets one C-ABI call; ``summary()`` synchronises and aggregates per kernel class."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.items = []
+        self.only = set(only) if only else None  # restrict to these kernel classes (keeps the timed region undisturbed)
 
     def begin(self):
         e = torch.cuda.Event(enable_timing=True)
@@ -59,7 +60,7 @@ class _timed:
         self.k, self.f, self.b = kernel, flops, nbytes
 
     def __enter__(self):
-        self.s = _prof.begin() if _prof is not None else None
+        self.s = _prof.begin() if (_prof is not None and (_prof.only is None or self.k in _prof.only)) else None
 
     def __exit__(self, *a):
         if self.s is not None:
