@@ -224,9 +224,16 @@ def main():
         g = summ.get("gemm_nt")
         if g and g["ms"] > 0:
             ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
+            traffic = None  # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/)
+            try:
+                import glob
+                latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))[-1]
+                traffic = round(json.load(open(latest)).get("gemm_nt_traffic_bytes_per_launch"))
+            except Exception:  # noqa: BLE001
+                traffic = None
             out["roofline"] = {"kernel": "gemm_nt_kernel (bf16 MFMA GEMM, all Linear fwd / input-grad launches)", "bound": "mfma",
                                "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches": g["launches"],
+                               "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "launches": g["launches"],
                                "avg_launch_us": round(1e3 * g["ms"] / g["launches"], 2),
                                "gflop_per_launch": round(g["flops"] / g["launches"] / 1e9, 2)}
         tot = sum(v["ms"] for v in summ.values())
