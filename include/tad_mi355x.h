@@ -142,6 +142,24 @@ int tad_scale_cast_bf16(const float* x, uint16_t* y, const float* gamma, const f
 /* sum of squares of an f32 vector, accumulated into *out (f32, device) -- get_grad_norm_ (utils.py:415-427) */
 int tad_sumsq_f32(const float* x, int64_t n, float* out, tad_stream_t stream);
 
+/* ---- "precise" mode (parity gate, not throughput): f32-accurate Linear via split-bf16 operands, f32 attention ----------
+ * x = hi + lo (bf16 each).  concat mode: out [M,3K] = [hi|hi|lo] (role_b=0) or [hi|lo|hi] (role_b=1); stack mode: out [3M,K]
+ * with the three parts stacked along rows.  Feeding tad_linear_* with both operands split this way (K or M tripled) gives the
+ * f32 product to ~2^-17 using the same MFMA kernels. */
+int tad_split_bf16x3(const float* x, uint16_t* out, int64_t M, int K, int role_b, int stack, tad_stream_t stream);
+int tad_im2col_tubelets_f32(const float* x, float* cols, int B, int C, int T, int H, int W, int tubelet, int patch,
+                            tad_stream_t stream);
+/* qkv [B,N,3,H,64] f32 -> out [B,N,H,64] f32, lse [B,H,N] (nullable) */
+int tad_attn_fwd_f32(const float* qkv, float* out, float* lse, int B, int N, int H, int d, float scale, tad_stream_t stream);
+
+/* precise-mode backward pieces: f32 attention backward (dqkv [B,N,3,H,64] f32 fully overwritten; delta [B,H,N] scratch),
+ * erf-GELU forward / backward on f32, column sums of an f32 matrix (bias gradients). */
+int tad_attn_bwd_f32(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, float* delta,
+                     int B, int N, int H, int d, float scale, tad_stream_t stream);
+int tad_gelu_f32(const float* h, float* a, int64_t n, tad_stream_t stream);
+int tad_gelu_bwd_f32(const float* dy, const float* h, float* dh, int64_t n, tad_stream_t stream);
+int tad_colsum_f32(const float* a, float* out, int64_t M, int N, tad_stream_t stream);
+
 /* ---- device info ------------------------------------------------------------------------ */
 int tad_device_info(int* cu_count, int* clock_khz, int* lds_bytes_per_cu, char* name, int name_len);
 

@@ -4,8 +4,9 @@ shared library is loaded on first use and every op fails loudly if it is missing
 from . import registry
 from .registry import create_model, register_model, list_models
 from . import modeling_finetune
+from .ops import set_precision, get_precision
 from .modeling_finetune import (VisionTransformer, PatchEmbed, Block, Attention, Mlp, DropPath,
                                 get_sinusoid_encoding_table)
 
-__all__ = ["create_model", "register_model", "list_models", "modeling_finetune", "VisionTransformer", "PatchEmbed", "Block",
+__all__ = ["set_precision", "get_precision", "create_model", "register_model", "list_models", "modeling_finetune", "VisionTransformer", "PatchEmbed", "Block",
            "Attention", "Mlp", "DropPath", "get_sinusoid_encoding_table"]

@@ -38,6 +38,13 @@ SIGNATURES = {
     "tad_colsum_bf16": (_i, [_vp, _vp, _i, _vp, _sz, _i64, _i, _vp]),
     "tad_scale_cast_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp]),
     "tad_sumsq_f32": (_i, [_vp, _i64, _vp, _vp]),
+    "tad_split_bf16x3": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp]),
+    "tad_im2col_tubelets_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "tad_attn_fwd_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "tad_attn_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "tad_gelu_f32": (_i, [_vp, _vp, _i64, _vp]),
+    "tad_gelu_bwd_f32": (_i, [_vp, _vp, _vp, _i64, _vp]),
+    "tad_colsum_f32": (_i, [_vp, _vp, _i64, _i, _vp]),
     "tad_device_info": (_i, [C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.c_char_p, _i]),
 }
 

@@ -50,10 +50,12 @@ __device__ __forceinline__ bf16x8 row_frag_dual(const char* tile, int row, int k
 }
 
 __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int s2) {
-  bf16x8 r;
+  // pairwise v_cvt_pk_bf16_f32 (one instruction per two elements)
+  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+  u32x4 r;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) r[j] = (__bf16)a[8 * s2 + j];
-  return r;
+  for (int j = 0; j < 4; ++j) r[j] = pack_bf16x2(a[8 * s2 + 2 * j], a[8 * s2 + 2 * j + 1]);
+  return __builtin_bit_cast(bf16x8, r);
 }
 
 // ------------------------------------------------------------------------------------------------ delta

@@ -1,0 +1,435 @@
+// "Precise" mode helpers: f32-accurate variants used for the parity gate (end-to-end <= 1e-3 against the fp32 reference),
+// not for throughput.
+//
+//  * split_bf16x3: x = hi + lo with hi = bf16(x), lo = bf16(x - hi).  A product of two f32 operands is recovered to ~2^-17
+//    relative from three bf16 MFMA products  A_hi*B_hi + A_hi*B_lo + A_lo*B_hi  -- and those three products are ONE bf16 GEMM
+//    over a 3x longer reduction dimension: [A_hi | A_hi | A_lo] . [B_hi | B_lo | B_hi]^T.  So the precise Linear reuses the
+//    production MFMA GEMM kernels unchanged; only the operand preparation differs.
+//  * attn_fwd_f32_kernel: plain f32 (VALU FMA) flash-style attention for packed f32 qkv, 64 query rows per workgroup.
+#include "common.h"
+
+namespace tad {
+
+// out row r, for source row m = r % M (stack mode) or r (concat mode)
+// concat (along K): out [M, 3K]; role A: [hi | hi | lo], role B: [hi | lo | hi]
+// stack  (along M): out [3M, K]; role A: rows [hi ; hi ; lo], role B: rows [hi ; lo ; hi]
+__global__ void split_bf16x3_kernel(const float* __restrict__ x, uint16_t* __restrict__ out, int64_t M, int K, int role_b, int stack) {
+  const int K4 = K >> 2;
+  const int64_t total = M * K4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t m = i / K4;
+    const int c = (int)(i - m * K4) * 4;
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float f[4] = {v.x, v.y, v.z, v.w};
+    uint16_t hi[4], lo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      hi[e] = f32_to_bf16(f[e]);
+      lo[e] = f32_to_bf16(f[e] - bf16_to_f32(hi[e]));
+    }
+    const uint2 H = make_uint2((uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16));
+    const uint2 L = make_uint2((uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16));
+    const uint2 s0 = H, s1 = role_b ? L : H, s2 = role_b ? H : L;
+    if (stack) {
+      *reinterpret_cast<uint2*>(out + (m)*K + c) = s0;
+      *reinterpret_cast<uint2*>(out + (M + m) * K + c) = s1;
+      *reinterpret_cast<uint2*>(out + (2 * M + m) * K + c) = s2;
+    } else {
+      uint16_t* o = out + m * 3 * K;
+      *reinterpret_cast<uint2*>(o + c) = s0;
+      *reinterpret_cast<uint2*>(o + K + c) = s1;
+      *reinterpret_cast<uint2*>(o + 2 * K + c) = s2;
+    }
+  }
+}
+
+// x [B,C,T,H,W] f32 -> cols [B*N, K] f32 (same token / k order as im2col_tubelets_kernel)
+__global__ void im2col_tubelets_f32_kernel(const float* __restrict__ x, float* __restrict__ cols, int B, int C, int T, int H, int W,
+                                           int tub, int p) {
+  const int W4 = W >> 2;
+  const int64_t total = (int64_t)B * C * T * H * W4;
+  const int Hp = H / p, Wp = W / p, Tp = T / tub;
+  const int K = C * tub * p * p;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    int64_t r = i;
+    const int w4 = (int)(r % W4); r /= W4;
+    const int h = (int)(r % H); r /= H;
+    const int t = (int)(r % T); r /= T;
+    const int c = (int)(r % C); r /= C;
+    const int b = (int)r;
+    const int w = w4 << 2;
+    const int tp = t / tub, kt = t - tp * tub, hp = h / p, kh = h - hp * p, wp = w / p, kw = w - wp * p;
+    const int64_t n = ((int64_t)(b * Tp + tp) * Hp + hp) * Wp + wp;
+    const int k = ((c * tub + kt) * p + kh) * p + kw;
+    *reinterpret_cast<float4*>(cols + n * K + k) = reinterpret_cast<const float4*>(x)[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// f32 attention forward.  Workgroup = 256 threads = 64 query rows of one (batch, head); thread (ty = tid>>4, tx = tid&15) owns
+// query rows 4ty..4ty+3 and, per 64-key tile, keys 4tx..4tx+3 (scores) / head-dim columns 4tx..4tx+3 (output).
+__global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out, float* __restrict__ lse,
+                                                           int N, int H, float scale) {
+  __shared__ float Qs[64][65], Ks[64][65], Vs[64][65], Ps[64][65];
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  const int head = blockIdx.y, b = blockIdx.z, q0 = blockIdx.x * 64;
+  const int64_t tok = (int64_t)3 * H * 64;
+  const float* base = qkv + (int64_t)b * N * tok + head * 64;
+  for (int i = tid; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    const int q = min(q0 + r, N - 1);
+    Qs[r][c] = base[(int64_t)q * tok + c] * scale;
+  }
+  float m_run[4], l_run[4], o[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    m_run[i] = -1e30f; l_run[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[i][j] = 0.f;
+  }
+  for (int kv0 = 0; kv0 < N; kv0 += 64) {
+    __syncthreads();
+    for (int i = tid; i < 64 * 64; i += 256) {
+      const int r = i >> 6, c = i & 63;
+      const int key = min(kv0 + r, N - 1);
+      Ks[r][c] = base[(int64_t)key * tok + (int64_t)H * 64 + c];
+      Vs[r][c] = base[(int64_t)key * tok + (int64_t)2 * H * 64 + c];
+    }
+    __syncthreads();
+    float s[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s[i][j] = 0.f;
+    for (int d = 0; d < 64; ++d) {
+      float qa[4], kb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { qa[i] = Qs[4 * ty + i][d]; kb[i] = Ks[4 * tx + i][d]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[i][j] = fmaf(qa[i], kb[j], s[i][j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float mx = -1e30f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (kv0 + 4 * tx + j >= N) s[i][j] = -1e30f;
+        mx = fmaxf(mx, s[i][j]);
+      }
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));  // the 16 lanes tx = 0..15 share query rows
+      const float m_new = fmaxf(m_run[i], mx);
+      const float alpha = __expf(m_run[i] - m_new);
+      float ps = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float pv = __expf(s[i][j] - m_new);
+        ps += pv;
+        Ps[4 * ty + i][4 * tx + j] = pv;
+      }
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) ps += __shfl_xor(ps, off, 64);
+      l_run[i] = l_run[i] * alpha + ps;
+      m_run[i] = m_new;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[i][j] *= alpha;
+    }
+    __syncthreads();
+    for (int k = 0; k < 64; ++k) {
+      float pa[4], vb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { pa[i] = Ps[4 * ty + i][k]; vb[i] = Vs[k][4 * tx + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[i][j] = fmaf(pa[i], vb[j], o[i][j]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = q0 + 4 * ty + i;
+    if (q >= N) continue;
+    const float inv = 1.f / l_run[i];
+    float* op = out + (((int64_t)b * N + q) * H + head) * 64 + 4 * tx;
+    *reinterpret_cast<float4*>(op) = make_float4(o[i][0] * inv, o[i][1] * inv, o[i][2] * inv, o[i][3] * inv);
+    if (tx == 0 && lse) lse[((int64_t)b * H + head) * N + q] = m_run[i] + __logf(l_run[i]);
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// f32 attention backward (verification mode): delta, dQ pass (per 64 query rows) and dK/dV pass (per 64 keys); same thread
+// layout as the forward kernel.  No atomics.
+__global__ void attn_delta_f32_kernel(const float* __restrict__ o, const float* __restrict__ dout, float* __restrict__ delta, int B, int N,
+                                      int H) {
+  const int64_t rows = (int64_t)B * N * H;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t row = gid >> 4;
+  const int sub = (int)(gid & 15);
+  float s = 0.f;
+  if (row < rows) {
+    const float4 a = *reinterpret_cast<const float4*>(o + row * 64 + sub * 4);
+    const float4 g = *reinterpret_cast<const float4*>(dout + row * 64 + sub * 4);
+    s = a.x * g.x + a.y * g.y + a.z * g.z + a.w * g.w;
+  }
+#pragma unroll
+  for (int off = 1; off < 16; off <<= 1) s += __shfl_xor(s, off, 64);
+  if (row < rows && sub == 0) {
+    const int h = (int)(row % H);
+    const int64_t bq = row / H;
+    delta[((bq / N) * H + h) * N + (bq % N)] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dq_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                              const float* __restrict__ lse, const float* __restrict__ delta,
+                                                              float* __restrict__ dqkv, int N, int H, float scale) {
+  __shared__ float Qs[64][65], Gs[64][65], Ks[64][65], Vs[64][65], Ds[64][65];
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  const int head = blockIdx.y, b = blockIdx.z, q0 = blockIdx.x * 64;
+  const int64_t tok = (int64_t)3 * H * 64;
+  const float* base = qkv + (int64_t)b * N * tok + head * 64;
+  for (int i = tid; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    const int q = min(q0 + r, N - 1);
+    Qs[r][c] = base[(int64_t)q * tok + c] * scale;
+    Gs[r][c] = dout[(((int64_t)b * N + q) * H + head) * 64 + c];
+  }
+  float lq[4], dq_[4], acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = min(q0 + 4 * ty + i, N - 1);
+    lq[i] = lse[((int64_t)b * H + head) * N + q];
+    dq_[i] = delta[((int64_t)b * H + head) * N + q];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  }
+  for (int kv0 = 0; kv0 < N; kv0 += 64) {
+    __syncthreads();
+    for (int i = tid; i < 64 * 64; i += 256) {
+      const int r = i >> 6, c = i & 63;
+      const int key = min(kv0 + r, N - 1);
+      Ks[r][c] = base[(int64_t)key * tok + (int64_t)H * 64 + c];
+      Vs[r][c] = base[(int64_t)key * tok + (int64_t)2 * H * 64 + c];
+    }
+    __syncthreads();
+    float s[4][4], dp[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s[i][j] = 0.f; dp[i][j] = 0.f; }
+    for (int d = 0; d < 64; ++d) {
+      float qa[4], ga[4], kb[4], vb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { qa[i] = Qs[4 * ty + i][d]; ga[i] = Gs[4 * ty + i][d]; kb[i] = Ks[4 * tx + i][d]; vb[i] = Vs[4 * tx + i][d]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s[i][j] = fmaf(qa[i], kb[j], s[i][j]); dp[i][j] = fmaf(ga[i], vb[j], dp[i][j]); }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float pv = (kv0 + 4 * tx + j < N) ? __expf(s[i][j] - lq[i]) : 0.f;
+        Ds[4 * ty + i][4 * tx + j] = pv * (dp[i][j] - dq_[i]);
+      }
+    __syncthreads();
+    for (int k = 0; k < 64; ++k) {
+      float da[4], kb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { da[i] = Ds[4 * ty + i][k]; kb[i] = Ks[k][4 * tx + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(da[i], kb[j], acc[i][j]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = q0 + 4 * ty + i;
+    if (q >= N) continue;
+    float* op = dqkv + ((int64_t)b * N + q) * tok + head * 64 + 4 * tx;
+    *reinterpret_cast<float4*>(op) = make_float4(acc[i][0] * scale, acc[i][1] * scale, acc[i][2] * scale, acc[i][3] * scale);
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dkv_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                               const float* __restrict__ lse, const float* __restrict__ delta,
+                                                               float* __restrict__ dqkv, int N, int H, float scale) {
+  __shared__ float Ks[64][65], Vs[64][65], Qs[64][65], Gs[64][65], Pt[64][65], Dt[64][65];
+  __shared__ float Ls[64], Es[64];
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  const int head = blockIdx.y, b = blockIdx.z, k0 = blockIdx.x * 64;
+  const int64_t tok = (int64_t)3 * H * 64;
+  const float* base = qkv + (int64_t)b * N * tok + head * 64;
+  for (int i = tid; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    const int key = min(k0 + r, N - 1);
+    Ks[r][c] = base[(int64_t)key * tok + (int64_t)H * 64 + c];
+    Vs[r][c] = base[(int64_t)key * tok + (int64_t)2 * H * 64 + c];
+  }
+  float dk[4][4], dv[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { dk[i][j] = 0.f; dv[i][j] = 0.f; }
+  for (int q0 = 0; q0 < N; q0 += 64) {
+    __syncthreads();
+    for (int i = tid; i < 64 * 64; i += 256) {
+      const int r = i >> 6, c = i & 63;
+      const int q = min(q0 + r, N - 1);
+      Qs[r][c] = base[(int64_t)q * tok + c] * scale;
+      Gs[r][c] = dout[(((int64_t)b * N + q) * H + head) * 64 + c];
+    }
+    if (tid < 64) {
+      const int q = min(q0 + tid, N - 1);
+      Ls[tid] = lse[((int64_t)b * H + head) * N + q];
+      Es[tid] = delta[((int64_t)b * H + head) * N + q];
+    }
+    __syncthreads();
+    float s[4][4], dp[4][4];  // [key i][query j]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s[i][j] = 0.f; dp[i][j] = 0.f; }
+    for (int d = 0; d < 64; ++d) {
+      float ka[4], va[4], qb[4], gb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { ka[i] = Ks[4 * ty + i][d]; va[i] = Vs[4 * ty + i][d]; qb[i] = Qs[4 * tx + i][d]; gb[i] = Gs[4 * tx + i][d]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s[i][j] = fmaf(ka[i], qb[j], s[i][j]); dp[i][j] = fmaf(va[i], gb[j], dp[i][j]); }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ql = 4 * tx + j;
+        const float pv = (q0 + ql < N) ? __expf(s[i][j] - Ls[ql]) : 0.f;
+        Pt[4 * ty + i][ql] = pv;
+        Dt[4 * ty + i][ql] = pv * (dp[i][j] - Es[ql]);
+      }
+    __syncthreads();
+    for (int q = 0; q < 64; ++q) {
+      float pa[4], da[4], gb[4], qb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { pa[i] = Pt[4 * ty + i][q]; da[i] = Dt[4 * ty + i][q]; gb[i] = Gs[q][4 * tx + i]; qb[i] = Qs[q][4 * tx + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { dv[i][j] = fmaf(pa[i], gb[j], dv[i][j]); dk[i][j] = fmaf(da[i], qb[j], dk[i][j]); }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int key = k0 + 4 * ty + i;
+    if (key >= N) continue;
+    float* okp = dqkv + ((int64_t)b * N + key) * tok + (int64_t)H * 64 + head * 64 + 4 * tx;
+    // Qs carried the softmax scale already: dK = dS^T (scale*Q)
+    *reinterpret_cast<float4*>(okp) = make_float4(dk[i][0], dk[i][1], dk[i][2], dk[i][3]);
+    *reinterpret_cast<float4*>(okp + (int64_t)H * 64) = make_float4(dv[i][0], dv[i][1], dv[i][2], dv[i][3]);
+  }
+}
+
+// elementwise erf-GELU forward / backward on f32 and f32 column sums (bias gradients) for the precise path
+__global__ void gelu_f32_kernel(const float* __restrict__ h, float* __restrict__ a, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float x = h[i];
+    a[i] = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+  }
+}
+__global__ void gelu_bwd_f32_kernel(const float* __restrict__ dy, const float* __restrict__ h, float* __restrict__ dh, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float x = h[i];
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+    dh[i] = dy[i] * (cdf + x * pdf);
+  }
+}
+__global__ void colsum_f32_kernel(const float* __restrict__ a, float* __restrict__ out, int64_t M, int N) {
+  // one block per 64 columns; 4 waves over rows, f64 accumulation (verification path)
+  __shared__ double red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  double s = 0.0;
+  if (c < N)
+    for (int64_t m = wave; m < M; m += 4) s += (double)a[m * N + c];
+  red[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && c < N) out[c] = (float)(red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+}
+
+static inline int grid_for(int64_t items) {
+  int64_t g = (items + 255) / 256;
+  return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
+}
+
+}  // namespace tad
+
+using namespace tad;
+
+extern "C" {
+
+int tad_split_bf16x3(const float* x, uint16_t* out, int64_t M, int K, int role_b, int stack, tad_stream_t stream) {
+  TAD_REQUIRE(x && out && M > 0 && K > 0 && K % 4 == 0, "split_bf16x3: bad args (K must be a multiple of 4)");
+  hipLaunchKernelGGL(split_bf16x3_kernel, dim3(grid_for(M * (K / 4))), dim3(256), 0, (hipStream_t)stream, x, out, M, K, role_b, stack);
+  return check_launch("split_bf16x3");
+}
+
+int tad_im2col_tubelets_f32(const float* x, float* cols, int B, int C, int T, int H, int W, int tubelet, int patch, tad_stream_t stream) {
+  TAD_REQUIRE(x && cols, "im2col_f32: null pointer");
+  TAD_REQUIRE(B > 0 && C > 0 && tubelet > 0 && patch > 0 && T % tubelet == 0 && H % patch == 0 && W % patch == 0 && patch % 4 == 0,
+              "im2col_f32: T/H/W must be multiples of tubelet/patch and patch a multiple of 4");
+  hipLaunchKernelGGL(im2col_tubelets_f32_kernel, dim3(grid_for((int64_t)B * C * T * H * (W / 4))), dim3(256), 0, (hipStream_t)stream, x,
+                     cols, B, C, T, H, W, tubelet, patch);
+  return check_launch("im2col_f32");
+}
+
+int tad_attn_fwd_f32(const float* qkv, float* out, float* lse, int B, int N, int H, int d, float scale, tad_stream_t stream) {
+  TAD_REQUIRE(qkv && out, "attn_fwd_f32: null pointer");
+  TAD_REQUIRE(d == 64, "attn_fwd_f32: head_dim must be 64 (got %d)", d);
+  TAD_REQUIRE(B > 0 && N > 0 && H > 0 && H <= 65535 && B <= 65535 && scale > 0.f, "attn_fwd_f32: bad shape");
+  hipLaunchKernelGGL(attn_fwd_f32_kernel, dim3((N + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, qkv, out, lse, N, H, scale);
+  return check_launch("attn_fwd_f32");
+}
+
+int tad_attn_bwd_f32(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, float* delta, int B, int N, int H,
+                     int d, float scale, tad_stream_t stream) {
+  TAD_REQUIRE(qkv && out && dout && lse && dqkv && delta, "attn_bwd_f32: null pointer");
+  TAD_REQUIRE(d == 64 && B > 0 && N > 0 && H > 0 && H <= 65535 && B <= 65535 && scale > 0.f, "attn_bwd_f32: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t rows = (int64_t)B * N * H;
+  hipLaunchKernelGGL(attn_delta_f32_kernel, dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, st, out, dout, delta, B, N, H);
+  const dim3 grid((N + 63) / 64, H, B);
+  hipLaunchKernelGGL(attn_bwd_dq_f32_kernel, grid, dim3(256), 0, st, qkv, dout, lse, delta, dqkv, N, H, scale);
+  hipLaunchKernelGGL(attn_bwd_dkv_f32_kernel, grid, dim3(256), 0, st, qkv, dout, lse, delta, dqkv, N, H, scale);
+  return check_launch("attn_bwd_f32");
+}
+
+int tad_gelu_f32(const float* h, float* a, int64_t n, tad_stream_t stream) {
+  TAD_REQUIRE(h && a && n > 0, "gelu_f32: bad args");
+  hipLaunchKernelGGL(gelu_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, h, a, n);
+  return check_launch("gelu_f32");
+}
+
+int tad_gelu_bwd_f32(const float* dy, const float* h, float* dh, int64_t n, tad_stream_t stream) {
+  TAD_REQUIRE(dy && h && dh && n > 0, "gelu_bwd_f32: bad args");
+  hipLaunchKernelGGL(gelu_bwd_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dy, h, dh, n);
+  return check_launch("gelu_bwd_f32");
+}
+
+int tad_colsum_f32(const float* a, float* out, int64_t M, int N, tad_stream_t stream) {
+  TAD_REQUIRE(a && out && M > 0 && N > 0, "colsum_f32: bad args");
+  hipLaunchKernelGGL(colsum_f32_kernel, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, a, out, M, N);
+  return check_launch("colsum_f32");
+}
+
+}  // extern "C"

@@ -336,3 +336,66 @@ def device_info():
     name = C.create_string_buffer(64)
     check(_lib.load().tad_device_info(C.byref(cu), C.byref(clk), C.byref(ldsb), name, 64), "tad_device_info")
     return {"cu_count": cu.value, "clock_khz": clk.value, "lds_bytes_per_cu": ldsb.value, "arch": name.value.decode()}
+
+
+# ----------------------------------------------------------------------------- precise mode (parity gate)
+def split_bf16x3(x, role_b: bool, stack: bool = False):
+    """x [M,K] f32 -> bf16 [M,3K] ([hi|hi|lo] or [hi|lo|hi]) or, stacked, [3M,K]"""
+    _req(x, torch.float32, "split.x")
+    M, K = x.shape
+    out = torch.empty((3 * M, K) if stack else (M, 3 * K), dtype=torch.bfloat16, device=x.device)
+    check(_lib.load().tad_split_bf16x3(x.data_ptr(), out.data_ptr(), M, K, int(role_b), int(stack), _stream()), "tad_split_bf16x3")
+    return out
+
+
+def im2col_tubelets_f32(x, tubelet: int, patch: int):
+    _req(x, torch.float32, "im2col_f32.x")
+    B, Cc, T, H, W = x.shape
+    ntok = (T // tubelet) * (H // patch) * (W // patch)
+    cols = torch.empty((B * ntok, Cc * tubelet * patch * patch), dtype=torch.float32, device=x.device)
+    check(_lib.load().tad_im2col_tubelets_f32(x.data_ptr(), cols.data_ptr(), B, Cc, T, H, W, tubelet, patch, _stream()),
+          "tad_im2col_tubelets_f32")
+    return cols
+
+
+def attn_fwd_f32(qkv, B: int, N: int, H: int, scale: float, want_lse=False):
+    _req(qkv, torch.float32, "attn_f32.qkv")
+    if qkv.numel() != B * N * 3 * H * 64:
+        raise _lib.TadError("attn_fwd_f32: qkv element count mismatch")
+    out = torch.empty((B * N, H * 64), dtype=torch.float32, device=qkv.device)
+    lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device) if want_lse else None
+    check(_lib.load().tad_attn_fwd_f32(qkv.data_ptr(), out.data_ptr(), _p(lse), B, N, H, 64, float(scale), _stream()), "tad_attn_fwd_f32")
+    return out, lse
+
+
+def attn_bwd_f32(qkv, out, dout, lse, B: int, N: int, H: int, scale: float):
+    for t, n in ((qkv, "qkv"), (out, "out"), (dout, "dout"), (lse, "lse")):
+        _req(t, torch.float32, "attn_bwd_f32." + n)
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
+    check(_lib.load().tad_attn_bwd_f32(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), delta.data_ptr(),
+                                       B, N, H, 64, float(scale), _stream()), "tad_attn_bwd_f32")
+    return dqkv
+
+
+def gelu_f32(h):
+    _req(h, torch.float32, "gelu_f32.h")
+    a = torch.empty_like(h)
+    check(_lib.load().tad_gelu_f32(h.data_ptr(), a.data_ptr(), h.numel(), _stream()), "tad_gelu_f32")
+    return a
+
+
+def gelu_bwd_f32(dy, h):
+    _req(dy, torch.float32, "gelu_bwd_f32.dy")
+    _req(h, torch.float32, "gelu_bwd_f32.h")
+    dh = torch.empty_like(h)
+    check(_lib.load().tad_gelu_bwd_f32(dy.data_ptr(), h.data_ptr(), dh.data_ptr(), h.numel(), _stream()), "tad_gelu_bwd_f32")
+    return dh
+
+
+def colsum_f32(a):
+    _req(a, torch.float32, "colsum_f32.a")
+    M, N = a.shape
+    out = torch.empty(N, dtype=torch.float32, device=a.device)
+    check(_lib.load().tad_colsum_f32(a.data_ptr(), out.data_ptr(), M, N, _stream()), "tad_colsum_f32")
+    return out

@@ -85,6 +85,13 @@ class Mlp(nn.Module):
             raise TadError("Mlp: only the exact-erf nn.GELU activation has a fused kernel")
 
     def forward(self, x):
+        if ops.get_precision() == "precise":
+            ops._need_gpu(x, "Mlp")
+            ops._no_grad_only(x, self.fc1.weight)
+            shp = x.shape
+            y = ops.precise_mlp(x.detach().float().reshape(-1, shp[-1]).contiguous(), self.fc1.weight, self.fc1.bias, self.fc2.weight,
+                                self.fc2.bias)
+            return self.drop(y.reshape(*shp[:-1], -1))
         x = ops.MlpFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
         return self.drop(x)
 
@@ -125,6 +132,13 @@ class Attention(nn.Module):
 
     def forward(self, x):
         self._check()
+        if ops.get_precision() == "precise":
+            ops._need_gpu(x, "Attention")
+            ops._no_grad_only(x, self.qkv.weight)
+            B, N, C = x.shape
+            y = ops.precise_attention(x.detach().float().reshape(B * N, C).contiguous(), B, N, self.qkv.weight, self.q_bias, self.v_bias,
+                                      self.proj.weight, self.proj.bias, self.num_heads, self.scale)
+            return self.proj_drop(y.reshape(B, N, -1))
         x = ops.AttentionFn.apply(x, self.qkv.weight, self.q_bias, self.v_bias, self.proj.weight, self.proj.bias, self.num_heads,
                                   self.scale)
         return self.proj_drop(x)
@@ -155,6 +169,14 @@ class Block(nn.Module):
                 and not (self.training and (self.mlp.drop.p > 0 or self.attn.proj_drop.p > 0)))
 
     def forward(self, x):
+        if self._fusable() and ops.get_precision() == "precise":
+            self.attn._check()
+            if isinstance(self.drop_path, DropPath) and self.training and self.drop_path.drop_prob:
+                raise TadError('precision "precise" does not implement drop-path (verification runs use drop_path_rate=0)')
+            a, m = self.attn, self.mlp
+            return ops.precise_block(x, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.q_bias, a.v_bias, a.proj.weight, a.proj.bias,
+                                     self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias,
+                                     a.num_heads, a.scale, self.norm1.eps)
         if self._fusable():
             self.attn._check()
             dp = self.drop_path if isinstance(self.drop_path, DropPath) else None
@@ -200,6 +222,8 @@ class PatchEmbed(nn.Module):
             f"Input image size ({H}*{W}) doesn't match model ({self.img_size[0]}*{self.img_size[1]})."
         if self.patch_size[0] != self.patch_size[1]:
             raise TadError("PatchEmbed: only square patches have a kernel")
+        if ops.get_precision() == "precise":
+            return ops.precise_patch_embed(x, self.proj.weight, self.proj.bias, pos_embed, self.tubelet_size, self.patch_size[0])
         return ops.PatchEmbedFn.apply(x, self.proj.weight, self.proj.bias, pos_embed, self.tubelet_size, self.patch_size[0])
 
 

@@ -69,6 +69,96 @@ def _qkv_bias(q_bias, v_bias):
     return torch.cat((q_bias.detach(), torch.zeros_like(v_bias), v_bias.detach())).float().contiguous()
 
 
+# --------------------------------------------------------------------------- precise mode (parity gate)
+def _cached_split(p: torch.Tensor):
+    """[N,3K] bf16 split-operand copy ([hi|lo|hi]) of an f32 weight for the precise Linear."""
+    pid = id(p)
+    ent = _wcache.get(pid)
+    key = (p._version, p.data_ptr())
+    if ent is None or ent["ref"]() is not p or ent["key"] != key:
+        ent = {"ref": weakref.ref(p, lambda _r, pid=pid: _wcache.pop(pid, None)), "key": key}
+        _wcache[pid] = ent
+    if "s" not in ent:
+        w2 = p.detach().reshape(p.shape[0], -1).float().contiguous()
+        ent["s"] = K.split_bf16x3(w2, role_b=True)
+    return ent["s"]
+
+
+# --------------------------------------------------------------------------- precision mode
+_PRECISION = "fast"
+
+
+def set_precision(mode: str):
+    """"fast": single-pass bf16 MFMA operands (training / throughput).  "precise": split-bf16 (hi+lo, 3 MFMA products) Linears,
+    f32 attention and f32 activations -- forward only, used for the <= 1e-3 end-to-end parity gate against the fp32 reference."""
+    global _PRECISION
+    if mode not in ("fast", "precise"):
+        raise ValueError(mode)
+    _PRECISION = mode
+
+
+def get_precision() -> str:
+    return _PRECISION
+
+
+def _no_grad_only(*tensors):
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        raise TadError('precision "precise" is forward-only (parity gate); wrap the call in torch.no_grad()')
+
+
+def _cached_split_T(p: torch.Tensor):
+    """[K,3N] split-operand copy of W^T for the precise input-gradient GEMM."""
+    pid = id(p)
+    ent = _wcache.get(pid)
+    key = (p._version, p.data_ptr())
+    if ent is None or ent["ref"]() is not p or ent["key"] != key:
+        ent = {"ref": weakref.ref(p, lambda _r, pid=pid: _wcache.pop(pid, None)), "key": key}
+        _wcache[pid] = ent
+    if "st" not in ent:
+        wt = p.detach().reshape(p.shape[0], -1).float().t().contiguous()
+        ent["st"] = K.split_bf16x3(wt, role_b=True)
+    return ent["st"]
+
+
+def precise_dx(dy, weight):
+    """dx [M,K] f32 = dy [M,N] @ W [N,K] with split operands (reduction over 3N)"""
+    dx, _ = K.linear_fwd(K.split_bf16x3(dy, role_b=False), _cached_split_T(weight), None, out_dtype=torch.float32)
+    return dx
+
+
+def precise_dw(dy, x, want_bias=True):
+    """dW [N,K] = dy^T x with both operands split and stacked along the reduction (row) dimension; db = column sums of dy"""
+    dW, _ = K.linear_bwd_weight(K.split_bf16x3(dy, role_b=False, stack=True), K.split_bf16x3(x, role_b=True, stack=True), want_bias=False)
+    return dW, (K.colsum_f32(dy) if want_bias else None)
+
+
+def precise_linear(x2d, weight, bias, epilogue=EPI_BIAS, residual=None, rowscale=None, rows_per_scale=1):
+    xs = K.split_bf16x3(x2d, role_b=False)
+    y, _ = K.linear_fwd(xs, _cached_split(weight), _f32c(bias), out_dtype=torch.float32, epilogue=epilogue, residual=residual,
+                        rowscale=rowscale, rows_per_scale=rows_per_scale)
+    return y
+
+
+def precise_attention(x2d, B, N, qkv_w, q_bias, v_bias, proj_w, proj_b, H, scale, residual=None):
+    qkv = precise_linear(x2d, qkv_w, _qkv_bias(q_bias, v_bias))
+    ao, _ = K.attn_fwd_f32(qkv, B, N, H, scale)
+    return precise_linear(ao, proj_w, proj_b, EPI_BIAS_RESIDUAL if residual is not None else EPI_BIAS, residual=residual)
+
+
+def precise_mlp(x2d, fc1_w, fc1_b, fc2_w, fc2_b, residual=None):
+    a = precise_linear(x2d, fc1_w, fc1_b, EPI_BIAS_GELU)
+    return precise_linear(a, fc2_w, fc2_b, EPI_BIAS_RESIDUAL if residual is not None else EPI_BIAS, residual=residual)
+
+
+def precise_block(x, n1w, n1b, qkv_w, q_bias, v_bias, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, H, scale, eps):
+    return PreciseBlockFn.apply(x, n1w, n1b, qkv_w, q_bias, v_bias, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, H, scale, eps)
+
+
+def precise_patch_embed(x, weight, bias, pos, tubelet, patch):
+    return PrecisePatchEmbedFn.apply(x, weight, bias, pos, tubelet, patch)
+
+
+
 # --------------------------------------------------------------------------- LayerNorm
 class LayerNormFn(torch.autograd.Function):
     """nn.LayerNorm(D, eps) on f32 rows -> f32 (modeling_finetune.py:143,149,270)."""
@@ -261,3 +351,72 @@ class MeanPoolFn(torch.autograd.Function):
     def backward(ctx, dy):
         dx, _ = K.meanpool_bwd(_f32c(dy), ctx.n)
         return dx
+
+
+# --------------------------------------------------------------------------- precise mode: autograd
+class PreciseBlockFn(torch.autograd.Function):
+    """Block forward/backward in the precise mode (f32 activations, split-bf16 Linears, f32 attention): the gradient side of the
+    parity gate.  Same data flow as BlockFn; no drop-path (verification runs use drop_path_rate = 0)."""
+
+    @staticmethod
+    def forward(ctx, x, n1w, n1b, qkv_w, q_bias, v_bias, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, H, scale, eps):
+        _need_gpu(x, "Block")
+        B, N, D = x.shape
+        M = B * N
+        x0 = _f32c(x).reshape(M, D)
+        g1, b1, g2, b2 = _f32c(n1w), _f32c(n1b), _f32c(n2w), _f32c(n2b)
+        xn1, mean1, rstd1 = K.layernorm_fwd(x0, g1, b1, eps, out_dtype=torch.float32)
+        qkv = precise_linear(xn1, qkv_w, _qkv_bias(q_bias, v_bias))
+        ao, lse = K.attn_fwd_f32(qkv, B, N, H, scale, want_lse=True)
+        x1 = precise_linear(ao, proj_w, proj_b, EPI_BIAS_RESIDUAL, residual=x0)
+        xn2, mean2, rstd2 = K.layernorm_fwd(x1, g2, b2, eps, out_dtype=torch.float32)
+        h = precise_linear(xn2, fc1_w, fc1_b)
+        a = K.gelu_f32(h)
+        x2 = precise_linear(a, fc2_w, fc2_b, EPI_BIAS_RESIDUAL, residual=x1)
+        ctx.save_for_backward(x0, g1, mean1, rstd1, xn1, qkv, ao, lse, x1, g2, mean2, rstd2, xn2, h, a, qkv_w, proj_w, fc1_w, fc2_w)
+        ctx.meta = (B, N, D, H, scale, q_bias is not None)
+        return x2.reshape(B, N, D)
+
+    @staticmethod
+    def backward(ctx, g):
+        x0, g1, mean1, rstd1, xn1, qkv, ao, lse, x1, g2, mean2, rstd2, xn2, h, a, qkv_w, proj_w, fc1_w, fc2_w = ctx.saved_tensors
+        B, N, D, H, scale, has_qb = ctx.meta
+        g = _f32c(g).reshape(B * N, D)
+        dh = K.gelu_bwd_f32(precise_dx(g, fc2_w), h)
+        dW2, db2 = precise_dw(g, a)
+        dxn2 = precise_dx(dh, fc1_w)
+        dW1, db1 = precise_dw(dh, xn2)
+        gmid, _, dg2, dbeta2, _ = K.layernorm_bwd(dxn2, x1, g2, mean2, rstd2, dres=g)
+        d_ao = precise_dx(gmid, proj_w)
+        dWp, dbp = precise_dw(gmid, ao)
+        dqkv = K.attn_bwd_f32(qkv, ao, d_ao, lse, B, N, H, scale)
+        dxn1 = precise_dx(dqkv, qkv_w)
+        dWqkv, dbqkv = precise_dw(dqkv, xn1, want_bias=has_qb)
+        dqb = dvb = None
+        if has_qb:
+            AH = dbqkv.numel() // 3
+            dqb, dvb = dbqkv[:AH].clone(), dbqkv[2 * AH:].clone()
+        gin, _, dg1, dbeta1, _ = K.layernorm_bwd(dxn1, x0, g1, mean1, rstd1, dres=gmid)
+        return (gin.reshape(B, N, D), dg1, dbeta1, dWqkv, dqb, dvb, dWp, dbp, dg2, dbeta2, dW1, db1, dW2, db2, None, None, None)
+
+
+class PrecisePatchEmbedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, pos, tubelet, patch):
+        _need_gpu(x, "PatchEmbed")
+        B = x.shape[0]
+        cols = K.im2col_tubelets_f32(_f32c(x), tubelet, patch)
+        ntok = cols.shape[0] // B
+        res = _f32c(pos).repeat(B, 1) if pos is not None else None
+        y, _ = K.linear_fwd(K.split_bf16x3(cols, role_b=False), _cached_split(weight), _f32c(bias), out_dtype=torch.float32,
+                            epilogue=EPI_BIAS_RESIDUAL if res is not None else EPI_BIAS, residual=res)
+        ctx.save_for_backward(cols)
+        ctx.wshape = weight.shape
+        ctx.has_bias = bias is not None
+        return y.reshape(B, ntok, weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        (cols,) = ctx.saved_tensors
+        dW, db = precise_dw(_f32c(dy).reshape(-1, dy.shape[-1]), cols, want_bias=ctx.has_bias)
+        return None, dW.reshape(ctx.wshape), db, None, None, None

@@ -266,3 +266,41 @@ def test_errors_are_loud(K):
         K.linear_fwd(torch.zeros(4, 60, dtype=torch.bfloat16, device="cuda"), torch.zeros(8, 60, dtype=torch.bfloat16, device="cuda"))
     with pytest.raises(TadError):
         K.attn_fwd(torch.zeros(4, 3 * 64, dtype=torch.bfloat16, device="cuda"), 1, 5, 1, 0.125)  # wrong element count
+
+
+# ------------------------------------------------------------------ precise-mode kernels (parity gate): 1e-3 is met with margin
+def test_split_bf16x3_linear_matches_f32_product(K):
+    M, N, Kd = 300, 256, 128
+    x = R.tensor_for("sp.x", (M, Kd))
+    w = R.tensor_for("sp.w", (N, Kd), scale=0.05)
+    xs, ws = K.split_bf16x3(dev(x), role_b=False), K.split_bf16x3(dev(w), role_b=True)
+    assert xs.shape == (M, 3 * Kd) and ws.shape == (N, 3 * Kd)
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    assert torch.equal(xs.cpu().view(torch.int16), torch.cat([hi, hi, lo], 1).view(torch.int16))           # bit-exact split
+    y, _ = K.linear_fwd(xs, ws, None, out_dtype=torch.float32)
+    check(y, x.double() @ w.double().t(), tol=2e-5, what="split-bf16 linear")                                  # f32-level product
+    # stacked form for the weight gradient: dW = dy^T x
+    dy = R.tensor_for("sp.dy", (M, N))
+    dW, _ = K.linear_bwd_weight(K.split_bf16x3(dev(dy), role_b=False, stack=True), K.split_bf16x3(dev(x), role_b=True, stack=True),
+                                want_bias=False)
+    check(dW, dy.double().t() @ x.double(), tol=2e-5, what="split-bf16 dW")
+    check(K.colsum_f32(dev(dy)), dy.double().sum(0), tol=1e-6, what="colsum f32")
+    h = R.tensor_for("sp.h", (M, N), scale=1.5)
+    hd = h.double().requires_grad_()
+    a = O.gelu_erf(hd)
+    a.backward(dy.double())
+    check(K.gelu_f32(dev(h)), a.detach(), tol=1e-6, what="gelu f32")
+    check(K.gelu_bwd_f32(dev(dy), dev(h)), hd.grad, tol=1e-6, what="gelu bwd f32")
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 100, 2), (1, 1568, 1), (2, 8, 3)])
+def test_attention_f32_fwd_bwd(K, B, N, H):
+    scale = 64 ** -0.5
+    qkv = R.tensor_for(f"attf.qkv{N}", (B * N, 3 * H * 64))
+    dout = R.tensor_for(f"attf.do{N}", (B * N, H * 64))
+    ref, ref_dqkv = _attn_ref(qkv, B, N, H, scale, dout)
+    out, lse = K.attn_fwd_f32(dev(qkv), B, N, H, scale, want_lse=True)
+    check(out.reshape(B, N, -1), ref, tol=1e-5, what="attn f32 fwd")
+    dqkv = K.attn_bwd_f32(dev(qkv), out, dev(dout), lse, B, N, H, scale)
+    check(dqkv.reshape(B, N, -1), ref_dqkv, tol=1e-5, what="attn f32 bwd")

@@ -139,3 +139,82 @@ def test_real_shape_logits_vs_reference_golden(golden, tag, name, frames):
     if tag == "s8":
         probs = torch.softmax(logits, -1)
         assert relmax(probs, g["s8.infer_probs"]) < 5e-3  # run_inference_simple's model (softmax baked in)
+
+
+# ------------------------------------------------------------------ precise mode: the 1e-3 end-to-end parity gate
+@pytest.mark.parametrize("tag,name,frames", [("s8", "vit_small_patch16_224", 8), ("b16", "vit_base_patch16_224", 16)])
+def test_precise_mode_logits_within_1e3_of_reference(golden, tag, name, frames):
+    """north_star tolerance: outputs match the reference PyTorch (fp32) path within 1e-3 relative.  Split-bf16 Linears (three MFMA
+    products through the production GEMM kernel), f32 attention, f32 activations.  Forward only."""
+    g = golden("g4_real_shape")
+    torch.manual_seed(0)
+    m = T.create_model(name, pretrained=False, num_classes=2, all_frames=frames, tubelet_size=2, final_reduction="fc_norm",
+                       use_flash_attn=False, init_scale=1.0, drop_path_rate=0.0)
+    gen = torch.Generator().manual_seed(1234)
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if p.dim() == 1:
+                p.copy_(torch.randn(p.shape, generator=gen) * 0.02 + (1.0 if "norm" in k and k.endswith("weight") else 0.0))
+    torch.manual_seed(1)
+    x = torch.randn(2, 3, frames, 224, 224)
+    m = m.cuda().eval()
+    T.set_precision("precise")
+    try:
+        with torch.no_grad():
+            feats = m.forward_features(x.cuda())
+            logits = m.head(feats)
+        with pytest.raises(Exception):
+            m.train()
+            T.set_precision("precise")
+            m.blocks[0].attn(torch.randn(1, 8, m.embed_dim, device="cuda", requires_grad=True))  # forward-only: loud
+    finally:
+        T.set_precision("fast")
+        m.eval()
+    e_f, e_l = rell2(feats, g[f"{tag}.features"]), rell2(logits, g[f"{tag}.logits"])
+    m_f, m_l = relmax(feats, g[f"{tag}.features"]), relmax(logits, g[f"{tag}.logits"])
+    print(tag, "precise: features rel-l2", e_f, "max-rel", m_f, "| logits rel-l2", e_l, "max-rel", m_l)
+    assert e_f < 1e-3 and e_l < 1e-3 and m_f < 1e-3 and m_l < 1e-3
+
+
+def test_precise_tiny_model_vs_fp64_golden(golden):
+    g = golden("g3_tiny_model")
+    m, P, x = build_tiny()
+    m.eval()
+    T.set_precision("precise")
+    try:
+        with torch.no_grad():
+            feats = m.forward_features(x.cuda())
+            logits = m.head(feats)
+    finally:
+        T.set_precision("fast")
+    assert rell2(feats, g["features"]) < 1e-4 and rell2(logits, g["logits"]) < 1e-4, (rell2(feats, g["features"]), rell2(logits, g["logits"]))
+
+
+def test_precise_mode_training_step_vs_reference_golden(golden):
+    """Gradient side of the parity gate: loss, every gradient and the grad-norm of the tiny model within 1e-3 of the reference
+    (fp64 run of the real reference, tests/golden/g3_tiny_model.npz)."""
+    g = golden("g3_tiny_model")
+    m, P, x = build_tiny()
+    m.train()
+    T.set_precision("precise")
+    try:
+        feats = m.forward_features(x.cuda())
+        logits = m.head(feats)
+        loss = F.cross_entropy(logits, torch.tensor([0, 1], device="cuda"))
+        loss.backward()
+    finally:
+        T.set_precision("fast")
+    assert rell2(logits, g["logits"]) < 1e-4 and abs(loss.item() - float(g["loss"])) < 1e-5
+    grads = {k: p.grad for k, p in m.named_parameters()}
+    gn = O.grad_norm([v.float().cpu() for v in grads.values()])
+    assert abs(gn.item() - float(g["grad_norm"])) < 1e-3 * float(g["grad_norm"])
+    worst = 0.0
+    for k, v in grads.items():
+        head = torch.from_numpy(g[f"grad.{k}.head"]).double()
+        got = v.detach().double().cpu().flatten()[: head.numel()]
+        e = ((got - head).norm() / head.norm().clamp_min(1e-12)).item()
+        worst = max(worst, e)
+        assert e < 1e-3, (k, e)
+        sq = float(g[f"grad.{k}.sqsum"])
+        assert abs((v.double() ** 2).sum().item() - sq) < 2e-3 * sq, k
+    print("precise worst grad rel-l2", worst)
