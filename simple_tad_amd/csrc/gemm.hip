@@ -173,50 +173,53 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
   }
 
   const int nk = p.K / BKT;
-#pragma unroll
-  for (int st = 0; st < STAGES - 1; ++st)
-    if (st < nk) { STAGE_NT(st, st); }
-  int rd = 0, wr = STAGES - 1;
-  for (int kt = 0; kt < nk; ++kt) {
-    // tile kt has landed once all but the younger stages' DMAs of this wave are done; the barrier then (a) publishes every
-    // wave's part of tile kt and (b) proves all waves finished reading tile kt-1, whose buffer the next DMA overwrites
-    wait_stage<LOADS>(min(STAGES - 2, nk - 1 - kt));
-    block_barrier();
-    const char* sa = lds + rd * STAGE_BYTES;
-    const char* sb = sa + A_BYTES;
-    const bool more = kt + STAGES - 1 < nk;
-    const int wr_now = wr, kt_next = kt + STAGES - 1;
-    rd = (rd + 1 == STAGES) ? 0 : rd + 1;
-    wr = (wr + 1 == STAGES) ? 0 : wr + 1;
-#define KSTEP_NT(ks)                                                                                   \
-  {                                                                                                    \
-    bf16x8 af[MREP], bfr[NREP];                                                                        \
-    _Pragma("unroll") for (int j = 0; j < NREP; ++j)                                                   \
-        bfr[j] = *reinterpret_cast<const bf16x8*>(sb + b_rd[j] + ((((KSTEPS > 1 ? 4 * (ks) : 0) + kq) ^ b_sw[j]) << 4));  \
-    _Pragma("unroll") for (int i = 0; i < MREP; ++i)                                                   \
-        af[i] = *reinterpret_cast<const bf16x8*>(sa + a_rd[i] + ((((KSTEPS > 1 ? 4 * (ks) : 0) + kq) ^ a_sw[i]) << 4));   \
-    if (!(p.debug & 2)) {                                                                              \
-      _Pragma("unroll") for (int i = 0; i < MREP; ++i)                                                 \
-          _Pragma("unroll") for (int j = 0; j < NREP; ++j)                                             \
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);  \
-    } else {                                                                                           \
-      _Pragma("unroll") for (int i = 0; i < MREP; ++i) asm volatile("" ::"v"(af[i]));                  \
-      _Pragma("unroll") for (int j = 0; j < NREP; ++j) asm volatile("" ::"v"(bfr[j]));                 \
-    }                                                                                                  \
+#define FRAG_A(dst, base, ks) \
+  _Pragma("unroll") for (int i = 0; i < MREP; ++i)  \
+      dst[i] = *reinterpret_cast<const bf16x8*>((base) + a_rd[i] + ((((KSTEPS > 1 ? 4 * (ks) : 0) + kq) ^ a_sw[i]) << 4))
+#define FRAG_B(dst, base, ks) \
+  _Pragma("unroll") for (int j = 0; j < NREP; ++j)  \
+      dst[j] = *reinterpret_cast<const bf16x8*>((base) + b_rd[j] + ((((KSTEPS > 1 ? 4 * (ks) : 0) + kq) ^ b_sw[j]) << 4))
+#define MFMA_BLOCK(afr, bfr_)                                                                            \
+  if (!(p.debug & 2)) {                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < MREP; ++i)                                                     \
+        _Pragma("unroll") for (int j = 0; j < NREP; ++j)                                                 \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr_[j], afr[i], acc[i][j], 0, 0, 0);    \
+  } else {                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < MREP; ++i) asm volatile("" ::"v"(afr[i]));                     \
+    _Pragma("unroll") for (int j = 0; j < NREP; ++j) asm volatile("" ::"v"(bfr_[j]));                    \
   }
-    // Issuing a tile's LDS-DMA pieces blocks the issuing wave for ~100 cycles per piece.  The two waves that share a SIMD
-    // (wave w and w + NW/2) therefore issue them at different times: the older half before its first k-step, the younger
-    // half between its two k-steps, so the SIMD's matrix pipe always has one wave feeding it.
-    const bool late = wave >= NW / 2;  // wave-uniform (scalar branches); the MFMA code is shared by both halves
-    const bool dma = more && !(p.debug & 1);
-    if (KSTEPS == 2) {
-      if (dma && !late) { STAGE_NT(wr_now, kt_next); }
-      KSTEP_NT(0);
-      if (dma && late) { STAGE_NT(wr_now, kt_next); }
-      KSTEP_NT(1);
-    } else {
-      if (dma) { STAGE_NT(wr_now, kt_next); }
-      KSTEP_NT(0);
+  const bool late = wave >= NW / 2;  // wave-uniform (scalar branches); the MFMA code is shared by both halves
+  {
+#pragma unroll
+    for (int st = 0; st < STAGES - 1; ++st)
+      if (st < nk) { STAGE_NT(st, st); }
+    int rd = 0, wr = STAGES - 1;
+    for (int kt = 0; kt < nk; ++kt) {
+      // tile kt has landed once all but the younger stages' DMAs of this wave are done; the barrier then (a) publishes every
+      // wave's part of tile kt and (b) proves all waves finished reading tile kt-1, whose buffer the next DMA overwrites
+      wait_stage<LOADS>(min(STAGES - 2, nk - 1 - kt));
+      block_barrier();
+      const char* sa = lds + rd * STAGE_BYTES;
+      const char* sb = sa + A_BYTES;
+      const bool more = kt + STAGES - 1 < nk;
+      const int wr_now = wr, kt_next = kt + STAGES - 1;
+      rd = (rd + 1 == STAGES) ? 0 : rd + 1;
+      wr = (wr + 1 == STAGES) ? 0 : wr + 1;
+      // Issuing a tile's LDS-DMA pieces blocks the issuing wave for ~100 cycles per piece.  The two waves that share a SIMD
+      // (wave w and w + NW/2) therefore issue them at different times: the older half before its first k-step, the younger
+      // half between its two k-steps, so the SIMD's matrix pipe always has one wave feeding it.
+      const bool dma = more && !(p.debug & 1);
+      bf16x8 af[MREP], bfr[NREP];
+      if (dma && (!late || KSTEPS == 1)) { STAGE_NT(wr_now, kt_next); }
+      FRAG_B(bfr, sb, 0);
+      FRAG_A(af, sa, 0);
+      MFMA_BLOCK(af, bfr);
+      if (KSTEPS == 2) {
+        if (dma && late) { STAGE_NT(wr_now, kt_next); }
+        FRAG_B(bfr, sb, 1);
+        FRAG_A(af, sa, 1);
+        MFMA_BLOCK(af, bfr);
+      }
     }
   }
 
@@ -340,9 +343,10 @@ struct GemmTN {
   const uint16_t* P;  // [Mr, N]  (dy)
   const uint16_t* Q;  // [Mr, K]  (x)
   float* slab;        // [splits][N][K]
-  float* bias_slab;   // [splits][N] column sums of P (bias gradient), or null
+  float* bias_slab;   // [splits * tiles_k][N] partial column sums of P (bias gradient), or null
   int Mr, N, K;
   int rows_per_split;  // multiple of 64
+  int debug;           // ablation bits as in GemmNT
 };
 
 // swizzle of the 16-byte chunk index within a tile row (rows are >= 256 bytes); changes bits 1..3 only
@@ -364,13 +368,14 @@ __device__ __forceinline__ bf16x8 tr_frag_tn(const char* base, int rowbytes, int
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int BKT = 64>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(const GemmTN p) {
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   constexpr int MREP = WTM / 16, NREP = WTN / 16;
   constexpr int PROW = BM * 2, QROW = BN * 2;  // bytes per LDS row
-  constexpr int P_BYTES = BK * PROW, Q_BYTES = BK * QROW;
+  constexpr int KSTEPS = BKT / 32;             // reduction rows per stage: 64 (two k-steps) or 32 (one, deeper ring)
+  constexpr int P_BYTES = BKT * PROW, Q_BYTES = BKT * QROW;
   constexpr int STAGE_BYTES = P_BYTES + Q_BYTES;
   constexpr int P_PIECES = P_BYTES / 1024 / NW, Q_PIECES = Q_BYTES / 1024 / NW;
   constexpr int P_LPR = PROW / 16, Q_LPR = QROW / 16;  // lanes (16-B chunks) per row
@@ -394,7 +399,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(const Ge
   const int tn_ = tile / tiles_k, tk_ = tile - tn_ * tiles_k;
   const int n0 = tn_ * BM, k0 = tk_ * BN;
   const int mr0 = split * p.rows_per_split;
-  const int nt = p.rows_per_split / BK;
+  const int nt = p.rows_per_split / BKT;
 
   const int p_bytes = (int)((int64_t)p.Mr * p.N * 2), q_bytes = (int)((int64_t)p.Mr * p.K * 2);
 
@@ -420,21 +425,25 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(const Ge
     q_off[i] = (uint32_t)(mr0 + row) * (uint32_t)(p.K * 2) + (uint32_t)(col * 2);
   }
 #define STAGE_TN(buf, t) \
-  stage_tile<P_PIECES, NW>(p.P, p_bytes, lds + (buf) * STAGE_BYTES, p_off, (uint32_t)(t) * BK * (uint32_t)(p.N * 2), wave); \
-  stage_tile<Q_PIECES, NW>(p.Q, q_bytes, lds + (buf) * STAGE_BYTES + P_BYTES, q_off, (uint32_t)(t) * BK * (uint32_t)(p.K * 2), wave)
+  stage_tile<P_PIECES, NW>(p.P, p_bytes, lds + (buf) * STAGE_BYTES, p_off, (uint32_t)(t) * BKT * (uint32_t)(p.N * 2), wave); \
+  stage_tile<Q_PIECES, NW>(p.Q, q_bytes, lds + (buf) * STAGE_BYTES + P_BYTES, q_off, (uint32_t)(t) * BKT * (uint32_t)(p.K * 2), wave)
 
   // transposed fragment reads: 16-lane group g = lane>>4 covers reduction rows 8g..8g+7 of a 32-deep k-step;
   // lane i = lane&15 of the group supplies row (i>>2) (+4 for the second read), columns c0 + 4*(i&3) .. +3
   const int g = lane >> 4, li = lane & 15;
-  // bias gradient = column sums of P = P^T * ones: one extra MFMA per row fragment against an all-ones B operand, done only by
-  // the workgroups of the first K column-panel and, inside them, by the waves of the first wave column
-  const bool do_bias = (p.bias_slab != nullptr) && (tk_ == 0) && (wn == 0);
+  // bias gradient = column sums of P = P^T * ones: one extra MFMA per row fragment against an all-ones B operand.  The work is
+  // spread evenly (the grid is one workgroup per CU, so any imbalance is pure idle time): the tiles_k workgroups that share a
+  // row panel take turns over the reduction tiles (t % tiles_k == own column-panel index), and inside a workgroup the WAVES_N
+  // waves that share the same rows split the row fragments (i % WAVES_N == wn).  Partials: bias_slab[split*tiles_k + tk_][N].
+  const bool bias_on = (p.bias_slab != nullptr);
+  static_assert(MREP % WAVES_N == 0, "bias fragments split across the waves of a row");
+  constexpr int BREP = MREP / WAVES_N;
   bf16x8 ones;
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
-  f32x4 bacc[MREP];
+  f32x4 bacc[BREP];
 #pragma unroll
-  for (int i = 0; i < MREP; ++i) bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < BREP; ++i) bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 acc[MREP][NREP];
 #pragma unroll
   for (int i = 0; i < MREP; ++i)
@@ -452,6 +461,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(const Ge
     const char* sp = lds + rd * STAGE_BYTES;
     const char* sq = sp + P_BYTES;
     const bool more = t + STAGES - 1 < nt;
+    const bool bias_now = bias_on && (t % tiles_k == tk_);
     const int wr_now = wr, t_next = t + STAGES - 1;
     rd = (rd + 1 == STAGES) ? 0 : rd + 1;
     wr = (wr + 1 == STAGES) ? 0 : wr + 1;
@@ -460,29 +470,41 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(const Ge
     bf16x8 pf[MREP], qf[NREP];                                                                              \
     _Pragma("unroll") for (int j = 0; j < NREP; ++j) qf[j] = tr_frag_tn(sq, QROW, (ks), wn * WTN + 16 * j, lane);  \
     _Pragma("unroll") for (int i = 0; i < MREP; ++i) pf[i] = tr_frag_tn(sp, PROW, (ks), wm * WTM + 16 * i, lane);  \
-    _Pragma("unroll") for (int i = 0; i < MREP; ++i)                                                        \
-        _Pragma("unroll") for (int j = 0; j < NREP; ++j)                                                    \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[i], qf[j], acc[i][j], 0, 0, 0);          \
-    if (do_bias) {                                                                                          \
+    if (!(p.debug & 2)) {                                                                                   \
       _Pragma("unroll") for (int i = 0; i < MREP; ++i)                                                      \
-          bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[i], ones, bacc[i], 0, 0, 0);                 \
+          _Pragma("unroll") for (int j = 0; j < NREP; ++j)                                                  \
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[i], qf[j], acc[i][j], 0, 0, 0);        \
+    } else {                                                                                                \
+      _Pragma("unroll") for (int i = 0; i < MREP; ++i) asm volatile("" ::"v"(pf[i]));                       \
+      _Pragma("unroll") for (int j = 0; j < NREP; ++j) asm volatile("" ::"v"(qf[j]));                       \
+    }                                                                                                       \
+    if (bias_now) {                                                                                         \
+      _Pragma("unroll") for (int ib = 0; ib < BREP; ++ib)                                                   \
+          _Pragma("unroll") for (int w2 = 0; w2 < WAVES_N; ++w2)                                            \
+              if (w2 == wn) bacc[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[ib * WAVES_N + w2], ones, bacc[ib], 0, 0, 0); \
     }                                                                                                       \
   }
     const bool late = wave >= NW / 2;  // stagger the DMA issue of the two waves that share a SIMD (see gemm_nt_kernel)
-    if (more && !late) { STAGE_TN(wr_now, t_next); }
-    KSTEP_TN(0);
-    if (more && late) { STAGE_TN(wr_now, t_next); }
-    KSTEP_TN(1);
+    const bool dma = more && !(p.debug & 1);
+    if (KSTEPS == 2) {
+      if (dma && !late) { STAGE_TN(wr_now, t_next); }
+      KSTEP_TN(0);
+      if (dma && late) { STAGE_TN(wr_now, t_next); }
+      KSTEP_TN(1);
+    } else {
+      if (dma) { STAGE_TN(wr_now, t_next); }
+      KSTEP_TN(0);
+    }
   }
 
-  if (do_bias && li == 0) {
-    float* bo = p.bias_slab + (int64_t)split * p.N;
+  if (bias_on && li == 0) {
+    float* bo = p.bias_slab + ((int64_t)split * tiles_k + tk_) * p.N;
 #pragma unroll
-    for (int i = 0; i < MREP; ++i)
+    for (int ib = 0; ib < BREP; ++ib)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int n = n0 + wm * WTM + 16 * i + 4 * g + r;
-        if (n < p.N) bo[n] = bacc[i][r];
+        const int n = n0 + wm * WTM + 16 * (ib * WAVES_N + wn) + 4 * g + r;
+        if (n < p.N) bo[n] = bacc[ib][r];
       }
   }
   // D[row = n][col = k]: lane col = lane&15, rows 4*(lane>>4) + r
@@ -552,7 +574,7 @@ static int tn_variant() {
   return forced ? forced : 1;
 }
 static int tn_plan(int64_t Mr, int N, int K, int* splits, int* rows_per_split) {
-  const int bn = tn_variant() == 1 ? 256 : 128;
+  const int bn = tn_variant() != 3 ? 256 : 128;
   const int tiles = ((N + 255) / 256) * ((K + bn - 1) / bn);
   const int64_t ktiles = (Mr + BK - 1) / BK;
   int s = (256 + tiles - 1) / tiles;
@@ -568,7 +590,8 @@ static int tn_plan(int64_t Mr, int N, int K, int* splits, int* rows_per_split) {
 size_t gemm_tn_workspace_bytes(int64_t Mr, int N, int K) {
   int s, r;
   tn_plan(Mr, N, K, &s, &r);
-  return (size_t)s * ((size_t)N * (size_t)K + (size_t)N) * sizeof(float);
+  const int bn = tn_variant() != 3 ? 256 : 128;
+  return (size_t)s * ((size_t)N * (size_t)K + (size_t)((K + bn - 1) / bn) * (size_t)N) * sizeof(float);
 }
 
 int launch_gemm_tn(const uint16_t* P, const uint16_t* Q, float* out, float* bias_out, int accumulate, void* ws, size_t ws_bytes,
@@ -578,9 +601,12 @@ int launch_gemm_tn(const uint16_t* P, const uint16_t* Q, float* out, float* bias
   if (Mr * (int64_t)N * 2 >= (1ll << 32) || Mr * (int64_t)K * 2 >= (1ll << 32)) { set_error("gemm_tn: operand exceeds 4 GiB"); return TAD_EINVAL; }
   GemmTN p;
   p.P = P; p.Q = Q; p.slab = (float*)ws; p.Mr = (int)Mr; p.N = N; p.K = K;
+  static const int debug = env_int("TAD_GEMM_DEBUG");
+  p.debug = debug;
   int splits;
   const int tiles = tn_plan(Mr, N, K, &splits, &p.rows_per_split);
-  if (ws_bytes < (size_t)splits * ((size_t)N * K + N) * sizeof(float)) { set_error("gemm_tn: workspace too small"); return TAD_ENOSPACE; }
+  const int tiles_k = (K + (tn_variant() != 3 ? 256 : 128) - 1) / (tn_variant() != 3 ? 256 : 128);
+  if (ws_bytes < (size_t)splits * ((size_t)N * K + (size_t)tiles_k * N) * sizeof(float)) { set_error("gemm_tn: workspace too small"); return TAD_ENOSPACE; }
   p.bias_slab = bias_out ? p.slab + (size_t)splits * N * K : nullptr;
   if (tn_variant() == 1)
     hipLaunchKernelGGL((gemm_tn_kernel<256, 256, 2, 4, 2>), dim3(tiles * splits), dim3(512), 0, st, p);
@@ -590,7 +616,7 @@ int launch_gemm_tn(const uint16_t* P, const uint16_t* Q, float* out, float* bias
   if (rc) return rc;
   rc = launch_reduce_partials(p.slab, out, splits, (int64_t)N * K, accumulate, st);
   if (rc || !bias_out) return rc;
-  return launch_reduce_partials(p.bias_slab, bias_out, splits, N, accumulate, st);
+  return launch_reduce_partials(p.bias_slab, bias_out, splits * tiles_k, N, accumulate, st);
 }
 
 }  // namespace tad
