@@ -33,6 +33,8 @@ __device__ __forceinline__ float half_swap_sum(float x) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+
 template <bool OUT_BF16>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, void* __restrict__ out,
                                                        float* __restrict__ lse, int N, int H, float scale) {
@@ -98,100 +100,90 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
   const int v_q = li >> 2, v_p = li & 3;
   const int v_h = G >> 1, v_dc = 16 * (G & 1) + 4 * v_p;  // d offset inside a 32-wide d tile
 
+  // all-ones A operand: row sums of P^T come out of the matrix pipe (4 extra MFMAs per tile) instead of 32 v_add per lane --
+  // the kernel is VALU-issue bound (MFMA pipe ~30 % busy), and the sum then uses the same bf16-rounded P as the PV product
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+
+  // One K/V tile of 64 keys out of LDS buffer BUF (a literal: every LDS address below is then lane-constant + immediate).
+#define FWD_TILE(BUF, T)                                                                                                  \
+  {                                                                                                                       \
+    const int kv0 = (T) * KV_TILE;                                                                                        \
+    LOAD_TILE(kv0 + KV_TILE);                                                                                             \
+    const char* kl = lds + (BUF) * 2 * TILE_BYTES;                                                                        \
+    const char* vl = kl + TILE_BYTES;                                                                                     \
+    f32x16 s[2];                                                                                                          \
+    _Pragma("unroll") for (int kt = 0; kt < 2; ++kt) {                                                                    \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;                                                      \
+      const int key = kt * 32 + ql;                                                                                       \
+      _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                                  \
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kl + key * 128 + (((2 * ks + h5) ^ swk(key)) << 4));           \
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kt], 0, 0, 0);                                      \
+      }                                                                                                                   \
+    }                                                                                                                     \
+    if (kv0 + KV_TILE > N) { /* ragged last tile: mask keys >= N */                                                       \
+      _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                                    \
+          _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                \
+        const int key = kv0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h5;                                                  \
+        if (key >= N) s[kt][r] = -1e30f;                                                                                  \
+      }                                                                                                                   \
+    }                                                                                                                     \
+    float mloc = s[0][0];                                                                                                 \
+    _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                                      \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[kt][r]);                                      \
+    /* deferred rescale: keep the old running max while the tile max exceeds it by < RESCALE_THR (log2 units): P may reach   \
+       2^THR instead of 1 (harmless in f32/bf16) and the O-wide multiply disappears from almost every tile.  The decision    \
+       precedes the exponentiation of this tile (textbook order). */                                                      \
+    const float m_tile = half_swap_max(mloc);                                                                             \
+    if (__any((m_tile - m_run) * c > RESCALE_THR)) {                                                                      \
+      const float m_new = fmaxf(m_run, m_tile);                                                                           \
+      const float alpha = fast_exp2((m_run - m_new) * c);                                                                 \
+      m_run = m_new;                                                                                                      \
+      l_run *= alpha;                                                                                                     \
+      _Pragma("unroll") for (int dt = 0; dt < 2; ++dt)                                                                    \
+          _Pragma("unroll") for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;                                               \
+    }                                                                                                                     \
+    const float mc = m_run * c;                                                                                           \
+    bf16x8 pf[2][2];                                                                                                      \
+    _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                                      \
+        _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2)                                                                  \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                                 \
+                pf[kt][s2][j] = (__bf16)fast_exp2(s[kt][8 * s2 + j] * c - mc);                                            \
+    f32x16 rs;                                                                                                            \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) rs[r] = 0.f;                                                           \
+    _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                                      \
+        _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                                \
+      rs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[kt][s2], rs, 0, 0, 0);                                        \
+      const int k0 = kt * 32 + 16 * s2 + 4 * v_h + v_q; /* first transposed read: 4 keys from k0 - v_q; second: +8 */      \
+      const int k1 = k0 + 8;                                                                                              \
+      _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) {                                                                  \
+        const int col = dt * 32 + v_dc;                                                                                   \
+        const int ch = col >> 3, sub = (col & 7) * 2;                                                                     \
+        const char* a0 = vl + k0 * 128 + ((ch ^ swv(k0)) << 4) + sub;                                                     \
+        const char* a1 = vl + k1 * 128 + ((ch ^ swv(k1)) << 4) + sub;                                                     \
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(a0)); \
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(a1)); \
+        const s16x8_t vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};                                      \
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[kt][s2], o[dt], 0, 0, 0);      \
+      }                                                                                                                   \
+    }                                                                                                                     \
+    l_run += rs[0]; /* every row of rs holds the full column sum over the 64 keys: no cross-lane step */                  \
+    WRITE_TILE((BUF) ^ 1);                                                                                                \
+    __syncthreads();                                                                                                      \
+  }
+
   const int nt = (N + KV_TILE - 1) / KV_TILE;
   LOAD_TILE(0);
   WRITE_TILE(0);
   __syncthreads();
-  for (int t = 0; t < nt; ++t) {
-    const int kv0 = t * KV_TILE;
-    LOAD_TILE(kv0 + KV_TILE);
-    const char* kl = lds + (t & 1) * 2 * TILE_BYTES;
-    const char* vl = kl + TILE_BYTES;
-
-    // ---- S^T = K Q^T : two 32-key tiles
-    f32x16 s[2];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-      const int key = kt * 32 + ql;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kl + key * 128 + (((2 * ks + h5) ^ swk(key)) << 4));
-        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kt], 0, 0, 0);
-      }
-    }
-    if (kv0 + KV_TILE > N) {  // ragged last tile: mask keys >= N
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kv0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h5;
-          if (key >= N) s[kt][r] = -1e30f;
-        }
-    }
-    // ---- online softmax (query on the lane)
-    float mloc = s[0][0];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[kt][r]);
-    // deferred rescale: keep the old running max while the tile max exceeds it by less than RESCALE_THR (log2 units), so P can
-    // reach 2^THR instead of 1 -- harmless in f32 / bf16 (relative precision is scale-free) and it removes the O-wide multiply
-    // from almost every tile.  The decision precedes the exponentiation of this tile (textbook order).
-    const float m_tile = half_swap_max(mloc);
-    if (__any((m_tile - m_run) * c > RESCALE_THR)) {
-      const float m_new = fmaxf(m_run, m_tile);
-      const float alpha = fast_exp2((m_run - m_new) * c);
-      m_run = m_new;
-      l_run *= alpha;
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-    }
-    const float mc = m_run * c;
-    float psum = 0.f;
-    bf16x8 pf[2][2];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float pv = fast_exp2(s[kt][8 * s2 + j] * c - mc);
-          psum += pv;
-          pf[kt][s2][j] = (__bf16)pv;
-        }
-    l_run += psum;
-
-    // ---- O^T += V^T P^T
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const int k0 = kt * 32 + 16 * s2 + 4 * v_h + v_q;  // first transposed read: keys k0-v_q .. +3 ; second: +8
-        const int k1 = k0 + 8;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          const int col = dt * 32 + v_dc;
-          const int ch = col >> 3, sub = (col & 7) * 2;
-          const char* a0 = vl + k0 * 128 + ((ch ^ swv(k0)) << 4) + sub;
-          const char* a1 = vl + k1 * 128 + ((ch ^ swv(k1)) << 4) + sub;
-          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(a0));
-          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(a1));
-          typedef __attribute__((ext_vector_type(8))) short s16x8;
-          const s16x8 vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[kt][s2], o[dt], 0, 0, 0);
-        }
-      }
-
-    WRITE_TILE((t + 1) & 1);
-    __syncthreads();
+  for (int t = 0; t < nt; t += 2) {
+    FWD_TILE(0, t);
+    if (t + 1 < nt) FWD_TILE(1, t + 1);
   }
 
   // ---- epilogue
-  const float l_tot = half_swap_sum(l_run);
+  const float l_tot = l_run;  // already the full row sum (see FWD_TILE)
   const float inv = 1.f / l_tot;
   const int qrow = q0 + ql;
   if (qrow < N) {
