@@ -1,0 +1,122 @@
+"""Module-surface variants and the training loop on the GPU: other widths (ViT-S D=384 -> N=1152 column tails, ViT-L D=1024),
+final_reduction modes, learnable pos-embed, activation checkpointing, gradient accumulation through the engine, and a short
+optimisation run whose loss must fall.  Reference semantics come from the oracle."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import golden_recipe as R
+import simple_tad_amd as T
+from simple_tad_amd import engine as E
+from simple_tad_amd.parallel import DataParallel
+from oracle import vit_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def rell2(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def _model(embed_dim, heads, depth=2, **kw):
+    torch.manual_seed(0)
+    m = T.VisionTransformer(img_size=32, patch_size=16, embed_dim=embed_dim, depth=depth, num_heads=heads, mlp_ratio=4, qkv_bias=True,
+                            all_frames=4, tubelet_size=2, num_classes=2, init_scale=1.0, **kw)
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.02)
+    return m
+
+
+@pytest.mark.parametrize("D,H", [(384, 6), (1024, 16), (1280, 20)])
+def test_other_widths_forward_backward(D, H):
+    m = _model(D, H).cuda().train()
+    x = torch.randn(3, 3, 4, 32, 32)
+    y = torch.tensor([0, 1, 1])
+    logits = m(x.cuda())
+    loss = F.cross_entropy(logits, y.cuda())
+    loss.backward()
+    P = {k: v.detach().double().cpu().requires_grad_() for k, v in m.state_dict().items()}
+    ref = O.forward(x.double(), P, depth=2, num_heads=H, tubelet=2, patch=16)
+    F.cross_entropy(ref, y).backward()
+    assert rell2(logits, ref) < 1e-2
+    for k in ("blocks.0.attn.qkv.weight", "blocks.1.mlp.fc2.weight", "patch_embed.proj.weight", "blocks.0.attn.q_bias", "fc_norm.weight"):
+        got = dict(m.named_parameters())[k].grad
+        assert rell2(got, P[k].grad) < 4e-2, (k, rell2(got, P[k].grad))
+
+
+def test_final_reduction_modes_learnable_pos_and_checkpointing():
+    x = torch.randn(2, 3, 4, 32, 32)
+    for fr in ("cls", "none"):
+        m = _model(128, 2, final_reduction=fr).cuda().eval()
+        with torch.no_grad():
+            f = m.forward_features(x.cuda())
+        P = {k: v.detach().double().cpu() for k, v in m.state_dict().items()}
+        ref = O.forward_features(x.double(), P, depth=2, num_heads=2, tubelet=2, patch=16, final_reduction=fr)
+        assert f.shape == ref.shape and rell2(f, ref) < 6e-3, fr
+    # learnable positional embedding: pos_embed is a Parameter, appears in the state dict and receives a gradient
+    m = _model(128, 2, use_learnable_pos_emb=True).cuda().train()
+    assert "pos_embed" in m.state_dict()
+    out = m(x.cuda())
+    out.sum().backward()
+    assert m.pos_embed.grad is not None and float(m.pos_embed.grad.abs().sum()) > 0
+    P = {k: v.detach().double().cpu() for k, v in m.state_dict().items()}
+    ref = O.forward(x.double(), P, depth=2, num_heads=2, tubelet=2, patch=16, pos_embed=P["pos_embed"])
+    assert rell2(out, ref) < 6e-3
+    # activation checkpointing gives the same gradients as the plain path
+    m1 = _model(128, 2).cuda().train()
+    m2 = _model(128, 2, use_checkpoint=True).cuda().train()
+    m2.load_state_dict(m1.state_dict())
+    for mm in (m1, m2):
+        F.cross_entropy(mm(x.cuda()), torch.tensor([1, 0], device="cuda")).backward()
+    for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert torch.allclose(p1.grad, p2.grad, rtol=0, atol=0), k   # same kernels, same order -> bit-identical
+
+
+def test_training_loop_on_gpu_loss_falls_and_accumulation_matches():
+    torch.manual_seed(0)
+    m = _model(128, 2, drop_path_rate=0.1).cuda()
+    dp = DataParallel(m)                       # world size 1: flat gradient buffer, no exchange
+    opt = E.create_optimizer(dp, lr=2e-3, weight_decay=0.05, layer_decay=0.75)
+    scaler = E.NativeScalerWithGradNormCount(dp)
+    # learnable synthetic task: label = sign of the mean of channel 0
+    xs = torch.randn(32, 3, 4, 32, 32)
+    xs[:, 0] += (torch.arange(32) % 2).float().view(-1, 1, 1, 1) * 1.5 - 0.75
+    ys = (torch.arange(32) % 2).long()
+    data = [(xs[i:i + 8], ys[i:i + 8], None, None) for i in range(0, 32, 8)] * 12
+    lr = E.cosine_scheduler(2e-3, 1e-5, 1, len(data), warmup_epochs=0)
+    stats = E.train_one_epoch(dp, torch.nn.CrossEntropyLoss(), data, opt, torch.device("cuda"), 0, scaler, lr_schedule_values=lr,
+                              num_training_steps_per_epoch=len(data), update_freq=1)
+    first, last = sum(stats["loss"][:4]) / 4, sum(stats["loss"][-4:]) / 4
+    assert all(math.isfinite(v) for v in stats["loss"]) and all(g is not None and g > 0 for g in stats["grad_norm"])
+    assert last < 0.6 * first, (first, last)
+    # gradient accumulation (update_freq=2 over two half batches) == one full batch, with drop-path off
+    ma, mb = _model(128, 2).cuda().train(), _model(128, 2).cuda().train()
+    mb.load_state_dict(ma.state_dict())
+    xb, yb = xs[:8].cuda(), ys[:8].cuda()
+    F.cross_entropy(ma(xb), yb).backward()
+    for half in (slice(0, 4), slice(4, 8)):
+        (F.cross_entropy(mb(xb[half]), yb[half]) / 2).backward()
+    for (k, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert rell2(pb.grad, pa.grad) < 2e-2, k
+    # grad-norm definition on the GPU path == reference definition on the same gradients
+    gn = E.get_grad_norm_(list(ma.parameters()))
+    ref = O.grad_norm([p.grad.float().cpu() for p in ma.parameters()])
+    assert abs(gn.item() - ref.item()) < 1e-4 * ref.item()
+
+
+def test_ragged_and_tiny_inputs():
+    """single clip, single token-row tiles, N not a multiple of any tile (8 tokens), batch that is not a multiple of anything"""
+    m = _model(128, 2).cuda().eval()
+    for B in (1, 5):
+        x = torch.randn(B, 3, 4, 32, 32)
+        with torch.no_grad():
+            out = m(x.cuda())
+        P = {k: v.detach().double().cpu() for k, v in m.state_dict().items()}
+        assert rell2(out, O.forward(x.double(), P, depth=2, num_heads=2, tubelet=2, patch=16)) < 6e-3
+    with pytest.raises(AssertionError):
+        m(torch.randn(1, 3, 4, 48, 48).cuda())  # wrong spatial size: the reference's assert (modeling_finetune.py:188)
