@@ -61,31 +61,29 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
   }
 
-  // staging: thread -> key (tid>>3) + 32*pass, 16-byte chunk tid&7.  Plain named registers (no arrays / lambdas: those were
-  // demoted to scratch memory by the compiler) and unconditional loads (the tile index is clamped, the last prefetch is a
-  // harmless reload of the final tile).
-  const int skey = tid >> 3, schunk = tid & 7;
-  uint4 kreg0, kreg1, vreg0, vreg1;
-#define LOAD_TILE(kv0)                                                                              \
-  {                                                                                                 \
-    int key0_ = (kv0) + skey, key1_ = (kv0) + skey + 32;                                            \
-    key0_ = key0_ > N - 1 ? N - 1 : key0_;                                                          \
-    key1_ = key1_ > N - 1 ? N - 1 : key1_;                                                          \
-    kreg0 = *reinterpret_cast<const uint4*>(kbase + (int64_t)key0_ * tok_stride + schunk * 8);      \
-    kreg1 = *reinterpret_cast<const uint4*>(kbase + (int64_t)key1_ * tok_stride + schunk * 8);      \
-    vreg0 = *reinterpret_cast<const uint4*>(vbase + (int64_t)key0_ * tok_stride + schunk * 8);      \
-    vreg1 = *reinterpret_cast<const uint4*>(vbase + (int64_t)key1_ * tok_stride + schunk * 8);      \
+  // staging: K/V tiles go global -> LDS by LDS-DMA (no staging registers, no ds_write): a 1-KiB piece = 8 keys x 128 B; wave w
+  // moves pieces w and w+4 of K and of V.  The LDS destination is lane-linear, so the swizzle is applied to the per-lane
+  // SOURCE chunk.  Keys past the end of the tensor read as zero (buffer bounds check); keys >= N of this sequence are masked.
+  const uint32_t qkv_bytes = (uint32_t)gridDim.z * (uint32_t)N * (uint32_t)tok_stride * 2u;
+  const auto rs_qkv = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(qkv), 0, (int)qkv_bytes, 0x00020000);
+  const int dkey = lane >> 3, dch = lane & 7;
+  uint32_t dma_k[2], dma_v[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int key = (wave + 4 * i) * 8 + dkey;
+    const uint32_t rowb = (uint32_t)(((int64_t)b * N + key) * tok_stride * 2) + (uint32_t)(head * HD * 2);
+    dma_k[i] = rowb + (uint32_t)(H * HD * 2) + (uint32_t)((dch ^ swk(key)) << 4);
+    dma_v[i] = rowb + (uint32_t)(2 * H * HD * 2) + (uint32_t)((dch ^ swv(key)) << 4);
   }
-  const int kw0 = skey * 128 + ((schunk ^ swk(skey)) << 4), kw1 = (skey + 32) * 128 + ((schunk ^ swk(skey + 32)) << 4);
-  const int vw0 = skey * 128 + ((schunk ^ swv(skey)) << 4), vw1 = (skey + 32) * 128 + ((schunk ^ swv(skey + 32)) << 4);
-#define WRITE_TILE(buf)                                                  \
-  {                                                                      \
-    char* kl_ = lds + (buf) * 2 * TILE_BYTES;                            \
-    char* vl_ = kl_ + TILE_BYTES;                                        \
-    *reinterpret_cast<uint4*>(kl_ + kw0) = kreg0;                        \
-    *reinterpret_cast<uint4*>(kl_ + kw1) = kreg1;                        \
-    *reinterpret_cast<uint4*>(vl_ + vw0) = vreg0;                        \
-    *reinterpret_cast<uint4*>(vl_ + vw1) = vreg1;                        \
+  const uint32_t tile_step = (uint32_t)(tok_stride * 2);  // bytes per key
+#define DMA_TILE(buf, kv0)                                                                                                  \
+  {                                                                                                                         \
+    char* kl_ = lds + (buf) * 2 * TILE_BYTES;                                                                               \
+    const uint32_t adv_ = (uint32_t)(kv0) * tile_step;                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                         \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_qkv, LDS_PTR(kl_ + (wave + 4 * i) * 1024), 16, dma_k[i] + adv_, 0, 0, 0); \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_qkv, LDS_PTR(kl_ + TILE_BYTES + (wave + 4 * i) * 1024), 16, dma_v[i] + adv_, 0, 0, 0); \
+    }                                                                                                                       \
   }
 
   f32x16 o[2];
@@ -110,7 +108,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
 #define FWD_TILE(BUF, T)                                                                                                  \
   {                                                                                                                       \
     const int kv0 = (T) * KV_TILE;                                                                                        \
-    LOAD_TILE(kv0 + KV_TILE);                                                                                             \
+    if ((T) + 1 < nt) DMA_TILE((BUF) ^ 1, kv0 + KV_TILE);                                                                   \
     const char* kl = lds + (BUF) * 2 * TILE_BYTES;                                                                        \
     const char* vl = kl + TILE_BYTES;                                                                                     \
     f32x16 s[2];                                                                                                          \
@@ -169,13 +167,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
       }                                                                                                                   \
     }                                                                                                                     \
     l_run += rs[0]; /* every row of rs holds the full column sum over the 64 keys: no cross-lane step */                  \
-    WRITE_TILE((BUF) ^ 1);                                                                                                \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                      \
     __syncthreads();                                                                                                      \
   }
 
   const int nt = (N + KV_TILE - 1) / KV_TILE;
-  LOAD_TILE(0);
-  WRITE_TILE(0);
+  DMA_TILE(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int t = 0; t < nt; t += 2) {
     FWD_TILE(0, t);
