@@ -123,27 +123,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
   const float lse2 = lse[((int64_t)b * H + head) * N + qrow] * LOG2E;
   const float dlt = delta[((int64_t)b * H + head) * N + qrow];
 
-  const int skey = tid >> 3, schunk = tid & 7;
-  uint4 kreg0, kreg1, vreg0, vreg1;  // named registers, unconditional clamped loads (see attn_fwd.hip)
-#define LOAD_KV(kv0)                                                                         \
-  {                                                                                          \
-    int key0_ = (kv0) + skey, key1_ = (kv0) + skey + 32;                                     \
-    key0_ = key0_ > N - 1 ? N - 1 : key0_;                                                   \
-    key1_ = key1_ > N - 1 ? N - 1 : key1_;                                                   \
-    kreg0 = *reinterpret_cast<const uint4*>(kbase + (int64_t)key0_ * tok + schunk * 8);      \
-    kreg1 = *reinterpret_cast<const uint4*>(kbase + (int64_t)key1_ * tok + schunk * 8);      \
-    vreg0 = *reinterpret_cast<const uint4*>(vbase + (int64_t)key0_ * tok + schunk * 8);      \
-    vreg1 = *reinterpret_cast<const uint4*>(vbase + (int64_t)key1_ * tok + schunk * 8);      \
+  // K/V tiles go global -> LDS by LDS-DMA (see attn_fwd.hip): 1-KiB piece = 8 keys x 128 B, wave w moves pieces w and w+4 of K and
+  // of V; the swizzle is applied to the per-lane SOURCE chunk.  Reads past the tensor return zero; keys >= N are masked below.
+  const uint32_t qkv_bytes = (uint32_t)gridDim.z * (uint32_t)N * (uint32_t)tok * 2u;
+  const auto rs_qkv = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(qkv), 0, (int)qkv_bytes, 0x00020000);
+  uint32_t dma_k[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int key = (wave + 4 * i) * 8 + (lane >> 3);
+    dma_k[i] = (uint32_t)(((int64_t)b * N + key) * tok * 2) + (uint32_t)((head + H) * BHD * 2) + (uint32_t)(((lane & 7) ^ sw_dual(key)) << 4);
   }
-  const int w0 = skey * 128 + ((schunk ^ sw_dual(skey)) << 4), w1 = (skey + 32) * 128 + ((schunk ^ sw_dual(skey + 32)) << 4);
-#define WRITE_KV(buf)                                           \
-  {                                                             \
-    char* kl_ = lds + (buf) * 2 * TILE_BYTES;                   \
-    char* vl_ = kl_ + TILE_BYTES;                               \
-    *reinterpret_cast<uint4*>(kl_ + w0) = kreg0;                \
-    *reinterpret_cast<uint4*>(kl_ + w1) = kreg1;                \
-    *reinterpret_cast<uint4*>(vl_ + w0) = vreg0;                \
-    *reinterpret_cast<uint4*>(vl_ + w1) = vreg1;                \
+  const uint32_t v_off = (uint32_t)(H * BHD * 2), key_step = (uint32_t)(tok * 2);
+#define DMA_KV(buf, kv0)                                                                                                        \
+  {                                                                                                                             \
+    char* kl_ = lds + (buf) * 2 * TILE_BYTES;                                                                                   \
+    const uint32_t adv_ = (uint32_t)(kv0) * key_step;                                                                           \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                             \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_qkv, LDS_PTR(kl_ + (wave + 4 * i) * 1024), 16, dma_k[i] + adv_, 0, 0, 0);     \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_qkv, LDS_PTR(kl_ + TILE_BYTES + (wave + 4 * i) * 1024), 16, dma_k[i] + v_off + adv_, 0, 0, 0); \
+    }                                                                                                                           \
   }
 
   f32x16 dq[2];
@@ -153,12 +151,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
     for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
 
   const int nt = (N + 63) / 64;
-  LOAD_KV(0);
-  WRITE_KV(0);
+  DMA_KV(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
     const int kv0 = t * 64;
-    LOAD_KV(kv0 + 64);
+    if (t + 1 < nt) DMA_KV((t + 1) & 1, kv0 + 64);
     const char* kl = lds + (t & 1) * 2 * TILE_BYTES;
     const char* vl = kl + TILE_BYTES;
 #pragma unroll
@@ -191,7 +189,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
           dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_dual(kl, kt * 32 + 16 * s2, dt * 32, lane), dsf, dq[dt], 0, 0, 0);
       }
     }
-    WRITE_KV((t + 1) & 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
 
@@ -211,7 +209,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
+__global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
                                                            uint16_t* __restrict__ dqkv, int N, int H, float scale) {
   constexpr int TILE_BYTES = 64 * 128;
@@ -242,19 +240,30 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
     vfr[ks] = *reinterpret_cast<const bf16x8*>(vbase + (int64_t)krow * tok + 16 * ks + 8 * h5);
   }
 
-  const int srow = tid >> 3, schunk = tid & 7;
-  uint4 qreg0, qreg1, doreg0, doreg1;
+  // Q / dO tiles go global -> LDS by LDS-DMA (1-KiB piece = 8 rows x 128 B, wave w moves pieces w and w+4 of each; swizzle on the
+  // per-lane SOURCE chunk); rows past the tensor read as zero, rows >= N are neutralised through the row constants below.
+  const uint32_t qkv_bytes = (uint32_t)gridDim.z * (uint32_t)N * (uint32_t)tok * 2u;
+  const uint32_t do_bytes = (uint32_t)gridDim.z * (uint32_t)N * (uint32_t)(H * BHD) * 2u;
+  const auto rs_qkv = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(qkv), 0, (int)qkv_bytes, 0x00020000);
+  const auto rs_do = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(dout), 0, (int)do_bytes, 0x00020000);
+  uint32_t dma_q[2], dma_do[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wave + 4 * i) * 8 + (lane >> 3);
+    const uint32_t ch = (uint32_t)(((lane & 7) ^ sw_dual(row)) << 4);
+    dma_q[i] = (uint32_t)(((int64_t)b * N + row) * tok * 2) + (uint32_t)(head * BHD * 2) + ch;
+    dma_do[i] = (uint32_t)((((int64_t)b * N + row) * H + head) * BHD * 2) + ch;
+  }
+  const uint32_t q_step = (uint32_t)(tok * 2), do_step = (uint32_t)(H * BHD * 2);
   float sreg = 0.f;  // tid < 64: -lse*log2e/c of row tid ; 64 <= tid < 128: -delta of row tid-64
-#define LOAD_QDO(q0)                                                                                       \
+#define LOAD_QDO(buf, q0)                                                                                  \
   {                                                                                                        \
-    int r0_ = (q0) + srow, r1_ = (q0) + srow + 32;                                                         \
-    r0_ = r0_ > N - 1 ? N - 1 : r0_;                                                                       \
-    r1_ = r1_ > N - 1 ? N - 1 : r1_;                                                                       \
-    qreg0 = *reinterpret_cast<const uint4*>(base + (int64_t)r0_ * tok + schunk * 8);                       \
-    qreg1 = *reinterpret_cast<const uint4*>(base + (int64_t)r1_ * tok + schunk * 8);                       \
-    doreg0 = *reinterpret_cast<const uint4*>(dobase + (int64_t)r0_ * H * BHD + schunk * 8);                \
-    doreg1 = *reinterpret_cast<const uint4*>(dobase + (int64_t)r1_ * H * BHD + schunk * 8);                \
-    {                                                                                                      \
+    char* ql_ = lds + (buf) * STAGE;                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                        \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_qkv, LDS_PTR(ql_ + (wave + 4 * i) * 1024), 16, dma_q[i] + (uint32_t)(q0) * q_step, 0, 0, 0); \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_do, LDS_PTR(ql_ + TILE_BYTES + (wave + 4 * i) * 1024), 16, dma_do[i] + (uint32_t)(q0) * do_step, 0, 0, 0); \
+    }                                                                                                      \
+    if (tid < 128) {                                                                                       \
       const int qq_ = (q0) + (tid & 63);                                                                   \
       const int qc_ = qq_ > N - 1 ? N - 1 : qq_;                                                           \
       const float lv_ = lsebase[qc_], dv_ = dltbase[qc_];                                                  \
@@ -262,16 +271,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
       sreg = (tid < 64) ? (qq_ < N ? -lv_ * LOG2E * inv_c : -3.0e30f) : (qq_ < N ? -dv_ : 0.f);            \
     }                                                                                                      \
   }
-  const int w0 = srow * 128 + ((schunk ^ sw_dual(srow)) << 4), w1 = (srow + 32) * 128 + ((schunk ^ sw_dual(srow + 32)) << 4);
-#define WRITE_QDO(buf)                                                              \
-  {                                                                                 \
-    char* ql_ = lds + (buf) * STAGE;                                                \
-    char* dl_ = ql_ + TILE_BYTES;                                                   \
-    *reinterpret_cast<uint4*>(ql_ + w0) = qreg0;                                    \
-    *reinterpret_cast<uint4*>(ql_ + w1) = qreg1;                                    \
-    *reinterpret_cast<uint4*>(dl_ + w0) = doreg0;                                   \
-    *reinterpret_cast<uint4*>(dl_ + w1) = doreg1;                                   \
-    if (tid < 128) reinterpret_cast<float*>(ql_ + 2 * TILE_BYTES)[tid] = sreg;      \
+#define WRITE_QDO(buf)                                                                             \
+  {                                                                                                \
+    if (tid < 128) reinterpret_cast<float*>(lds + (buf) * STAGE + 2 * TILE_BYTES)[tid] = sreg;     \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                               \
   }
 
   f32x16 dk[2], dv[2];
@@ -281,11 +284,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
     for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
 
   const int nt = (N + 63) / 64;
-  LOAD_QDO(0);
+  LOAD_QDO(0, 0);
   WRITE_QDO(0);
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
-    LOAD_QDO((t + 1) * 64);
+    if (t + 1 < nt) LOAD_QDO((t + 1) & 1, (t + 1) * 64);
     const char* ql = lds + (t & 1) * STAGE;
     const char* dl = ql + TILE_BYTES;
     const float* rowc = reinterpret_cast<const float*>(ql + 2 * TILE_BYTES);  // [0..63] -lse2/c, [64..127] -delta
