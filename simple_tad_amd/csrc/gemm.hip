@@ -573,16 +573,36 @@ static int tn_variant() {
   static const int forced = env_int("TAD_GEMM_TN_VARIANT");
   return forced ? forced : 1;
 }
+static int cu_count() {
+  static const int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    return v;
+  }();
+  return n;
+}
+// One workgroup per CU is resident (128 KiB of LDS), so the grid runs in rounds of cu_count() workgroups and a grid of
+// cu_count() + 1 costs two full rounds.  Pick the split count that minimises rounds x (reduction tiles per split + epilogue)
+// plus the slab-reduce pass, all in units of one reduction tile (~2 us on MI355X).
 static int tn_plan(int64_t Mr, int N, int K, int* splits, int* rows_per_split) {
   const int bn = tn_variant() != 3 ? 256 : 128;
   const int tiles = ((N + 255) / 256) * ((K + bn - 1) / bn);
   const int64_t ktiles = (Mr + BK - 1) / BK;
-  int s = (256 + tiles - 1) / tiles;
-  if (s > ktiles) s = (int)ktiles;
-  if (s < 1) s = 1;
-  const int64_t per = (ktiles + s - 1) / s;
-  s = (int)((ktiles + per - 1) / per);
-  *splits = s;
+  const int cus = cu_count();
+  const double epi_units = 6.0;                                            // accumulator store of one workgroup
+  const double reduce_units = (double)N * (double)K * 8.0 / 4.0e12 / 2.0e-6;  // slab write + read per split
+  int best = 1;
+  double best_cost = 1e300;
+  for (int s = 1; s <= 64 && s <= ktiles; ++s) {
+    const int64_t per = (ktiles + s - 1) / s;
+    const int s_eff = (int)((ktiles + per - 1) / per);
+    if (s_eff != s) continue;
+    const int64_t rounds = ((int64_t)tiles * s + cus - 1) / cus;
+    const double cost = (double)rounds * ((double)per + epi_units) + (s > 1 ? s * reduce_units : 0.0);
+    if (cost < best_cost) { best_cost = cost; best = s; }
+  }
+  const int64_t per = (ktiles + best - 1) / best;
+  *splits = best;
   *rows_per_split = (int)(per * BK);
   return tiles;
 }
