@@ -18,6 +18,7 @@ import numpy as np
 import torch
 
 from . import kernels as K
+from . import ops
 from .parallel import DataParallel
 
 
@@ -143,6 +144,7 @@ class NativeScalerWithGradNormCount:
             else:
                 norm = get_grad_norm_(parameters)
         optimizer.step()
+        ops.invalidate_weight_cache()  # fused optimizers do not bump Parameter._version (see ops._cached)
         return norm
 
     def state_dict(self):

@@ -19,33 +19,58 @@ import torch
 from . import kernels as K
 from ._lib import EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, TadError
 
-# --------------------------------------------------------------------------- bf16 weight cache
-_wcache = {}  # id(param) -> {"ref": weakref, "key": (version, data_ptr), "n": bf16, "t": bf16 transposed}
+# --------------------------------------------------------------------------- bf16 weight copies
+# GEMM operands are bf16 copies of the f32 master weights (torch owns the parameters; cached copies must never outlive
+# an optimizer step).  ``p._version`` cannot be the only guard: torch's fused / capturable optimizers update parameters through
+# ``_fused_adamw_`` WITHOUT bumping the version counter (measured on torch 2.10: version 0 -> 0 across a fused AdamW step).  So:
+#   * a forward that will be differentiated (training) always re-derives its copies from the master weights and drops any cached
+#     entry for them (``fresh=True``); backward derives the transposed copy at backward time (weights do not change between the
+#     two);
+#   * only forwards without autograd (inference) reuse cached copies, keyed by (version, data_ptr), and ``invalidate_weight_cache``
+#     (called by this package's optimizer wrapper after every step) clears them explicitly.
+_wcache = {}  # id(param) -> {"ref": weakref, "key": (version, data_ptr), kind: tensor}
+_MAKERS = {}
 
 
-def _cached(p: torch.Tensor, kind: str):
-    """bf16 copy ('n': same layout [N,K]; 't': transposed [K,N]) of an f32 weight, invalidated when the parameter is
-    modified in place (optimizer step bumps ._version), re-allocated, or garbage-collected."""
+def invalidate_weight_cache():
+    """Drop every cached bf16 weight copy (call after modifying parameters by any means that may not bump ``_version``)."""
+    _wcache.clear()
+
+
+def _w2d(p):
+    w2 = p.detach().reshape(p.shape[0], -1)
+    if w2.dtype != torch.float32:
+        w2 = w2.float()
+    return w2 if w2.is_contiguous() else w2.contiguous()
+
+
+_MAKERS["n"] = lambda p: K.cast_bf16(_w2d(p))                                  # [N,K] bf16
+_MAKERS["t"] = lambda p: K.transpose_cast_bf16(_w2d(p))                        # [K,N] bf16
+_MAKERS["s"] = lambda p: K.split_bf16x3(_w2d(p), role_b=True)                  # [N,3K] split operand ([hi|lo|hi]), precise Linear
+_MAKERS["st"] = lambda p: K.split_bf16x3(_w2d(p).t().contiguous(), role_b=True)  # [K,3N] split operand of W^T, precise dX
+
+
+def _cached(p: torch.Tensor, kind: str, fresh: bool = False):
     pid = id(p)
+    if fresh:
+        _wcache.pop(pid, None)
+        return _MAKERS[kind](p)
     ent = _wcache.get(pid)
     key = (p._version, p.data_ptr())
     if ent is None or ent["ref"]() is not p or ent["key"] != key:
         ent = {"ref": weakref.ref(p, lambda _r, pid=pid: _wcache.pop(pid, None)), "key": key}
         _wcache[pid] = ent
     if kind not in ent:
-        w2 = p.detach().reshape(p.shape[0], -1)
-        if not w2.is_contiguous():
-            w2 = w2.contiguous()
-        ent[kind] = K.cast_bf16(w2) if kind == "n" else K.transpose_cast_bf16(w2)
+        ent[kind] = _MAKERS[kind](p)
     return ent[kind]
 
 
-def w_bf16(p):
-    return _cached(p, "n")
+def w_bf16(p, fresh: bool = False):
+    return _cached(p, "n", fresh)
 
 
-def wT_bf16(p):
-    return _cached(p, "t")
+def wT_bf16(p, fresh: bool = False):
+    return _cached(p, "t", fresh)
 
 
 def _f32c(t: Optional[torch.Tensor]):
@@ -70,18 +95,8 @@ def _qkv_bias(q_bias, v_bias):
 
 
 # --------------------------------------------------------------------------- precise mode (parity gate)
-def _cached_split(p: torch.Tensor):
-    """[N,3K] bf16 split-operand copy ([hi|lo|hi]) of an f32 weight for the precise Linear."""
-    pid = id(p)
-    ent = _wcache.get(pid)
-    key = (p._version, p.data_ptr())
-    if ent is None or ent["ref"]() is not p or ent["key"] != key:
-        ent = {"ref": weakref.ref(p, lambda _r, pid=pid: _wcache.pop(pid, None)), "key": key}
-        _wcache[pid] = ent
-    if "s" not in ent:
-        w2 = p.detach().reshape(p.shape[0], -1).float().contiguous()
-        ent["s"] = K.split_bf16x3(w2, role_b=True)
-    return ent["s"]
+def _cached_split(p: torch.Tensor, fresh: bool = False):
+    return _cached(p, "s", fresh)
 
 
 # --------------------------------------------------------------------------- precision mode
@@ -106,23 +121,13 @@ def _no_grad_only(*tensors):
         raise TadError('precision "precise" is forward-only (parity gate); wrap the call in torch.no_grad()')
 
 
-def _cached_split_T(p: torch.Tensor):
-    """[K,3N] split-operand copy of W^T for the precise input-gradient GEMM."""
-    pid = id(p)
-    ent = _wcache.get(pid)
-    key = (p._version, p.data_ptr())
-    if ent is None or ent["ref"]() is not p or ent["key"] != key:
-        ent = {"ref": weakref.ref(p, lambda _r, pid=pid: _wcache.pop(pid, None)), "key": key}
-        _wcache[pid] = ent
-    if "st" not in ent:
-        wt = p.detach().reshape(p.shape[0], -1).float().t().contiguous()
-        ent["st"] = K.split_bf16x3(wt, role_b=True)
-    return ent["st"]
+def _cached_split_T(p: torch.Tensor, fresh: bool = False):
+    return _cached(p, "st", fresh)
 
 
 def precise_dx(dy, weight):
-    """dx [M,K] f32 = dy [M,N] @ W [N,K] with split operands (reduction over 3N)"""
-    dx, _ = K.linear_fwd(K.split_bf16x3(dy, role_b=False), _cached_split_T(weight), None, out_dtype=torch.float32)
+    """dx [M,K] f32 = dy [M,N] @ W [N,K] with split operands (reduction over 3N); backward only, so the copy is always re-derived"""
+    dx, _ = K.linear_fwd(K.split_bf16x3(dy, role_b=False), _cached_split_T(weight, True), None, out_dtype=torch.float32)
     return dx
 
 
@@ -132,9 +137,9 @@ def precise_dw(dy, x, want_bias=True):
     return dW, (K.colsum_f32(dy) if want_bias else None)
 
 
-def precise_linear(x2d, weight, bias, epilogue=EPI_BIAS, residual=None, rowscale=None, rows_per_scale=1):
+def precise_linear(x2d, weight, bias, epilogue=EPI_BIAS, residual=None, rowscale=None, rows_per_scale=1, fresh=False):
     xs = K.split_bf16x3(x2d, role_b=False)
-    y, _ = K.linear_fwd(xs, _cached_split(weight), _f32c(bias), out_dtype=torch.float32, epilogue=epilogue, residual=residual,
+    y, _ = K.linear_fwd(xs, _cached_split(weight, fresh), _f32c(bias), out_dtype=torch.float32, epilogue=epilogue, residual=residual,
                         rowscale=rowscale, rows_per_scale=rows_per_scale)
     return y
 
@@ -188,7 +193,7 @@ class PatchEmbedFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, pos, tubelet, patch):
         _need_gpu(x, "PatchEmbed")
         xc = _f32c(x)
-        out, cols = K.patch_embed_fwd(xc, w_bf16(weight), _f32c(bias), _f32c(pos), tubelet, patch)
+        out, cols = K.patch_embed_fwd(xc, w_bf16(weight, any(ctx.needs_input_grad)), _f32c(bias), _f32c(pos), tubelet, patch)
         ctx.save_for_backward(cols)
         ctx.wshape = weight.shape
         ctx.has_bias = bias is not None
@@ -205,7 +210,7 @@ class PatchEmbedFn(torch.autograd.Function):
 
 # --------------------------------------------------------------------------- attention / mlp cores (2-D tensors)
 def _attn_fwd_core(xn, qkv_w, q_bias, v_bias, B, N, H, scale, train):
-    qkv, _ = K.linear_fwd(xn, w_bf16(qkv_w), _qkv_bias(q_bias, v_bias), out_dtype=torch.bfloat16)
+    qkv, _ = K.linear_fwd(xn, w_bf16(qkv_w, train), _qkv_bias(q_bias, v_bias), out_dtype=torch.bfloat16)
     ao, lse = K.attn_fwd(qkv, B, N, H, scale, out_dtype=torch.bfloat16, want_lse=train)
     return qkv, ao, lse
 
@@ -214,7 +219,7 @@ def _attn_bwd_core(d_ao, xn, qkv, ao, lse, qkv_w, has_qkv_bias, B, N, H, scale, 
     """returns dxn, dWqkv, dq_bias, dv_bias"""
     D = xn.shape[1]
     dqkv = K.attn_bwd(qkv, ao, d_ao, lse, B, N, H, scale)
-    dxn = K.linear_bwd_input(dqkv, wT_bf16(qkv_w), out_dtype=dx_dtype)
+    dxn = K.linear_bwd_input(dqkv, wT_bf16(qkv_w, True), out_dtype=dx_dtype)
     dWqkv, dbqkv = K.linear_bwd_weight(dqkv, xn, want_bias=has_qkv_bias)
     if has_qkv_bias:
         AH = dbqkv.numel() // 3
@@ -232,7 +237,7 @@ class AttentionFn(torch.autograd.Function):
         train = any(ctx.needs_input_grad)
         xb = K.cast_bf16(_f32c(x).reshape(B * N, C))
         qkv, ao, lse = _attn_fwd_core(xb, qkv_w, q_bias, v_bias, B, N, H, scale, train)
-        y, _ = K.linear_fwd(ao, w_bf16(proj_w), _f32c(proj_b), out_dtype=torch.float32)
+        y, _ = K.linear_fwd(ao, w_bf16(proj_w, train), _f32c(proj_b), out_dtype=torch.float32)
         if train:
             ctx.save_for_backward(xb, qkv, ao, lse, qkv_w, proj_w)
         ctx.meta = (B, N, H, scale, q_bias is not None, proj_b is not None)
@@ -243,7 +248,7 @@ class AttentionFn(torch.autograd.Function):
         xb, qkv, ao, lse, qkv_w, proj_w = ctx.saved_tensors
         B, N, H, scale, has_qb, has_pb = ctx.meta
         dyb = K.cast_bf16(_f32c(dy).reshape(B * N, -1))
-        d_ao = K.linear_bwd_input(dyb, wT_bf16(proj_w))
+        d_ao = K.linear_bwd_input(dyb, wT_bf16(proj_w, True))
         dWp, dbp = K.linear_bwd_weight(dyb, ao, want_bias=has_pb)
         dx, dWqkv, dqb, dvb = _attn_bwd_core(d_ao, xb, qkv, ao, lse, qkv_w, has_qb, B, N, H, scale, torch.float32)
         return dx.reshape(B, N, -1), dWqkv, dqb, dvb, dWp, dbp, None, None
@@ -258,8 +263,8 @@ class MlpFn(torch.autograd.Function):
         shp = x.shape
         train = any(ctx.needs_input_grad)
         xb = K.cast_bf16(_f32c(x).reshape(-1, shp[-1]))
-        a, h = K.linear_fwd(xb, w_bf16(fc1_w), _f32c(fc1_b), out_dtype=torch.bfloat16, epilogue=EPI_BIAS_GELU, want_preact=train)
-        y, _ = K.linear_fwd(a, w_bf16(fc2_w), _f32c(fc2_b), out_dtype=torch.float32)
+        a, h = K.linear_fwd(xb, w_bf16(fc1_w, train), _f32c(fc1_b), out_dtype=torch.bfloat16, epilogue=EPI_BIAS_GELU, want_preact=train)
+        y, _ = K.linear_fwd(a, w_bf16(fc2_w, train), _f32c(fc2_b), out_dtype=torch.float32)
         if train:
             ctx.save_for_backward(xb, h, a, fc1_w, fc2_w)
         ctx.meta = (shp, fc1_b is not None, fc2_b is not None)
@@ -270,9 +275,9 @@ class MlpFn(torch.autograd.Function):
         xb, h, a, fc1_w, fc2_w = ctx.saved_tensors
         shp, has_b1, has_b2 = ctx.meta
         dyb = K.cast_bf16(_f32c(dy).reshape(-1, dy.shape[-1]))
-        dh = K.linear_bwd_input(dyb, wT_bf16(fc2_w), gelu_preact=h)
+        dh = K.linear_bwd_input(dyb, wT_bf16(fc2_w, True), gelu_preact=h)
         dW2, db2 = K.linear_bwd_weight(dyb, a, want_bias=has_b2)
-        dx = K.linear_bwd_input(dh, wT_bf16(fc1_w), out_dtype=torch.float32)
+        dx = K.linear_bwd_input(dh, wT_bf16(fc1_w, True), out_dtype=torch.float32)
         dW1, db1 = K.linear_bwd_weight(dh, xb, want_bias=has_b1)
         return dx.reshape(shp), dW1, db1, dW2, db2
 
@@ -294,11 +299,11 @@ class BlockFn(torch.autograd.Function):
         g1, b1, g2, b2 = _f32c(n1w), _f32c(n1b), _f32c(n2w), _f32c(n2b)
         xn1, mean1, rstd1 = K.layernorm_fwd(x0, g1, b1, eps, save_stats=train)
         qkv, ao, lse = _attn_fwd_core(xn1, qkv_w, q_bias, v_bias, B, N, H, scale, train)
-        x1, _ = K.linear_fwd(ao, w_bf16(proj_w), _f32c(proj_b), out_dtype=torch.float32, epilogue=EPI_BIAS_RESIDUAL, residual=x0,
+        x1, _ = K.linear_fwd(ao, w_bf16(proj_w, train), _f32c(proj_b), out_dtype=torch.float32, epilogue=EPI_BIAS_RESIDUAL, residual=x0,
                              rowscale=_f32c(dp1), rows_per_scale=N)
         xn2, mean2, rstd2 = K.layernorm_fwd(x1, g2, b2, eps, save_stats=train)
-        a, h = K.linear_fwd(xn2, w_bf16(fc1_w), _f32c(fc1_b), out_dtype=torch.bfloat16, epilogue=EPI_BIAS_GELU, want_preact=train)
-        x2, _ = K.linear_fwd(a, w_bf16(fc2_w), _f32c(fc2_b), out_dtype=torch.float32, epilogue=EPI_BIAS_RESIDUAL, residual=x1,
+        a, h = K.linear_fwd(xn2, w_bf16(fc1_w, train), _f32c(fc1_b), out_dtype=torch.bfloat16, epilogue=EPI_BIAS_GELU, want_preact=train)
+        x2, _ = K.linear_fwd(a, w_bf16(fc2_w, train), _f32c(fc2_b), out_dtype=torch.float32, epilogue=EPI_BIAS_RESIDUAL, residual=x1,
                              rowscale=_f32c(dp2), rows_per_scale=N)
         if train:
             ctx.save_for_backward(x0, g1, mean1, rstd1, xn1, qkv, ao, lse, x1, g2, mean2, rstd2, xn2, h, a, qkv_w, proj_w, fc1_w, fc2_w,
@@ -315,9 +320,9 @@ class BlockFn(torch.autograd.Function):
         g = _f32c(g).reshape(M, D)
         # ---- MLP branch
         gb = K.cast_bf16(g) if dp2 is None else K.scale_cast_bf16(g, None, dp2, N)
-        dh = K.linear_bwd_input(gb, wT_bf16(fc2_w), gelu_preact=h)
+        dh = K.linear_bwd_input(gb, wT_bf16(fc2_w, True), gelu_preact=h)
         dW2, db2 = K.linear_bwd_weight(gb, a)
-        dxn2 = K.linear_bwd_input(dh, wT_bf16(fc1_w))
+        dxn2 = K.linear_bwd_input(dh, wT_bf16(fc1_w, True))
         dW1, db1 = K.linear_bwd_weight(dh, xn2)
         gmid, gmid_b, dg2, dbeta2, cs = K.layernorm_bwd(dxn2, x1, g2, mean2, rstd2, dres=g, want_bf16=(dp1 is None),
                                                        want_colsum=(dp1 is None))
@@ -327,7 +332,7 @@ class BlockFn(torch.autograd.Function):
         else:
             gpb = K.scale_cast_bf16(gmid, None, dp1, N)
             dbp = None
-        d_ao = K.linear_bwd_input(gpb, wT_bf16(proj_w))
+        d_ao = K.linear_bwd_input(gpb, wT_bf16(proj_w, True))
         dWp, dbp2 = K.linear_bwd_weight(gpb, ao, want_bias=(dbp is None))
         if dbp is None:
             dbp = dbp2
@@ -363,16 +368,17 @@ class PreciseBlockFn(torch.autograd.Function):
         _need_gpu(x, "Block")
         B, N, D = x.shape
         M = B * N
+        fr = any(ctx.needs_input_grad)  # differentiated forward: never reuse cached weight copies (see _cached)
         x0 = _f32c(x).reshape(M, D)
         g1, b1, g2, b2 = _f32c(n1w), _f32c(n1b), _f32c(n2w), _f32c(n2b)
         xn1, mean1, rstd1 = K.layernorm_fwd(x0, g1, b1, eps, out_dtype=torch.float32)
-        qkv = precise_linear(xn1, qkv_w, _qkv_bias(q_bias, v_bias))
+        qkv = precise_linear(xn1, qkv_w, _qkv_bias(q_bias, v_bias), fresh=fr)
         ao, lse = K.attn_fwd_f32(qkv, B, N, H, scale, want_lse=True)
-        x1 = precise_linear(ao, proj_w, proj_b, EPI_BIAS_RESIDUAL, residual=x0)
+        x1 = precise_linear(ao, proj_w, proj_b, EPI_BIAS_RESIDUAL, residual=x0, fresh=fr)
         xn2, mean2, rstd2 = K.layernorm_fwd(x1, g2, b2, eps, out_dtype=torch.float32)
-        h = precise_linear(xn2, fc1_w, fc1_b)
+        h = precise_linear(xn2, fc1_w, fc1_b, fresh=fr)
         a = K.gelu_f32(h)
-        x2 = precise_linear(a, fc2_w, fc2_b, EPI_BIAS_RESIDUAL, residual=x1)
+        x2 = precise_linear(a, fc2_w, fc2_b, EPI_BIAS_RESIDUAL, residual=x1, fresh=fr)
         ctx.save_for_backward(x0, g1, mean1, rstd1, xn1, qkv, ao, lse, x1, g2, mean2, rstd2, xn2, h, a, qkv_w, proj_w, fc1_w, fc2_w)
         ctx.meta = (B, N, D, H, scale, q_bias is not None)
         return x2.reshape(B, N, D)
@@ -408,8 +414,8 @@ class PrecisePatchEmbedFn(torch.autograd.Function):
         cols = K.im2col_tubelets_f32(_f32c(x), tubelet, patch)
         ntok = cols.shape[0] // B
         res = _f32c(pos).repeat(B, 1) if pos is not None else None
-        y, _ = K.linear_fwd(K.split_bf16x3(cols, role_b=False), _cached_split(weight), _f32c(bias), out_dtype=torch.float32,
-                            epilogue=EPI_BIAS_RESIDUAL if res is not None else EPI_BIAS, residual=res)
+        y, _ = K.linear_fwd(K.split_bf16x3(cols, role_b=False), _cached_split(weight, any(ctx.needs_input_grad)), _f32c(bias),
+                            out_dtype=torch.float32, epilogue=EPI_BIAS_RESIDUAL if res is not None else EPI_BIAS, residual=res)
         ctx.save_for_backward(cols)
         ctx.wshape = weight.shape
         ctx.has_bias = bias is not None

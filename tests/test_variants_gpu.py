@@ -120,3 +120,38 @@ def test_ragged_and_tiny_inputs():
         assert rell2(out, O.forward(x.double(), P, depth=2, num_heads=2, tubelet=2, patch=16)) < 6e-3
     with pytest.raises(AssertionError):
         m(torch.randn(1, 3, 4, 48, 48).cuda())  # wrong spatial size: the reference's assert (modeling_finetune.py:188)
+
+
+def test_weight_copies_follow_master_weights_across_fused_optimizer_steps():
+    """torch's fused AdamW updates parameters without bumping Parameter._version, so the bf16 operand copies must not be keyed on
+    it alone: after a few large steps, training-mode and inference-mode forwards must both see the CURRENT master weights."""
+    m = _model(128, 2).cuda().train()
+    x = torch.randn(4, 3, 4, 32, 32)
+    y = torch.tensor([0, 1, 1, 0]).cuda()
+    with torch.no_grad():
+        m.eval()
+        m(x.cuda())  # populate the inference-time cache before training starts
+        m.train()
+    w0 = m.blocks[0].mlp.fc1.weight.detach().clone()
+    opt = torch.optim.AdamW(m.parameters(), lr=2e-2, fused=True)
+    for _ in range(3):
+        opt.zero_grad()
+        F.cross_entropy(m(x.cuda()), y).backward()
+        opt.step()
+    assert (m.blocks[0].mlp.fc1.weight - w0).abs().max() > 1e-2  # the weights did move
+    P = {k: v.detach().double().cpu() for k, v in m.state_dict().items()}
+    ref = O.forward(x.double(), P, depth=2, num_heads=2, tubelet=2, patch=16)
+    out_train = m(x.cuda())
+    m.eval()
+    with torch.no_grad():
+        out_eval = m(x.cuda())
+    assert rell2(out_train, ref) < 1e-2, rell2(out_train, ref)
+    assert rell2(out_eval, ref) < 1e-2, rell2(out_eval, ref)
+    # and the gradient side: backward after the updates matches the oracle on the current weights
+    m.train()
+    opt.zero_grad()
+    F.cross_entropy(m(x.cuda()), y).backward()
+    Pg = {k: v.clone().requires_grad_() for k, v in P.items()}
+    F.cross_entropy(O.forward(x.double(), Pg, depth=2, num_heads=2, tubelet=2, patch=16), y.cpu()).backward()
+    for k in ("blocks.0.attn.qkv.weight", "blocks.1.mlp.fc1.weight", "patch_embed.proj.weight"):
+        assert rell2(dict(m.named_parameters())[k].grad, Pg[k].grad) < 4e-2, k
