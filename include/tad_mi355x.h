@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TAD_ABI_VERSION 1
+#define TAD_ABI_VERSION 2
 
 enum tad_status {
   TAD_OK = 0,
@@ -141,6 +141,26 @@ int tad_scale_cast_bf16(const float* x, uint16_t* y, const float* gamma, const f
                         int rows_per_scale, int64_t M, int N, tad_stream_t stream);
 /* sum of squares of an f32 vector, accumulated into *out (f32, device) -- get_grad_norm_ (utils.py:415-427) */
 int tad_sumsq_f32(const float* x, int64_t n, float* out, tad_stream_t stream);
+
+/* ---- optimizer tail -------------------------------------------------------------------------------------------
+ * Fused multi-tensor AdamW over FLAT buffers: replaces torch.optim.AdamW as configured by optim_factory.create_optimizer
+ * (optim_factory.py:91-127) with the layer-decay parameter groups of optim_factory.get_parameter_groups (:49-88) and the per-step
+ * lr / weight-decay assignment of engine_for_finetuning.train_one_epoch (:49-54); the sum of g^2 that utils.get_grad_norm_
+ * (utils.py:415-427) needs comes out of the same pass.
+ * param / grad / exp_avg / exp_avg_sq: f32 [n], one shared layout in which every tensor starts on a TAD_ADAMW_CHUNK boundary.
+ * chunk_group[c] (device, uint8, ceil(n / CHUNK) entries) = parameter-group index of chunk c, or 255 = leave the chunk untouched.
+ * group_lr / group_wd / group_step: HOST arrays [n_groups] (this step's lr and weight decay; the 1-based count of updates the
+ * group's tensors will have received after this call -- torch keeps it per parameter).  Update rule = torch.optim.AdamW:
+ *   p *= 1 - lr*wd;  m += (1-b1)(g-m);  v = b2 v + (1-b2) g^2;  p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ * grad_scale (device scalar or NULL): g is multiplied by *grad_scale first (gradient clipping without a host sync).
+ * param_bf16 (or NULL): receives bf16(p_new) -- the operand copy the next forward's GEMMs read.
+ * sumsq_partials (or NULL): [ceil(n / CHUNK)] per-chunk sums of the UNSCALED g^2 (deterministic order). */
+#define TAD_ADAMW_CHUNK 4096
+#define TAD_ADAMW_MAX_GROUPS 128
+int tad_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint16_t* param_bf16,
+                   const uint8_t* chunk_group, int64_t n, const float* group_lr, const float* group_wd, int n_groups,
+                   const int32_t* group_step, float beta1, float beta2, float eps, const float* grad_scale,
+                   float* sumsq_partials, tad_stream_t stream);
 
 /* ---- "precise" mode (parity gate, not throughput): f32-accurate Linear via split-bf16 operands, f32 attention ----------
  * x = hi + lo (bf16 each).  concat mode: out [M,3K] = [hi|hi|lo] (role_b=0) or [hi|lo|hi] (role_b=1); stack mode: out [3M,K]

@@ -38,6 +38,8 @@ SIGNATURES = {
     "tad_colsum_bf16": (_i, [_vp, _vp, _i, _vp, _sz, _i64, _i, _vp]),
     "tad_scale_cast_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp]),
     "tad_sumsq_f32": (_i, [_vp, _i64, _vp, _vp]),
+    "tad_adamw_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(_f), C.POINTER(_f), _i, C.POINTER(C.c_int32), _f, _f, _f, _vp, _vp,
+                       _vp]),
     "tad_split_bf16x3": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp]),
     "tad_im2col_tubelets_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "tad_attn_fwd_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
@@ -50,7 +52,9 @@ SIGNATURES = {
 
 TAD_F32, TAD_BF16 = 0, 1
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
+ADAMW_CHUNK = 4096
+ADAMW_MAX_GROUPS = 128
 POOL_SPLIT = 8
 
 _lib = None

@@ -88,16 +88,24 @@ def get_parameter_groups(model, weight_decay=1e-5, skip_list=(), get_num_layer=N
 
 
 def create_optimizer(model, lr, weight_decay=0.05, betas=(0.9, 0.999), eps=1e-8, layer_decay: Optional[float] = None,
-                     skip_list=None):
+                     skip_list=None, fused_kernel: Optional[bool] = None):
     """AdamW over the reference's parameter groups (optim_factory.create_optimizer with opt='adamw',
-    optim_factory.py:91-127); the rest of the reference's optimizer zoo is out of scope."""
+    optim_factory.py:91-127); the rest of the reference's optimizer zoo is out of scope.  On the GPU this is
+    optim.FusedAdamW (one HIP launch per step over the flat layout it shares with DataParallel); ``fused_kernel=False`` or
+    CPU parameters give torch.optim.AdamW over the same groups."""
     inner = model.module if isinstance(model, DataParallel) else model
     skip = set(skip_list) if skip_list is not None else (inner.no_weight_decay() if hasattr(inner, "no_weight_decay") else set())
     assigner = LayerDecayValueAssigner.from_decay(layer_decay, inner.get_num_layers()) if layer_decay and layer_decay < 1.0 else None
     groups = get_parameter_groups(inner, weight_decay, skip, assigner.get_layer_id if assigner else None,
                                   assigner.get_scale if assigner else None)
-    fused = all(p.is_cuda for g in groups for p in g["params"])
-    return torch.optim.AdamW(groups, lr=lr, betas=betas, eps=eps, weight_decay=0.0, fused=fused)
+    on_gpu = all(p.is_cuda for g in groups for p in g["params"])
+    if fused_kernel is None:
+        fused_kernel = on_gpu
+    if fused_kernel:
+        from .optim import FusedAdamW
+        return FusedAdamW(groups, lr=lr, betas=betas, eps=eps, weight_decay=0.0,
+                          space=model.space if isinstance(model, DataParallel) else None)
+    return torch.optim.AdamW(groups, lr=lr, betas=betas, eps=eps, weight_decay=0.0, fused=on_gpu)
 
 
 def get_grad_norm_(parameters, norm_type: float = 2.0) -> torch.Tensor:
@@ -134,6 +142,18 @@ class NativeScalerWithGradNormCount:
             return None
         if dp is not None:
             dp.finish()
+        from .optim import FusedAdamW
+        if isinstance(optimizer, FusedAdamW):
+            # the norm of utils.get_grad_norm_ comes out of the optimizer's own pass over the gradients; with clipping the
+            # coefficient of torch.nn.utils.clip_grad_norm_ (max_norm / (norm + 1e-6), capped at 1) stays on the device
+            if clip_grad is not None and clip_grad > 0:
+                acc = torch.zeros(1, dtype=torch.float32, device=optimizer.flat_grad.device)
+                norm = K.sumsq(optimizer.flat_grad, acc).sqrt()[0]
+                coef = torch.clamp(clip_grad / (norm + 1e-6), max=1.0).reshape(1).float()
+                optimizer.step(grad_scale=coef)
+            else:
+                norm = optimizer.step(want_sumsq=True).sqrt()
+            return norm
         if clip_grad is not None and clip_grad > 0:
             assert parameters is not None
             norm = torch.nn.utils.clip_grad_norm_(parameters, clip_grad)

@@ -342,6 +342,38 @@ def sumsq(x, out):
     return out
 
 
+def adamw_step(param, grad, exp_avg, exp_avg_sq, chunk_group, group_lr, group_wd, group_step, beta1, beta2, eps, param_bf16=None,
+               grad_scale=None, sumsq_partials=None):
+    """Fused AdamW over flat f32 buffers (tad_adamw_step); group_lr / group_wd / group_step are host sequences, one entry per
+    parameter group (group_step: 1-based update count of the group's tensors after this call)."""
+    import ctypes as C
+    for t, nm in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _req(t, torch.float32, "adamw." + nm)
+    n = param.numel()
+    if not (grad.numel() == n and exp_avg.numel() == n and exp_avg_sq.numel() == n):
+        raise _lib.TadError("adamw_step: flat buffers differ in length")
+    chunks = (n + _lib.ADAMW_CHUNK - 1) // _lib.ADAMW_CHUNK
+    if chunk_group.dtype != torch.uint8 or chunk_group.numel() != chunks or not chunk_group.is_cuda:
+        raise _lib.TadError(f"adamw_step: chunk_group must be a uint8 device tensor with {chunks} entries")
+    if param_bf16 is not None:
+        _req(param_bf16, torch.bfloat16, "adamw.param_bf16")
+        assert param_bf16.numel() == n
+    if sumsq_partials is not None:
+        _req(sumsq_partials, torch.float32, "adamw.sumsq_partials")
+        assert sumsq_partials.numel() == chunks
+    if grad_scale is not None:
+        _req(grad_scale, torch.float32, "adamw.grad_scale")
+    ng = len(group_lr)
+    assert len(group_wd) == ng and len(group_step) == ng
+    lr = (C.c_float * ng)(*[float(v) for v in group_lr])
+    wd = (C.c_float * ng)(*[float(v) for v in group_wd])
+    st = (C.c_int32 * ng)(*[int(v) for v in group_step])
+    with _timed("adamw", 0.0, 30.0 * n):
+        check(_lib.load().tad_adamw_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), _p(param_bf16),
+                                         chunk_group.data_ptr(), n, lr, wd, ng, st, float(beta1), float(beta2), float(eps),
+                                         _p(grad_scale), _p(sumsq_partials), _stream()), "tad_adamw_step")
+
+
 def device_info():
     import ctypes as C
     cu, clk, ldsb = C.c_int(), C.c_int(), C.c_int()

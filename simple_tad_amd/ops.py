@@ -50,8 +50,29 @@ _MAKERS["s"] = lambda p: K.split_bf16x3(_w2d(p), role_b=True)                  #
 _MAKERS["st"] = lambda p: K.split_bf16x3(_w2d(p).t().contiguous(), role_b=True)  # [K,3N] split operand of W^T, precise dX
 
 
+# Operand mirrors: optim.FusedAdamW writes bf16(p) for every weight in the same pass that updates p and registers the views
+# here; a mirror is served only while the parameter still is the tensor (same storage, same version) the optimizer wrote.
+_mirrors = {}  # id(param) -> (weakref, bf16 [N,K] view, version, data_ptr)
+
+
+def register_mirror(p: torch.Tensor, view: torch.Tensor):
+    pid = id(p)
+    _mirrors[pid] = (weakref.ref(p, lambda _r, pid=pid: _mirrors.pop(pid, None)), view, p._version, p.data_ptr())
+
+
+def _mirror_of(p):
+    ent = _mirrors.get(id(p))
+    if ent is not None and ent[0]() is p and ent[2] == p._version and ent[3] == p.data_ptr():
+        return ent[1]
+    return None
+
+
 def _cached(p: torch.Tensor, kind: str, fresh: bool = False):
     pid = id(p)
+    if kind == "n":
+        m = _mirror_of(p)
+        if m is not None:
+            return m
     if fresh:
         _wcache.pop(pid, None)
         return _MAKERS[kind](p)

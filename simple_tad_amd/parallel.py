@@ -24,6 +24,8 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+from .flat import FlatSpace
+
 
 def init_distributed_mode(backend: Optional[str] = None):
     """utils.init_distributed_mode (utils.py:283-333): read RANK / WORLD_SIZE / LOCAL_RANK (torchrun / srun / OMPI),
@@ -72,23 +74,17 @@ class DataParallel(nn.Module):
                 for p in module.parameters():
                     p.copy_(flat[off:off + p.numel()].view_as(p))
                     off += p.numel()
-        # flat gradient buffer, reverse registration order, every tensor 16-byte aligned
-        order = list(reversed(params))
-        offs, total = [], 0
-        for p in order:
-            offs.append(total)
-            total += (p.numel() + 3) // 4 * 4
-        self.flat_grad = torch.zeros(total, dtype=dt, device=dev)
-        self._views = {}
-        for p, o in zip(order, offs):
-            self._views[id(p)] = self.flat_grad[o:o + p.numel()].view_as(p)
-            p.grad = self._views[id(p)]
+        # flat gradient buffer (layout shared with the fused optimizer: flat.FlatSpace)
+        self.space = FlatSpace(params)
+        self.flat_grad = self.space.ensure_grads()
+        order = self.space.params
+        offs = [self.space.offset[id(p)] for p in order]
         # buckets = contiguous ranges of the flat buffer
         limit = int(bucket_mb * (1 << 20) / self.flat_grad.element_size())
         self.buckets: List[dict] = []
         start, count = 0, 0
         for i, (p, o) in enumerate(zip(order, offs)):
-            end = o + (p.numel() + 3) // 4 * 4
+            end = o + FlatSpace.padded(p)
             count += 1
             if end - start >= limit or i == len(order) - 1:
                 self.buckets.append({"lo": start, "hi": end, "n": count, "ready": 0})
@@ -105,11 +101,7 @@ class DataParallel(nn.Module):
 
     # -- hook: runs on the autograd thread right after p.grad has been accumulated
     def _on_grad(self, p):
-        view = self._views[id(p)]
-        if p.grad is not view and p.grad.data_ptr() != view.data_ptr():
-            # someone called optimizer.zero_grad(set_to_none=True): autograd allocated a fresh tensor -> re-home it
-            view.copy_(p.grad)
-            p.grad = view
+        self.space.rehome_grad(p)  # someone called optimizer.zero_grad(set_to_none=True): autograd allocated a fresh tensor
         if self.world == 1 or not self.require_sync:
             return
         b = self.buckets[self._bucket_of[id(p)]]

@@ -39,7 +39,7 @@ def test_ctypes_binding_matches_header(lib_path):
     from simple_tad_amd import _lib
     assert sorted(_lib.SIGNATURES) == header_symbols()
     lib = _lib.load()
-    assert lib.tad_abi_version() == 1
+    assert lib.tad_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_host_validation_without_gpu(lib_path):
@@ -56,6 +56,14 @@ def test_host_validation_without_gpu(lib_path):
     assert b"K=60" in lib.tad_last_error_string()
     assert lib.tad_layernorm_fwd(p, p, p, p, 1, None, None, 4, 6, 1e-6, None) == -1  # D % 4
     assert lib.tad_im2col_tubelets(p, p, 1, 3, 3, 16, 16, 2, 8, None) == -1  # T % tubelet
+    lr = (ctypes.c_float * 2)(1e-3, 1e-3)
+    wd = (ctypes.c_float * 2)(0.05, 0.0)
+    st = (ctypes.c_int32 * 2)(1, 0)
+    assert lib.tad_adamw_step(p, p, p, p, None, p, 4096, lr, wd, 2, st, 0.9, 0.999, 1e-8, None, None, None) == -1  # steps count from 1
+    assert b"step" in lib.tad_last_error_string()
+    st[1] = 1
+    assert lib.tad_adamw_step(p, p, p, p, None, p, 4098, lr, wd, 2, st, 0.9, 0.999, 1e-8, None, None, None) == -1  # n % 4
+    assert lib.tad_adamw_step(p, p, p, p, None, p, 4096, lr, wd, 200, st, 0.9, 0.999, 1e-8, None, None, None) == -1  # > MAX_GROUPS
 
 
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):

@@ -1,0 +1,176 @@
+"""Fused AdamW on the GPU against the reference's pins: parameters after one step of the tiny model (golden G3,
+produced by torch.optim.AdamW inside the real reference run), the oracle's restated update rule over several steps with
+layer-decay groups and per-step lr / weight-decay tables, the grad-norm definition, clipping, the bf16 operand mirror and
+the torch.optim.AdamW state-dict layout.  Tolerance: f32 rounding (1e-6 relative) -- the update is elementwise f32."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import golden_recipe as R
+import simple_tad_amd as T
+from simple_tad_amd import engine as E, ops
+from simple_tad_amd.optim import FusedAdamW
+from simple_tad_amd.parallel import DataParallel
+from oracle import vit_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def rell2(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def tiny():
+    c = R.TINY
+    m = T.VisionTransformer(img_size=c["img_size"], patch_size=c["patch_size"], embed_dim=c["embed_dim"], depth=c["depth"],
+                            num_heads=c["num_heads"], mlp_ratio=4, qkv_bias=True, all_frames=c["all_frames"],
+                            tubelet_size=c["tubelet_size"], num_classes=c["num_classes"], init_scale=1.0)
+    shapes = R.vit_param_shapes(c["embed_dim"], c["depth"], c["num_classes"], tubelet=c["tubelet_size"], patch=c["patch_size"])
+    P = R.params_for(shapes, seed=3)
+    m.load_state_dict(P, strict=False)
+    x = R.tensor_for("tiny.x", (2, 3, c["all_frames"], c["img_size"], c["img_size"]), seed=3)
+    return m.cuda(), P, x
+
+
+def oracle_grads(P, x):
+    c = R.TINY
+    Pd = {k: v.double().requires_grad_() for k, v in P.items()}
+    logits = O.forward(x.double(), Pd, depth=c["depth"], num_heads=c["num_heads"], tubelet=c["tubelet_size"], patch=c["patch_size"])
+    F.cross_entropy(logits, torch.tensor([0, 1])).backward()
+    return {k: v.grad for k, v in Pd.items()}
+
+
+def test_one_step_matches_reference_golden(golden):
+    """G3 'after.*': parameters of the real reference after torch.optim.AdamW(lr 1e-3, wd 0.05).step() on the fp64 gradients."""
+    g = golden("g3_tiny_model")
+    m, P, x = tiny()
+    grads = oracle_grads(P, x)
+    opt = FusedAdamW(m.parameters(), lr=1e-3, weight_decay=0.05, betas=(0.9, 0.999))
+    for k, p in m.named_parameters():
+        p.grad.copy_(grads[k].float())
+    sumsq = opt.step(want_sumsq=True)
+    assert abs(sumsq.sqrt().item() - float(g["grad_norm"])) < 1e-5 * float(g["grad_norm"])  # utils.get_grad_norm_ definition
+    for k, p in m.named_parameters():
+        R.check_summary(p.detach().float().cpu(), g, "after." + k, rtol=2e-5)
+    # the bf16 operand mirror the next forward reads == bf16(new master weights), bit for bit, and is what ops serves
+    w = m.blocks[0].attn.qkv.weight
+    assert torch.equal(ops.w_bf16(w, True), w.detach().to(torch.bfloat16))
+    assert ops.w_bf16(w, True).data_ptr() == opt.space.view(opt.mirror, w).data_ptr()
+
+
+def test_layer_decay_groups_schedules_and_state_dict_over_steps():
+    m, P, x = tiny()
+    dp = DataParallel(m)
+    opt = E.create_optimizer(dp, lr=1e-3, weight_decay=0.05, layer_decay=0.75)
+    assert isinstance(opt, FusedAdamW) and opt.space is dp.space
+    names = {id(p): k for k, p in m.named_parameters()}
+    lr_tab = E.cosine_scheduler(2e-3, 1e-5, 1, 4, warmup_epochs=0)
+    wd_tab = E.cosine_scheduler(0.05, 0.1, 1, 4, warmup_epochs=0)
+    ref = {k: v.double().clone() for k, v in P.items()}
+    mom = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in ref.items()}
+    gen = torch.Generator().manual_seed(5)
+    for it in range(4):
+        for g in opt.param_groups:  # engine_for_finetuning.py:49-54
+            g["lr"] = lr_tab[it] * g["lr_scale"]
+            if g["weight_decay"] > 0:
+                g["weight_decay"] = wd_tab[it]
+        grads = {k: torch.randn(v.shape, generator=gen) * 0.1 for k, v in ref.items()}
+        for k, p in m.named_parameters():
+            p.grad.copy_(grads[k])
+        opt.step()
+        for g in opt.param_groups:
+            for p in g["params"]:
+                k = names[id(p)]
+                ref[k], m1, m2 = O.adamw_step(ref[k], grads[k].float().double(), mom[k][0], mom[k][1], it + 1, g["lr"], g["weight_decay"])
+                mom[k] = (m1, m2)
+    worst = max(rell2(p.detach(), ref[k]) for k, p in m.named_parameters())
+    assert worst < 2e-6, worst
+    # no-decay groups really had weight_decay 0 and deeper layers a larger lr_scale (optim_factory.py:49-88)
+    by = {names[id(p)]: g for g in opt.param_groups for p in g["params"]}
+    assert by["blocks.0.norm1.weight"]["weight_decay"] == 0 and by["blocks.0.attn.qkv.weight"]["weight_decay"] > 0
+    assert by["patch_embed.proj.weight"]["lr_scale"] < by["blocks.1.mlp.fc1.weight"]["lr_scale"] < by["head.weight"]["lr_scale"] == 1.0
+    # state dict = torch.optim.AdamW layout, round-trips through a fresh optimizer
+    sd = opt.state_dict()
+    assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 4
+    m2, _, _ = tiny()
+    m2.load_state_dict(m.state_dict())
+    opt2 = E.create_optimizer(m2, lr=1e-3, weight_decay=0.05, layer_decay=0.75)
+    opt2.load_state_dict(sd)
+    assert opt2.steps == 4  # (the two optimizers use different flat layouts: DataParallel's vs group order)
+    for a, b in zip(m.parameters(), m2.parameters()):
+        assert torch.equal(opt.state[a]["exp_avg_sq"], opt2.state[b]["exp_avg_sq"])
+        assert opt2.state[b]["exp_avg"].data_ptr() == opt2.space.view(opt2.exp_avg, b).data_ptr()  # still aliases the flat buffer
+    for k, p in m.named_parameters():
+        p.grad.fill_(0.01)
+    for p in m2.parameters():
+        p.grad.fill_(0.01)
+    opt.step()
+    opt2.step()
+    for (k, a), (_, b) in zip(m.named_parameters(), m2.named_parameters()):
+        assert torch.equal(a, b), k
+
+
+def test_matches_torch_adamw_clipping_and_missing_grads():
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in ((300, 70), (5000,), (17,), (64, 64))]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    fused = FusedAdamW([{"params": ps[:2], "weight_decay": 0.1}, {"params": ps[2:], "weight_decay": 0.0, "lr": 3e-3}], lr=1e-2)
+    plain = torch.optim.AdamW([{"params": qs[:2], "weight_decay": 0.1}, {"params": qs[2:], "weight_decay": 0.0, "lr": 3e-3}], lr=1e-2)
+    for it in range(5):
+        gs = [torch.randn_like(p) for p in ps]
+        for p, q, g in zip(ps, qs, gs):
+            p.grad.copy_(g)
+            q.grad = g.clone()
+        if it == 3:  # a parameter without a gradient is skipped by torch.optim: no decay, no moment update, no step count
+            ps[2].grad = None
+            qs[2].grad = None
+        if it == 4:  # clipping: clip_grad_norm_'s coefficient applied inside the kernel
+            norm = torch.nn.utils.clip_grad_norm_(qs, 0.5)
+            coef = torch.clamp(0.5 / (norm + 1e-6), max=1.0).reshape(1)
+            fused.step(grad_scale=coef)
+        else:
+            fused.step()
+        plain.step()
+        if it == 3:
+            fused.zero_grad()  # re-installs the flat view for ps[2]
+    for p, q in zip(ps, qs):
+        assert rell2(p.detach(), q.detach()) < 2e-6
+    assert float(fused.state[ps[2]]["step"]) == 4 and float(fused.state[ps[0]]["step"]) == 5
+
+
+def test_engine_step_with_fused_optimizer_trains_and_reports_the_norm():
+    torch.manual_seed(0)
+    m, P, x = tiny()
+    dp = DataParallel(m)
+    opt = E.create_optimizer(dp, lr=5e-3, weight_decay=0.05, layer_decay=0.75)
+    scaler = E.NativeScalerWithGradNormCount(dp)
+    y = torch.tensor([0, 1]).cuda()
+    m.train()
+    losses = []
+    for it in range(12):
+        loss = F.cross_entropy(dp(x.cuda()), y)
+        if it == 0:
+            # the norm returned by the step == reference definition on the same gradients (checked after backward)
+            loss.backward()
+            ref = O.grad_norm([p.grad.float().cpu() for p in m.parameters()])
+            dp.zero_grad()
+            loss = F.cross_entropy(dp(x.cuda()), y)
+            norm = scaler(loss, opt, parameters=list(m.parameters()), update_grad=True)
+            assert abs(norm.item() - ref.item()) < 1e-4 * ref.item()
+        else:
+            scaler(loss, opt, clip_grad=1.0 if it % 2 else None, parameters=list(m.parameters()), update_grad=True)
+        dp.zero_grad()
+        losses.append(loss.item())
+    assert all(math.isfinite(v) for v in losses) and losses[-1] < 0.5 * losses[0], losses
+    # after training the forward sees the current master weights (mirror path) -- compare with the oracle on them
+    Pn = {k: v.detach().double().cpu() for k, v in m.state_dict().items()}
+    c = R.TINY
+    ref = O.forward(x.double(), Pn, depth=c["depth"], num_heads=c["num_heads"], tubelet=c["tubelet_size"], patch=c["patch_size"])
+    m.eval()
+    with torch.no_grad():
+        out = m(x.cuda())
+    assert rell2(out, ref) < 1e-2

@@ -73,12 +73,12 @@ def _worker(rank, world, port, q):
     mean = torch.stack(allg).mean(0)
     mine = torch.cat([p.grad.flatten() for p in reversed(list(model.parameters()))])
     err = (mine - mean).abs().max().item()
-    same_views = all(p.grad.data_ptr() == dp._views[id(p)].data_ptr() for p in model.parameters())
+    same_views = all(p.grad.data_ptr() == dp.space.grad_view(p).data_ptr() for p in model.parameters())
     # optimizer.zero_grad(set_to_none=True) must not break the flat buffer
     opt.zero_grad(set_to_none=True)
     (crit(dp(xs[0]), ys[0])).backward()
     dp.finish()
-    rehomed = all(p.grad.data_ptr() == dp._views[id(p)].data_ptr() for p in model.parameters())
+    rehomed = all(p.grad.data_ptr() == dp.space.grad_view(p).data_ptr() for p in model.parameters())
     q.put((rank, err, same_views, rehomed, float(local_after_first.abs().sum()) > 0))
     dist.barrier()
     dist.destroy_process_group()
@@ -100,3 +100,27 @@ def test_bucketed_allreduce_world2_gloo():
     for rank, err, same_views, rehomed, had_local in res:
         assert err < 1e-6, (rank, err)
         assert same_views and rehomed and had_local
+
+
+def test_flat_space_layout_and_views():
+    """flat.FlatSpace: reverse registration order, every tensor on a 4096-element boundary, gradients/params re-homed as views."""
+    import torch
+    from simple_tad_amd.flat import FlatSpace
+    lin = torch.nn.Sequential(torch.nn.Linear(10, 7), torch.nn.Linear(7, 3))
+    before = [p.detach().clone() for p in lin.parameters()]
+    lin[0].weight.grad = torch.full_like(lin[0].weight, 2.0)
+    sp = FlatSpace(list(lin.parameters()))
+    assert [tuple(p.shape) for p in sp.params] == [(3,), (3, 7), (7,), (7, 10)]
+    assert all(o % FlatSpace.ALIGN == 0 for o in sp.offset.values()) and sp.total == 4 * FlatSpace.ALIGN
+    fg = sp.ensure_grads()
+    assert lin[0].weight.grad.data_ptr() == fg.data_ptr() + sp.offset[id(lin[0].weight)] * 4
+    assert float(fg.sum()) == 2.0 * 70  # an existing gradient is kept, padding stays zero
+    fp = sp.adopt_params()
+    assert sp.params_are_flat() and all(torch.equal(a, b) for a, b in zip(before, lin.parameters()))
+    lin[1].bias.data.add_(1.0)
+    assert torch.equal(sp.view(fp, lin[1].bias), before[3] + 1.0)  # the parameter IS the flat storage
+    lin[0].weight.grad = None
+    sp.rehome_grad(lin[0].weight)
+    assert lin[0].weight.grad.data_ptr() == sp.grad_view(lin[0].weight).data_ptr() and float(fg.sum()) == 0.0
+    lin[0].weight.data = lin[0].weight.data.clone()
+    assert not sp.params_are_flat()
