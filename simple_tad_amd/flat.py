@@ -61,6 +61,15 @@ class FlatSpace:
                 p.grad = v
         return self.flat_grad
 
+    def install_sinks(self, notify=None) -> None:
+        """Let the weight-gradient kernels accumulate straight into the flat gradient buffer (ops.register_grad_sink); ``notify(p)``
+        is called after a gradient has been written this way (autograd's own hooks do not fire for it)."""
+        from . import ops
+        self.ensure_grads()
+        for p in self.params:
+            if p.is_cuda:
+                ops.register_grad_sink(p, self._grad_views[id(p)], notify)
+
     def grad_view(self, p) -> torch.Tensor:
         return self._grad_views[id(p)]
 

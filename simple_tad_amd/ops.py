@@ -67,6 +67,45 @@ def _mirror_of(p):
     return None
 
 
+# Gradient sinks: when a parameter's gradient lives in a flat buffer (flat.FlatSpace, set up by parallel.DataParallel or
+# optim.FusedAdamW), the weight-gradient GEMM accumulates straight into ``p.grad`` (the kernel's ``accumulate`` mode) instead
+# of materialising dW and letting autograd run ``p.grad += dW`` -- one read-modify-write pass over every weight gradient and
+# ~80 small launches per step less.  The Function then returns None for that parameter, so autograd's post-accumulate hooks do
+# not fire; the sink's ``notify`` callback (DataParallel's bucket logic) is called instead.
+_sinks = {}  # id(param) -> (weakref, flat gradient view, notify | None)
+
+
+def register_grad_sink(p: torch.Tensor, view: torch.Tensor, notify=None):
+    pid = id(p)
+    _sinks[pid] = (weakref.ref(p, lambda _r, pid=pid: _sinks.pop(pid, None)), view, notify)
+
+
+def _sink(p):
+    """the flat gradient view of p if p.grad currently IS that view (f32, contiguous), else None"""
+    if p is None:
+        return None
+    ent = _sinks.get(id(p))
+    if ent is None or ent[0]() is not p or p.grad is None or p.grad.data_ptr() != ent[1].data_ptr() or torch.is_grad_enabled():
+        return None  # (grad mode is on inside backward only under create_graph=True: leave that to autograd)
+    return ent
+
+
+def linear_dw(dy, x, w, b=None, loose_bias=False):
+    """(dW, db) of a Linear for autograd.  With gradient sinks on the parameters the gradients are accumulated in place and None is
+    returned in their stead.  ``loose_bias``: the column sums of dy are wanted as a tensor although there is no bias Parameter to
+    sink them into (qkv: they are split into q_bias / v_bias afterwards)."""
+    sw = _sink(w)
+    sb = _sink(b) if b is not None else None
+    if sw is not None and (b is None or sb is not None):
+        db = sb[1] if b is not None else (torch.zeros(w.shape[0], dtype=torch.float32, device=dy.device) if loose_bias else None)
+        K.linear_bwd_weight(dy, x, want_bias=db is not None, dW=sw[1].view(w.shape[0], -1), db=db, accumulate=True)
+        for ent, prm in ((sw, w), (sb, b)):
+            if ent is not None and ent[2] is not None:
+                ent[2](prm)
+        return None, (db if b is None else None)
+    return K.linear_bwd_weight(dy, x, want_bias=(b is not None or loose_bias))
+
+
 def _cached(p: torch.Tensor, kind: str, fresh: bool = False):
     pid = id(p)
     if kind == "n":
@@ -216,17 +255,17 @@ class PatchEmbedFn(torch.autograd.Function):
         xc = _f32c(x)
         out, cols = K.patch_embed_fwd(xc, w_bf16(weight, any(ctx.needs_input_grad)), _f32c(bias), _f32c(pos), tubelet, patch)
         ctx.save_for_backward(cols)
-        ctx.wshape = weight.shape
-        ctx.has_bias = bias is not None
+        ctx.params = (weight, bias)
         return out
 
     @staticmethod
     def backward(ctx, dy):
         (cols,) = ctx.saved_tensors
+        weight, bias = ctx.params
         D = dy.shape[-1]
         dyb = K.cast_bf16(_f32c(dy).reshape(-1, D))
-        dW, db = K.linear_bwd_weight(dyb, cols, want_bias=ctx.has_bias)
-        return None, dW.reshape(ctx.wshape), db, None, None, None
+        dW, db = linear_dw(dyb, cols, weight, bias)
+        return None, (None if dW is None else dW.reshape(weight.shape)), db, None, None, None
 
 
 # --------------------------------------------------------------------------- attention / mlp cores (2-D tensors)
@@ -241,7 +280,7 @@ def _attn_bwd_core(d_ao, xn, qkv, ao, lse, qkv_w, has_qkv_bias, B, N, H, scale, 
     D = xn.shape[1]
     dqkv = K.attn_bwd(qkv, ao, d_ao, lse, B, N, H, scale)
     dxn = K.linear_bwd_input(dqkv, wT_bf16(qkv_w, True), out_dtype=dx_dtype)
-    dWqkv, dbqkv = K.linear_bwd_weight(dqkv, xn, want_bias=has_qkv_bias)
+    dWqkv, dbqkv = linear_dw(dqkv, xn, qkv_w, None, loose_bias=has_qkv_bias)
     if has_qkv_bias:
         AH = dbqkv.numel() // 3
         return dxn, dWqkv, dbqkv[:AH].clone(), dbqkv[2 * AH:].clone()
@@ -262,6 +301,7 @@ class AttentionFn(torch.autograd.Function):
         if train:
             ctx.save_for_backward(xb, qkv, ao, lse, qkv_w, proj_w)
         ctx.meta = (B, N, H, scale, q_bias is not None, proj_b is not None)
+        ctx.proj_b = proj_b
         return y.reshape(B, N, -1)
 
     @staticmethod
@@ -270,7 +310,7 @@ class AttentionFn(torch.autograd.Function):
         B, N, H, scale, has_qb, has_pb = ctx.meta
         dyb = K.cast_bf16(_f32c(dy).reshape(B * N, -1))
         d_ao = K.linear_bwd_input(dyb, wT_bf16(proj_w, True))
-        dWp, dbp = K.linear_bwd_weight(dyb, ao, want_bias=has_pb)
+        dWp, dbp = linear_dw(dyb, ao, proj_w, ctx.proj_b)
         dx, dWqkv, dqb, dvb = _attn_bwd_core(d_ao, xb, qkv, ao, lse, qkv_w, has_qb, B, N, H, scale, torch.float32)
         return dx.reshape(B, N, -1), dWqkv, dqb, dvb, dWp, dbp, None, None
 
@@ -289,6 +329,7 @@ class MlpFn(torch.autograd.Function):
         if train:
             ctx.save_for_backward(xb, h, a, fc1_w, fc2_w)
         ctx.meta = (shp, fc1_b is not None, fc2_b is not None)
+        ctx.biases = (fc1_b, fc2_b)
         return y.reshape(*shp[:-1], -1)
 
     @staticmethod
@@ -297,9 +338,9 @@ class MlpFn(torch.autograd.Function):
         shp, has_b1, has_b2 = ctx.meta
         dyb = K.cast_bf16(_f32c(dy).reshape(-1, dy.shape[-1]))
         dh = K.linear_bwd_input(dyb, wT_bf16(fc2_w, True), gelu_preact=h)
-        dW2, db2 = K.linear_bwd_weight(dyb, a, want_bias=has_b2)
+        dW2, db2 = linear_dw(dyb, a, fc2_w, ctx.biases[1])
         dx = K.linear_bwd_input(dh, wT_bf16(fc1_w, True), out_dtype=torch.float32)
-        dW1, db1 = K.linear_bwd_weight(dh, xb, want_bias=has_b1)
+        dW1, db1 = linear_dw(dh, xb, fc1_w, ctx.biases[0])
         return dx.reshape(shp), dW1, db1, dW2, db2
 
 
@@ -330,21 +371,23 @@ class BlockFn(torch.autograd.Function):
             ctx.save_for_backward(x0, g1, mean1, rstd1, xn1, qkv, ao, lse, x1, g2, mean2, rstd2, xn2, h, a, qkv_w, proj_w, fc1_w, fc2_w,
                                   dp1 if dp1 is None else _f32c(dp1), dp2 if dp2 is None else _f32c(dp2))
         ctx.meta = (B, N, D, H, scale, q_bias is not None)
+        ctx.biases = (proj_b, fc1_b, fc2_b)
         return x2.reshape(B, N, D)
 
     @staticmethod
     def backward(ctx, g):
         (x0, g1, mean1, rstd1, xn1, qkv, ao, lse, x1, g2, mean2, rstd2, xn2, h, a, qkv_w, proj_w, fc1_w, fc2_w, dp1,
          dp2) = ctx.saved_tensors
+        proj_b, fc1_b, fc2_b = ctx.biases
         B, N, D, H, scale, has_qb = ctx.meta
         M = B * N
         g = _f32c(g).reshape(M, D)
         # ---- MLP branch
         gb = K.cast_bf16(g) if dp2 is None else K.scale_cast_bf16(g, None, dp2, N)
         dh = K.linear_bwd_input(gb, wT_bf16(fc2_w, True), gelu_preact=h)
-        dW2, db2 = K.linear_bwd_weight(gb, a)
+        dW2, db2 = linear_dw(gb, a, fc2_w, fc2_b)
         dxn2 = K.linear_bwd_input(dh, wT_bf16(fc1_w, True))
-        dW1, db1 = K.linear_bwd_weight(dh, xn2)
+        dW1, db1 = linear_dw(dh, xn2, fc1_w, fc1_b)
         gmid, gmid_b, dg2, dbeta2, cs = K.layernorm_bwd(dxn2, x1, g2, mean2, rstd2, dres=g, want_bf16=(dp1 is None),
                                                        want_colsum=(dp1 is None))
         # ---- attention branch
@@ -354,9 +397,10 @@ class BlockFn(torch.autograd.Function):
             gpb = K.scale_cast_bf16(gmid, None, dp1, N)
             dbp = None
         d_ao = K.linear_bwd_input(gpb, wT_bf16(proj_w, True))
-        dWp, dbp2 = K.linear_bwd_weight(gpb, ao, want_bias=(dbp is None))
         if dbp is None:
-            dbp = dbp2
+            dWp, dbp = linear_dw(gpb, ao, proj_w, proj_b)
+        else:
+            dWp, _ = linear_dw(gpb, ao, proj_w)
         dxn1, dWqkv, dqb, dvb = _attn_bwd_core(d_ao, xn1, qkv, ao, lse, qkv_w, has_qb, B, N, H, scale, torch.bfloat16)
         gin, _, dg1, dbeta1, _ = K.layernorm_bwd(dxn1, x0, g1, mean1, rstd1, dres=gmid)
         return (gin.reshape(B, N, D), dg1, dbeta1, dWqkv, dqb, dvb, dWp, dbp, dg2, dbeta2, dW1, db1, dW2, db2, None, None, None, None,

@@ -35,6 +35,8 @@ class FusedAdamW(torch.optim.Optimizer):
         if not all(p in self.space for p in plist):
             raise TadError("FusedAdamW: the flat layout does not contain every optimised parameter")
         self.flat_grad = self.space.ensure_grads()
+        if space is None:
+            self.space.install_sinks()  # (DataParallel installs its own, with the bucket notification)
         self.flat_param = self.space.adopt_params()
         self.exp_avg, self.exp_avg_sq = self.space.zeros(), self.space.zeros()
         chunks = self.space.total // ADAMW_CHUNK

@@ -97,6 +97,7 @@ class DataParallel(nn.Module):
             self._bucket_of[id(p)] = bi
         self._works = []
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in order]
+        self.space.install_sinks(self._on_grad)  # GPU: dW GEMMs accumulate in place and call _on_grad themselves
         self.require_sync = True
 
     # -- hook: runs on the autograd thread right after p.grad has been accumulated

@@ -155,3 +155,28 @@ def test_weight_copies_follow_master_weights_across_fused_optimizer_steps():
     F.cross_entropy(O.forward(x.double(), Pg, depth=2, num_heads=2, tubelet=2, patch=16), y.cpu()).backward()
     for k in ("blocks.0.attn.qkv.weight", "blocks.1.mlp.fc1.weight", "patch_embed.proj.weight"):
         assert rell2(dict(m.named_parameters())[k].grad, Pg[k].grad) < 4e-2, k
+
+
+def test_gradient_sinks_write_the_same_gradients_in_place():
+    """With a flat gradient buffer (DataParallel / FusedAdamW) the dW GEMMs accumulate straight into p.grad and autograd sees None:
+    the result must equal the plain autograd path bit for bit, accumulate over two backward passes, and still notify the
+    bucket logic for every parameter."""
+    ma, mb = _model(128, 2, drop_path_rate=0.0).cuda().train(), _model(128, 2, drop_path_rate=0.0).cuda().train()
+    mb.load_state_dict(ma.state_dict())
+    x = torch.randn(4, 3, 4, 32, 32).cuda()
+    y = torch.tensor([0, 1, 1, 0]).cuda()
+    F.cross_entropy(ma(x), y).backward()
+    dp = DataParallel(mb)
+    seen = []
+    orig = dp._on_grad
+    dp._on_grad = lambda p: (seen.append(id(p)), orig(p))[1]
+    dp.space.install_sinks(dp._on_grad)
+    F.cross_entropy(dp(x), y).backward()
+    for (k, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert pb.grad.data_ptr() == dp.space.grad_view(pb).data_ptr(), k
+        assert torch.equal(pa.grad, pb.grad), k
+    sunk = [k for k, p in mb.named_parameters() if id(p) in seen]
+    assert {"blocks.0.attn.qkv.weight", "blocks.1.mlp.fc2.bias", "patch_embed.proj.weight", "blocks.0.attn.proj.weight"} <= set(sunk)
+    F.cross_entropy(dp(x), y).backward()  # second micro-step accumulates
+    for (k, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert rell2(pb.grad, 2 * pa.grad) < 1e-6, k
