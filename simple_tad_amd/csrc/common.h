@@ -83,6 +83,31 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return fmaf(x * 0.39894228040143267794f, e, cdf);  // Phi(x) + x * phi(x)
 }
 
+// ---- fast-mode GELU for the GEMM epilogues: no transcendental, packed f32 math (v_pk_fma_f32 does two elements per issue).
+// The epilogues of the fc1 / fc2-dX GEMMs are VALU-bound (128 outputs per lane; the A-S form above costs ~76 issue cycles per
+// element = as long as half the K loop); these forms cost ~38.  Coefficients: tools/fit_gelu_poly.py (Chebyshev fit of
+// (f(x) - 0.5)/x in x^2 on |x| <= XMAX, Horner in t = 2x^2/XMAX^2 - 1).  Errors (f32 evaluation): |Phi| <= 3.9e-7, gelu <= 1.9e-6,
+// gelu' <= 7e-6 absolute -- three orders below the bf16 rounding of the values these epilogues read and write.  The precise mode
+// keeps the A-S form.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+constexpr float PHI_XMAX = 5.0f;
+constexpr float PHI_C[13] = {1.413638185e-01f, -7.029590887e-02f, 5.151792974e-02f, -4.045128240e-02f, 3.147675865e-02f, -2.321312828e-02f, 1.623608981e-02f, -1.130712491e-02f, 6.766527505e-03f, -2.526916729e-03f, 1.374596151e-03f, -1.676730979e-03f, 7.353763888e-04f};
+constexpr float DGELU_XMAX = 5.5f;
+constexpr float DGELU_C[14] = {1.287606817e-01f, -6.574511122e-02f, 5.352302286e-02f, -5.354277321e-02f, 6.254520933e-02f, -7.080669140e-02f, 6.123300602e-02f, -6.376653697e-02f, 1.008177666e-01f, -7.514079910e-02f, -9.145315790e-03f, 6.300958162e-04f, 4.666087374e-02f, -2.511548108e-02f};
+
+__device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
+template <int N>
+__device__ __forceinline__ f32x2 half_plus_x_poly2(f32x2 x, const float (&c)[N], float xmax) {
+  const f32x2 xc = f32x2{__builtin_amdgcn_fmed3f(x[0], -xmax, xmax), __builtin_amdgcn_fmed3f(x[1], -xmax, xmax)};
+  const f32x2 t = __builtin_elementwise_fma(xc * xc, splat2(2.0f / (xmax * xmax)), splat2(-1.0f));
+  f32x2 r = splat2(c[N - 1]);
+#pragma unroll
+  for (int i = N - 2; i >= 0; --i) r = __builtin_elementwise_fma(r, t, splat2(c[i]));
+  return __builtin_elementwise_fma(xc, r, splat2(0.5f));
+}
+__device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) { return x * half_plus_x_poly2(x, PHI_C, PHI_XMAX); }
+__device__ __forceinline__ f32x2 gelu_grad_fast2(f32x2 x) { return half_plus_x_poly2(x, DGELU_C, DGELU_XMAX); }
+
 // Bijective XCD-aware block remap (8 XCDs, blocks dealt round-robin): consecutive logical ids land on one XCD.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7;

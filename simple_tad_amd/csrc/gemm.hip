@@ -303,13 +303,18 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
             }
           }
 #pragma unroll
-          for (int e = 0; e < CPL; ++e) v[b][e] = gelu_erf(v[b][e]);
+          for (int e = 0; e < CPL; e += 2) {
+            const f32x2 y2 = gelu_fast2(f32x2{v[b][e], v[b][e + 1]});
+            v[b][e] = y2[0];
+            v[b][e + 1] = y2[1];
+          }
         } else if (EPI == EPI_DGELU) {
           const uint32_t hw[4] = {hh[b].x, hh[b].y, hh[b].z, hh[b].w};
 #pragma unroll
           for (int e = 0; e < CPL / 2; ++e) {
-            v[b][2 * e] *= gelu_erf_grad(__uint_as_float(hw[e] << 16));
-            v[b][2 * e + 1] *= gelu_erf_grad(__uint_as_float(hw[e] & 0xffff0000u));
+            const f32x2 g2 = gelu_grad_fast2(f32x2{__uint_as_float(hw[e] << 16), __uint_as_float(hw[e] & 0xffff0000u)});
+            v[b][2 * e] *= g2[0];
+            v[b][2 * e + 1] *= g2[1];
           }
         } else if (EPI == EPI_RESIDUAL) {
           if (p.gamma || p.rowscale) {
