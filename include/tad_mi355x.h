@@ -142,6 +142,12 @@ int tad_scale_cast_bf16(const float* x, uint16_t* y, const float* gamma, const f
 /* sum of squares of an f32 vector, accumulated into *out (f32, device) -- get_grad_norm_ (utils.py:415-427) */
 int tad_sumsq_f32(const float* x, int64_t n, float* out, tad_stream_t stream);
 
+/* Batched bf16 transpose: every [R,C] matrix of a flat buffer -> [C,R] at the same offset of a second flat buffer, one launch (the
+ * transposed operand copies W^T that the input-gradient GEMMs of all Linear layers read; refreshed once per optimizer step).
+ * table (device, int32 [n_tiles][8]): per 64x64 tile {src offset, dst offset, C, R, valid rows, valid cols, 0, 0} in elements,
+ * offsets < 2^32; R % 8 == C % 8 == 0 and 16-byte aligned matrices. */
+int tad_transpose_bf16_batched(const uint16_t* src, uint16_t* dst, const int32_t* table, int n_tiles, tad_stream_t stream);
+
 /* ---- optimizer tail -------------------------------------------------------------------------------------------
  * Fused multi-tensor AdamW over FLAT buffers: replaces torch.optim.AdamW as configured by optim_factory.create_optimizer
  * (optim_factory.py:91-127) with the layer-decay parameter groups of optim_factory.get_parameter_groups (:49-88) and the per-step

@@ -47,6 +47,44 @@ __global__ void transpose_cast_kernel(const float* __restrict__ src, uint16_t* _
   }
 }
 
+// ---------------------------------------------------------------- batched bf16 transpose (operand mirrors of all weights, one launch)
+// One workgroup per 64x64 tile of some matrix of the batch; the tile list is precomputed on the host (flat layouts never change):
+// table[t] = {src offset of the tile, dst offset of the tile, C (src row pitch), R (dst row pitch), valid rows, valid cols,
+// 0, 0} in elements; every matrix has R % 8 == C % 8 == 0, so tiles are made of whole 16-byte chunks.
+__global__ __launch_bounds__(256) void transpose_bf16_batched_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst,
+                                                                     const int4* __restrict__ table) {
+  __shared__ uint16_t tile[64][66];
+  const int4 t0 = table[2 * blockIdx.x], t1 = table[2 * blockIdx.x + 1];
+  const int64_t so = (uint32_t)t0.x, d_o = (uint32_t)t0.y;
+  const int C = t0.z, R = t0.w, rows = t1.x, cols = t1.y;
+  const int r = threadIdx.x >> 2, ch = (threadIdx.x & 3) * 2;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int c0 = (ch + k) * 8;
+    if (r < rows && c0 < cols) {
+      const uint4 v = *reinterpret_cast<const uint4*>(src + so + (int64_t)r * C + c0);
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        tile[r][c0 + 2 * e] = (uint16_t)(w[e] & 0xffffu);
+        tile[r][c0 + 2 * e + 1] = (uint16_t)(w[e] >> 16);
+      }
+    }
+  }
+  __syncthreads();
+  const int c = r;  // dst row = src column
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int r0 = (ch + k) * 8;
+    if (c < cols && r0 < rows) {
+      uint32_t w[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] = (uint32_t)tile[r0 + 2 * e][c] | ((uint32_t)tile[r0 + 2 * e + 1][c] << 16);
+      *reinterpret_cast<uint4*>(dst + d_o + (int64_t)c * R + r0) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  }
+}
+
 // ---------------------------------------------------------------- tubelet im2col
 // x [B,C,T,H,W] f32 -> cols [B*N, K] bf16, token n = (t'*H' + h')*W' + w', k = ((c*tub+kt)*p+kh)*p+kw.
 // One thread moves 8 consecutive w (32 B in, 16 B out); threads walk x in memory order -> coalesced reads.
@@ -298,6 +336,14 @@ int tad_transpose_cast_f32_bf16(const float* src, uint16_t* dst, int R, int C, t
   TAD_REQUIRE(src && dst && R > 0 && C > 0, "transpose_cast: bad args");
   hipLaunchKernelGGL(transpose_cast_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, (hipStream_t)stream, src, dst, R, C);
   return check_launch("transpose_cast");
+}
+
+int tad_transpose_bf16_batched(const uint16_t* src, uint16_t* dst, const int32_t* table, int n_tiles, tad_stream_t stream) {
+  TAD_REQUIRE(src && dst && table && n_tiles > 0, "transpose_bf16_batched: bad args");
+  TAD_REQUIRE((((uintptr_t)src | (uintptr_t)dst | (uintptr_t)table) & 15) == 0, "transpose_bf16_batched: buffers must be 16-byte aligned");
+  hipLaunchKernelGGL(transpose_bf16_batched_kernel, dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, src, dst,
+                     reinterpret_cast<const int4*>(table));
+  return check_launch("transpose_bf16_batched");
 }
 
 int tad_im2col_tubelets(const float* x, uint16_t* cols, int B, int C, int T, int H, int W, int tubelet, int patch,

@@ -134,6 +134,34 @@ def transpose_cast_bf16(w: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def transpose_table(mats):
+    """Host-side tile list for transpose_bf16_batched: mats = [(element offset, R, C)], every matrix stored [R,C] row-major at
+    ``offset`` of the source buffer and written [C,R] at the same offset of the destination.  Returns an int32 [n_tiles, 8] tensor."""
+    rows = []
+    for off, R, C in mats:
+        if R % 8 or C % 8 or off % 8:
+            raise _lib.TadError(f"transpose_table: matrix [{R},{C}] at {off} is not made of whole 16-byte chunks")
+        for r0 in range(0, R, 64):
+            for c0 in range(0, C, 64):
+                rows.append((off + r0 * C + c0, off + c0 * R + r0, C, R, min(64, R - r0), min(64, C - c0), 0, 0))
+    import numpy as np
+    arr = np.asarray(rows, dtype=np.int64).reshape(-1, 8)
+    if arr.size and int(arr[:, :2].max()) >= (1 << 32):
+        raise _lib.TadError("transpose_table: offsets exceed 2^32 elements")
+    return torch.from_numpy(arr.astype(np.uint32).view(np.int32))
+
+
+def transpose_bf16_batched(src, dst, table):
+    _req(src, torch.bfloat16, "transpose_batched.src")
+    _req(dst, torch.bfloat16, "transpose_batched.dst")
+    if table.dtype != torch.int32 or not table.is_cuda or table.dim() != 2 or table.shape[1] != 8 or not table.is_contiguous():
+        raise _lib.TadError("transpose_bf16_batched: table must be a contiguous int32 [n_tiles, 8] device tensor")
+    with _timed("cast", 0.0, 4.0 * 4096 * table.shape[0]):
+        check(_lib.load().tad_transpose_bf16_batched(src.data_ptr(), dst.data_ptr(), table.data_ptr(), table.shape[0], _stream()),
+              "tad_transpose_bf16_batched")
+    return dst
+
+
 def scale_cast_bf16(x, gamma=None, rowscale=None, rows_per_scale=1):
     _req(x, torch.float32, "scale_cast.x")
     M, N = x.shape

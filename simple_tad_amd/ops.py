@@ -52,16 +52,18 @@ _MAKERS["st"] = lambda p: K.split_bf16x3(_w2d(p).t().contiguous(), role_b=True) 
 
 # Operand mirrors: optim.FusedAdamW writes bf16(p) for every weight in the same pass that updates p and registers the views
 # here; a mirror is served only while the parameter still is the tensor (same storage, same version) the optimizer wrote.
-_mirrors = {}  # id(param) -> (weakref, bf16 [N,K] view, version, data_ptr)
+_mirrors = {}    # id(param) -> (weakref, bf16 [N,K] view, version, data_ptr)
+_mirrors_t = {}  # id(param) -> (weakref, bf16 [K,N] view of W^T, version, data_ptr)
 
 
-def register_mirror(p: torch.Tensor, view: torch.Tensor):
+def register_mirror(p: torch.Tensor, view: torch.Tensor, transposed: bool = False):
     pid = id(p)
-    _mirrors[pid] = (weakref.ref(p, lambda _r, pid=pid: _mirrors.pop(pid, None)), view, p._version, p.data_ptr())
+    tab = _mirrors_t if transposed else _mirrors
+    tab[pid] = (weakref.ref(p, lambda _r, pid=pid, tab=tab: tab.pop(pid, None)), view, p._version, p.data_ptr())
 
 
-def _mirror_of(p):
-    ent = _mirrors.get(id(p))
+def _mirror_of(p, transposed: bool = False):
+    ent = (_mirrors_t if transposed else _mirrors).get(id(p))
     if ent is not None and ent[0]() is p and ent[2] == p._version and ent[3] == p.data_ptr():
         return ent[1]
     return None
@@ -108,8 +110,8 @@ def linear_dw(dy, x, w, b=None, loose_bias=False):
 
 def _cached(p: torch.Tensor, kind: str, fresh: bool = False):
     pid = id(p)
-    if kind == "n":
-        m = _mirror_of(p)
+    if kind in ("n", "t"):
+        m = _mirror_of(p, kind == "t")
         if m is not None:
             return m
     if fresh:

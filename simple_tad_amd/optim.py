@@ -52,10 +52,17 @@ class FusedAdamW(torch.optim.Optimizer):
         for p in plist:  # torch.optim.AdamW's state layout; the moment tensors alias the flat buffers
             self.state[p] = {"step": torch.tensor(0.0), "exp_avg": self.space.view(self.exp_avg, p),
                              "exp_avg_sq": self.space.view(self.exp_avg_sq, p)}
-        self.mirror = None
+        self.mirror = self.mirror_t = None
         if mirror:
             self.mirror = self.space.zeros(torch.bfloat16)
             K.cast_bf16(self.flat_param, out=self.mirror)
+            # transposed copies W^T [K,N] (operand of the input-gradient GEMMs), same offsets, refreshed by ONE batched launch
+            self._t_params = [p for p in self.space.params if p.dim() >= 2 and p.shape[0] % 8 == 0 and (p.numel() // p.shape[0]) % 8 == 0]
+            if self._t_params:
+                self.mirror_t = self.space.zeros(torch.bfloat16)
+                self._t_table = K.transpose_table([(self.space.offset[id(p)], p.shape[0], p.numel() // p.shape[0])
+                                                   for p in self._t_params]).to(self.space.device)
+                K.transpose_bf16_batched(self.mirror, self.mirror_t, self._t_table)
             self._publish_mirror()
 
     # ------------------------------------------------------------------ bf16 operand copies for the forward GEMMs
@@ -63,6 +70,10 @@ class FusedAdamW(torch.optim.Optimizer):
         for p in self.space.params:
             if p.dim() >= 2:
                 ops.register_mirror(p, self.space.view(self.mirror, p).view(p.shape[0], -1))
+        if self.mirror_t is not None:
+            for p in self._t_params:
+                o = self.space.offset[id(p)]
+                ops.register_mirror(p, self.mirror_t[o:o + p.numel()].view(p.numel() // p.shape[0], p.shape[0]), transposed=True)
 
     # ------------------------------------------------------------------ step
     @torch.no_grad()
@@ -123,6 +134,8 @@ class FusedAdamW(torch.optim.Optimizer):
             self.state[p]["step"] += 1
         ops.invalidate_weight_cache()
         if self.mirror is not None:
+            if self.mirror_t is not None:
+                K.transpose_bf16_batched(self.mirror, self.mirror_t, self._t_table)
             self._publish_mirror()
         if want_sumsq:
             return self.sumsq_partials.sum()

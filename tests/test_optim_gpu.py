@@ -60,6 +60,27 @@ def test_one_step_matches_reference_golden(golden):
     w = m.blocks[0].attn.qkv.weight
     assert torch.equal(ops.w_bf16(w, True), w.detach().to(torch.bfloat16))
     assert ops.w_bf16(w, True).data_ptr() == opt.space.view(opt.mirror, w).data_ptr()
+    # ... and the transposed mirror (operand of the input-gradient GEMMs) is its exact transpose, refreshed by the same step
+    for w in (m.blocks[0].attn.qkv.weight, m.blocks[1].mlp.fc2.weight, m.patch_embed.proj.weight):
+        wt = ops.wT_bf16(w, True)
+        assert wt.shape == (w.numel() // w.shape[0], w.shape[0])
+        assert torch.equal(wt, w.detach().reshape(w.shape[0], -1).to(torch.bfloat16).t())
+        assert opt.mirror_t.data_ptr() <= wt.data_ptr() < opt.mirror_t.data_ptr() + opt.mirror_t.numel() * 2
+
+
+def test_batched_transpose_ragged_tiles():
+    from simple_tad_amd import kernels as K
+    mats, off = [], 0
+    for R, C in ((8, 8), (72, 200), (64, 64), (136, 24), (768, 2304)):
+        mats.append((off, R, C))
+        off += (R * C + 4095) // 4096 * 4096
+    src = torch.randn(off, device="cuda").to(torch.bfloat16)
+    dst = torch.zeros_like(src)
+    K.transpose_bf16_batched(src, dst, K.transpose_table(mats).cuda())
+    for o, R, C in mats:
+        assert torch.equal(dst[o:o + R * C].view(C, R), src[o:o + R * C].view(R, C).t()), (R, C)
+    with pytest.raises(Exception):
+        K.transpose_table([(0, 10, 16)])
 
 
 def test_layer_decay_groups_schedules_and_state_dict_over_steps():
