@@ -82,12 +82,15 @@ int tad_layernorm_fwd(const float* x, const float* gamma, const float* beta, voi
                       float* mean, float* rstd, int64_t rows, int D, float eps, tad_stream_t stream);
 /* dx = (dres ? dres : 0) + LN'(dy).  Optional outputs: dx_bf16 (copy of dx), colsum_dx [D]
  * (sum over rows of dx: the bias gradient of the Linear that produced x's residual branch).
- * dgamma/dbeta [D] are overwritten.  ws: tad_layernorm_bwd_workspace_bytes(rows, D). */
+ * rowscale (nullable, [ceil(rows / rows_per_scale)]): dx_bf16 and colsum_dx are taken of rowscale[row / rows_per_scale] * dx --
+ * the gradient entering a residual branch whose output was scaled per sample (DropPath, modeling_finetune.py:23-34, 159-163).
+ * accumulate != 0: dgamma, dbeta and colsum_dx are added to (gradient accumulation in place), else overwritten.
+ * ws: tad_layernorm_bwd_workspace_bytes(rows, D). */
 size_t tad_layernorm_bwd_workspace_bytes(int64_t rows, int D);
 int tad_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* mean,
                       const float* rstd, const float* dres, float* dx, uint16_t* dx_bf16, float* dgamma,
-                      float* dbeta, float* colsum_dx, void* ws, size_t ws_bytes, int64_t rows, int D,
-                      tad_stream_t stream);
+                      float* dbeta, float* colsum_dx, const float* rowscale, int rows_per_scale, int accumulate,
+                      void* ws, size_t ws_bytes, int64_t rows, int D, tad_stream_t stream);
 
 /* ---- Linear: F.linear(x, W, b) with fused epilogues ---------------------------------
  * replaces qkv (modeling_finetune.py:88-92), proj (:104), fc1+GELU (:48-49), fc2 (:52) and the

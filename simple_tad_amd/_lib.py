@@ -25,7 +25,7 @@ SIGNATURES = {
     "tad_patch_embed_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i64, _i, _i, _vp]),
     "tad_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i64, _i, _f, _vp]),
     "tad_layernorm_bwd_workspace_bytes": (_sz, [_i64, _i]),
-    "tad_layernorm_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i64, _i, _vp]),
+    "tad_layernorm_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _sz, _i64, _i, _vp]),
     "tad_linear_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp]),
     "tad_linear_bwd_input": (_i, [_vp, _vp, _vp, _i, _vp, _i64, _i, _i, _vp]),
     "tad_linear_bwd_weight_workspace_bytes": (_sz, [_i64, _i, _i]),

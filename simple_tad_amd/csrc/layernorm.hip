@@ -77,7 +77,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
                                                             const float* __restrict__ rstd, const float* __restrict__ dres,
                                                             float* __restrict__ dx, uint16_t* __restrict__ dxb,
                                                             float* __restrict__ partial /*[grid][3][D]*/, int64_t rows, int D,
-                                                            int rows_per_block, int want_colsum) {
+                                                            int rows_per_block, int want_colsum,
+                                                            const float* __restrict__ rowscale, int rows_per_scale) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [4][3][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int D4 = D >> 2;
@@ -132,6 +133,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
           o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
         }
         reinterpret_cast<float4*>(dx + row * D)[c] = o;
+        if (rowscale) {  // the bf16 copy and the column sums feed the branch Linear, whose output was scaled per sample (drop-path)
+          const float sc = rowscale[row / rows_per_scale];
+          o.x *= sc; o.y *= sc; o.z *= sc; o.w *= sc;
+        }
         if (dxb) {
           uint2 p;
           p.x = pack_bf16x2(o.x, o.y);
@@ -211,11 +216,13 @@ int tad_layernorm_fwd(const float* x, const float* gamma, const float* beta, voi
 size_t tad_layernorm_bwd_workspace_bytes(int64_t rows, int D) { return (size_t)3 * ln_bwd_blocks(rows) * (size_t)D * sizeof(float); }
 
 int tad_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* mean, const float* rstd,
-                      const float* dres, float* dx, uint16_t* dx_bf16, float* dgamma, float* dbeta, float* colsum_dx, void* ws,
-                      size_t ws_bytes, int64_t rows, int D, tad_stream_t stream) {
+                      const float* dres, float* dx, uint16_t* dx_bf16, float* dgamma, float* dbeta, float* colsum_dx,
+                      const float* rowscale, int rows_per_scale, int accumulate, void* ws, size_t ws_bytes, int64_t rows, int D,
+                      tad_stream_t stream) {
   TAD_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && ws, "layernorm_bwd: null pointer");
   TAD_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * LN_MAX_V, "layernorm_bwd: unsupported D=%d", D);
   TAD_REQUIRE(dy_dtype == TAD_F32 || dy_dtype == TAD_BF16, "layernorm_bwd: bad dy_dtype %d", dy_dtype);
+  TAD_REQUIRE(!rowscale || rows_per_scale > 0, "layernorm_bwd: rows_per_scale must be positive");
   const int blocks = ln_bwd_blocks(rows);
   if (ws_bytes < (size_t)3 * blocks * D * sizeof(float)) { set_error("layernorm_bwd: workspace too small"); return TAD_ENOSPACE; }
   const int rows_per_block = (int)((rows + blocks - 1) / blocks);
@@ -227,10 +234,10 @@ int tad_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float*
 #define LN_BWD(NV)                                                                                                             \
   if (dy_dtype == TAD_BF16)                                                                                                    \
     hipLaunchKernelGGL((layernorm_bwd_kernel<NV, true>), dim3(blocks), dim3(256), smem, st, dy, x, gamma, mean, rstd, dres, dx, \
-                       dx_bf16, partial, rows, D, rows_per_block, want_cs);                                                    \
+                       dx_bf16, partial, rows, D, rows_per_block, want_cs, rowscale, rows_per_scale);                           \
   else                                                                                                                         \
     hipLaunchKernelGGL((layernorm_bwd_kernel<NV, false>), dim3(blocks), dim3(256), smem, st, dy, x, gamma, mean, rstd, dres, dx, \
-                       dx_bf16, partial, rows, D, rows_per_block, want_cs);
+                       dx_bf16, partial, rows, D, rows_per_block, want_cs, rowscale, rows_per_scale);
   switch (nv) {
     case 1: LN_BWD(1); break;
     case 2: LN_BWD(2); break;
@@ -243,7 +250,7 @@ int tad_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float*
 #undef LN_BWD
   int rc = check_launch("layernorm_bwd");
   if (rc) return rc;
-  rc = launch_reduce_cols(partial, dgamma, dbeta, colsum_dx, colsum_dx ? 3 : 2, blocks, D, 0, st);
+  rc = launch_reduce_cols(partial, dgamma, dbeta, colsum_dx, colsum_dx ? 3 : 2, blocks, D, accumulate ? 1 : 0, st);
   return rc;
 }
 

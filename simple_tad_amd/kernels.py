@@ -222,8 +222,11 @@ def layernorm_fwd(x, gamma, beta, eps: float, out_dtype=torch.bfloat16, save_sta
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, want_bf16=False, want_colsum=False):
-    """returns dx f32, dx_bf16|None, dgamma, dbeta, colsum_dx|None"""
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, want_bf16=False, want_colsum=False, rowscale=None, rows_per_scale=1,
+                  into=None):
+    """returns dx f32, dx_bf16|None, dgamma, dbeta, colsum_dx|None.  rowscale [rows/rows_per_scale]: per-sample scale applied to the
+    bf16 copy and the column sums (drop-path).  into=(dgamma, dbeta, colsum|None): accumulate the three reductions into these
+    existing f32 tensors (gradient sinks) instead of returning fresh ones."""
     _req(x, torch.float32, "layernorm_bwd.x")
     if dy.dtype not in (torch.float32, torch.bfloat16) or not dy.is_contiguous():
         raise _lib.TadError("layernorm_bwd.dy: must be contiguous f32 or bf16")
@@ -233,16 +236,27 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, want_bf16=False, want_col
         _req(dres, torch.float32, "layernorm_bwd.dres")
     dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
     dxb = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if want_bf16 else None
-    dg = torch.empty(D, dtype=torch.float32, device=x.device)
-    db = torch.empty(D, dtype=torch.float32, device=x.device)
-    cs = torch.empty(D, dtype=torch.float32, device=x.device) if want_colsum else None
+    if into is not None:
+        dg, db, cs = into
+        for t in (dg, db) + ((cs,) if want_colsum else ()):
+            _req(t, torch.float32, "layernorm_bwd.into")
+            assert t.numel() == D
+        if not want_colsum:
+            cs = None
+    else:
+        dg = torch.empty(D, dtype=torch.float32, device=x.device)
+        db = torch.empty(D, dtype=torch.float32, device=x.device)
+        cs = torch.empty(D, dtype=torch.float32, device=x.device) if want_colsum else None
+    if rowscale is not None:
+        _req(rowscale, torch.float32, "layernorm_bwd.rowscale")
+        assert rowscale.numel() * rows_per_scale >= rows
     lib = _lib.load()
     nbytes = lib.tad_layernorm_bwd_workspace_bytes(rows, D)
     ws = workspace(nbytes, x.device)
     with _timed("layernorm_bwd", 0.0, rows * D * (dy.element_size() + 4.0 + 4.0 + (4.0 if dres is not None else 0.0) + (2.0 if want_bf16 else 0.0))):
         check(lib.tad_layernorm_bwd(dy.data_ptr(), _dt(dy), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(dres),
-                                    dx.data_ptr(), _p(dxb), dg.data_ptr(), db.data_ptr(), _p(cs), ws.data_ptr(), ws.numel(), rows, D,
-                                    _stream()), "tad_layernorm_bwd")
+                                    dx.data_ptr(), _p(dxb), dg.data_ptr(), db.data_ptr(), _p(cs), _p(rowscale), int(rows_per_scale),
+                                    int(into is not None), ws.data_ptr(), ws.numel(), rows, D, _stream()), "tad_layernorm_bwd")
     return dx, dxb, dg, db, cs
 
 

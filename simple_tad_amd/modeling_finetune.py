@@ -49,6 +49,7 @@ class DropPath(nn.Module):
         super().__init__()
         self.drop_prob = drop_prob
         self.forced_mask = None
+        self.presampled = None  # scales drawn for the whole encoder in one launch (VisionTransformer._presample_drop_path)
 
     def sample(self, batch, device):
         if not self.training or not self.drop_prob:
@@ -56,6 +57,8 @@ class DropPath(nn.Module):
         keep = 1.0 - self.drop_prob
         if self.forced_mask is not None:
             mask = self.forced_mask.to(device=device, dtype=torch.float32)
+        elif self.presampled:
+            return self.presampled.pop(0)
         else:
             mask = (keep + torch.rand(batch, device=device, dtype=torch.float32)).floor_()
         return mask / keep
@@ -333,6 +336,7 @@ class VisionTransformer(nn.Module):
             for blk in self.blocks:
                 x = checkpoint.checkpoint(blk, x, use_reentrant=False)
         else:
+            self._presample_drop_path(x.shape[0], x.device)
             for blk in self.blocks:
                 x = blk(x)
         x = self._ln(self.norm, x)
@@ -342,6 +346,20 @@ class VisionTransformer(nn.Module):
             return x[:, 0]
         else:
             return x
+
+    def _presample_drop_path(self, batch, device):
+        """All stochastic-depth scales of one forward (two residual branches per block) from ONE torch.rand launch instead of
+        ~8 tiny launches per block.  Same distribution as DropPath.sample: floor(keep + U[0,1)) / keep per sample."""
+        if not self.training:
+            return
+        dps = [b.drop_path for b in self.blocks if isinstance(getattr(b, "drop_path", None), DropPath) and b.drop_path.drop_prob
+               and b.drop_path.forced_mask is None]
+        if not dps:
+            return
+        keep = torch.tensor([1.0 - d.drop_prob for d in dps], dtype=torch.float32, device=device).repeat_interleave(2).unsqueeze(1)
+        scales = (keep + torch.rand(2 * len(dps), batch, device=device, dtype=torch.float32)).floor_() / keep
+        for i, d in enumerate(dps):
+            d.presampled = [scales[2 * i], scales[2 * i + 1]]
 
     def forward(self, x):
         x = self.forward_features(x)

@@ -108,6 +108,20 @@ def linear_dw(dy, x, w, b=None, loose_bias=False):
     return K.linear_bwd_weight(dy, x, want_bias=(b is not None or loose_bias))
 
 
+def layernorm_bwd_sunk(dy, x, gamma, mean, rstd, w, b, colsum_param=None, **kw):
+    """K.layernorm_bwd whose reductions (dgamma, dbeta and, with ``colsum_param``, the column sums = that bias's gradient) go into
+    the parameters' gradient sinks when all of them have one.  Returns (dx, dx_bf16, dgamma|None, dbeta|None, colsum|None)."""
+    ents = [_sink(w), _sink(b)] + ([_sink(colsum_param)] if colsum_param is not None else [])
+    if all(e is not None for e in ents):
+        dx, dxb, _, _, _ = K.layernorm_bwd(dy, x, gamma, mean, rstd, want_colsum=colsum_param is not None,
+                                           into=(ents[0][1], ents[1][1], ents[2][1] if colsum_param is not None else None), **kw)
+        for ent, prm in zip(ents, (w, b, colsum_param)):
+            if ent[2] is not None:
+                ent[2](prm)
+        return dx, dxb, None, None, None
+    return K.layernorm_bwd(dy, x, gamma, mean, rstd, want_colsum=colsum_param is not None, **kw)
+
+
 def _cached(p: torch.Tensor, kind: str, fresh: bool = False):
     pid = id(p)
     if kind in ("n", "t"):
@@ -374,6 +388,7 @@ class BlockFn(torch.autograd.Function):
                                   dp1 if dp1 is None else _f32c(dp1), dp2 if dp2 is None else _f32c(dp2))
         ctx.meta = (B, N, D, H, scale, q_bias is not None)
         ctx.biases = (proj_b, fc1_b, fc2_b)
+        ctx.norms = (n1w, n1b, n2w, n2b)
         return x2.reshape(B, N, D)
 
     @staticmethod
@@ -390,21 +405,16 @@ class BlockFn(torch.autograd.Function):
         dW2, db2 = linear_dw(gb, a, fc2_w, fc2_b)
         dxn2 = K.linear_bwd_input(dh, wT_bf16(fc1_w, True))
         dW1, db1 = linear_dw(dh, xn2, fc1_w, fc1_b)
-        gmid, gmid_b, dg2, dbeta2, cs = K.layernorm_bwd(dxn2, x1, g2, mean2, rstd2, dres=g, want_bf16=(dp1 is None),
-                                                       want_colsum=(dp1 is None))
+        # LN2 backward also emits what the attention branch needs: bf16(drop-path scale * residual-stream grad) and its column
+        # sums (= proj bias gradient), so neither a cast pass nor a bias reduction in the dW GEMM is needed
+        n1w, n1b, n2w, n2b = ctx.norms
+        gmid, gpb, dg2, dbeta2, dbp = layernorm_bwd_sunk(dxn2, x1, g2, mean2, rstd2, n2w, n2b, colsum_param=proj_b, dres=g, want_bf16=True,
+                                                        rowscale=dp1, rows_per_scale=N)
         # ---- attention branch
-        if dp1 is None:
-            gpb, dbp = gmid_b, cs  # proj bias grad = column sums of the residual-stream grad
-        else:
-            gpb = K.scale_cast_bf16(gmid, None, dp1, N)
-            dbp = None
         d_ao = K.linear_bwd_input(gpb, wT_bf16(proj_w, True))
-        if dbp is None:
-            dWp, dbp = linear_dw(gpb, ao, proj_w, proj_b)
-        else:
-            dWp, _ = linear_dw(gpb, ao, proj_w)
+        dWp, _ = linear_dw(gpb, ao, proj_w)
         dxn1, dWqkv, dqb, dvb = _attn_bwd_core(d_ao, xn1, qkv, ao, lse, qkv_w, has_qb, B, N, H, scale, torch.bfloat16)
-        gin, _, dg1, dbeta1, _ = K.layernorm_bwd(dxn1, x0, g1, mean1, rstd1, dres=gmid)
+        gin, _, dg1, dbeta1, _ = layernorm_bwd_sunk(dxn1, x0, g1, mean1, rstd1, n1w, n1b, dres=gmid)
         return (gin.reshape(B, N, D), dg1, dbeta1, dWqkv, dqb, dvb, dWp, dbp, dg2, dbeta2, dW1, db1, dW2, db2, None, None, None, None,
                 None)
 
