@@ -93,13 +93,15 @@ __global__ void attn_delta_kernel(const uint16_t* __restrict__ o, const uint16_t
 // ------------------------------------------------------------------------------------------------ dQ
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
-                                                          uint16_t* __restrict__ dqkv, int N, int H, float scale) {
+                                                          uint16_t* __restrict__ dqkv, int N, int H, int B, float scale) {
   constexpr int TILE_BYTES = 64 * 128;
   __shared__ __attribute__((aligned(1024))) char lds[2 * 2 * TILE_BYTES];  // [buf][K|V]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int head = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int nblk = (N + 127) / 128;  // 1-D XCD-aware grid: the blocks of one (batch, head) pair share an L2 (see attn_fwd.hip)
+  const int lin = xcd_remap(blockIdx.x, gridDim.x);
+  const int head = (lin / nblk) % H, b = lin / nblk / H;
+  const int q0 = (lin % nblk) * 128 + wave * 32;
   const int ql = lane & 31, h5 = lane >> 5;
   const int64_t tok = (int64_t)3 * H * BHD;
   const uint16_t* base = qkv + (int64_t)b * N * tok + head * BHD;
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
 
   // K/V tiles go global -> LDS by LDS-DMA (see attn_fwd.hip): 1-KiB piece = 8 keys x 128 B, wave w moves pieces w and w+4 of K and
   // of V; the swizzle is applied to the per-lane SOURCE chunk.  Reads past the tensor return zero; keys >= N are masked below.
-  const uint32_t qkv_bytes = (uint32_t)gridDim.z * (uint32_t)N * (uint32_t)tok * 2u;
+  const uint32_t qkv_bytes = (uint32_t)B * (uint32_t)N * (uint32_t)tok * 2u;
   const auto rs_qkv = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(qkv), 0, (int)qkv_bytes, 0x00020000);
   uint32_t dma_k[2];
 #pragma unroll
@@ -211,14 +213,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
 // ------------------------------------------------------------------------------------------------ dK, dV
 __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
-                                                           uint16_t* __restrict__ dqkv, int N, int H, float scale) {
+                                                           uint16_t* __restrict__ dqkv, int N, int H, int B, float scale) {
   constexpr int TILE_BYTES = 64 * 128;
   constexpr int STAGE = 2 * TILE_BYTES + 512;  // Q tile, dO tile, 64 x (-lse/c), 64 x (-delta)
   __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int head = blockIdx.y, b = blockIdx.z;
-  const int key0 = blockIdx.x * 128 + wave * 32;
+  const int nblk = (N + 127) / 128;  // 1-D XCD-aware grid (see attn_fwd.hip)
+  const int lin = xcd_remap(blockIdx.x, gridDim.x);
+  const int head = (lin / nblk) % H, b = lin / nblk / H;
+  const int key0 = (lin % nblk) * 128 + wave * 32;
   const int kl_ = lane & 31, h5 = lane >> 5;
   const int64_t tok = (int64_t)3 * H * BHD;
   const uint16_t* base = qkv + (int64_t)b * N * tok + head * BHD;
@@ -242,8 +246,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const uint16_t* __
 
   // Q / dO tiles go global -> LDS by LDS-DMA (1-KiB piece = 8 rows x 128 B, wave w moves pieces w and w+4 of each; swizzle on the
   // per-lane SOURCE chunk); rows past the tensor read as zero, rows >= N are neutralised through the row constants below.
-  const uint32_t qkv_bytes = (uint32_t)gridDim.z * (uint32_t)N * (uint32_t)tok * 2u;
-  const uint32_t do_bytes = (uint32_t)gridDim.z * (uint32_t)N * (uint32_t)(H * BHD) * 2u;
+  const uint32_t qkv_bytes = (uint32_t)B * (uint32_t)N * (uint32_t)tok * 2u;
+  const uint32_t do_bytes = (uint32_t)B * (uint32_t)N * (uint32_t)(H * BHD) * 2u;
   const auto rs_qkv = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(qkv), 0, (int)qkv_bytes, 0x00020000);
   const auto rs_do = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(dout), 0, (int)do_bytes, 0x00020000);
   uint32_t dma_q[2], dma_do[2];
@@ -363,10 +367,10 @@ extern "C" int tad_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows * 8 + 255) / 256)), dim3(256), 0, st, out, dout, delta, B, N, H);
   int rc = check_launch("attn_delta");
   if (rc) return rc;
-  const dim3 grid((N + 127) / 128, H, B), block(256);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, block, 0, st, qkv, dout, lse, delta, dqkv, N, H, scale);
+  const dim3 grid((unsigned)(((N + 127) / 128) * H * B)), block(256);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, block, 0, st, qkv, dout, lse, delta, dqkv, N, H, B, scale);
   rc = check_launch("attn_bwd_dq");
   if (rc) return rc;
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, block, 0, st, qkv, dout, lse, delta, dqkv, N, H, scale);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, block, 0, st, qkv, dout, lse, delta, dqkv, N, H, B, scale);
   return check_launch("attn_bwd_dkv");
 }

@@ -37,13 +37,19 @@ typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 
 template <bool OUT_BF16>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, void* __restrict__ out,
-                                                       float* __restrict__ lse, int N, int H, float scale) {
+                                                       float* __restrict__ lse, int N, int H, int B, float scale) {
   __shared__ __attribute__((aligned(1024))) char lds[2 * 2 * KV_TILE * HD * 2];  // [buf][K|V][64 keys][128 B]
   constexpr int TILE_BYTES = KV_TILE * HD * 2;                                  // 8 KiB
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int head = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * Q_BLOCK + wave * Q_WAVE;
+  // 1-D grid, XCD-aware: the query blocks of one (batch, head) pair re-read the same K/V (400 KB); dealt round-robin over the
+  // 8 XCDs every L2 fetched them again (rocprofv3 FETCH_SIZE: 5.9x the algorithmic bytes), so consecutive logical ids -- the
+  // blocks of one pair -- are kept on one XCD
+  const int nblk = (N + Q_BLOCK - 1) / Q_BLOCK;
+  const int lin = xcd_remap(blockIdx.x, gridDim.x);
+  const int qblk = lin % nblk, pair = lin / nblk;
+  const int head = pair % H, b = pair / H;
+  const int q0 = qblk * Q_BLOCK + wave * Q_WAVE;
   const int ql = lane & 31, h5 = lane >> 5;
   const int64_t tok_stride = (int64_t)3 * H * HD;  // elements per token
   const uint16_t* base = qkv + (int64_t)b * N * tok_stride + head * HD;
@@ -64,7 +70,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
   // staging: K/V tiles go global -> LDS by LDS-DMA (no staging registers, no ds_write): a 1-KiB piece = 8 keys x 128 B; wave w
   // moves pieces w and w+4 of K and of V.  The LDS destination is lane-linear, so the swizzle is applied to the per-lane
   // SOURCE chunk.  Keys past the end of the tensor read as zero (buffer bounds check); keys >= N of this sequence are masked.
-  const uint32_t qkv_bytes = (uint32_t)gridDim.z * (uint32_t)N * (uint32_t)tok_stride * 2u;
+  const uint32_t qkv_bytes = (uint32_t)B * (uint32_t)N * (uint32_t)tok_stride * 2u;
   const auto rs_qkv = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(qkv), 0, (int)qkv_bytes, 0x00020000);
   const int dkey = lane >> 3, dch = lane & 7;
   uint32_t dma_k[2], dma_v[2];
@@ -217,10 +223,10 @@ extern "C" int tad_attn_fwd(const uint16_t* qkv, void* out, int out_dtype, float
   TAD_REQUIRE(B > 0 && N > 0 && H > 0 && H <= 65535 && B <= 65535, "attn_fwd: bad shape B=%d N=%d H=%d", B, N, H);
   TAD_REQUIRE(out_dtype == TAD_F32 || out_dtype == TAD_BF16, "attn_fwd: bad out_dtype %d", out_dtype);
   TAD_REQUIRE(scale > 0.f, "attn_fwd: scale must be positive");
-  const dim3 grid((N + Q_BLOCK - 1) / Q_BLOCK, H, B), block(256);
+  const dim3 grid((unsigned)(((N + Q_BLOCK - 1) / Q_BLOCK) * H * B)), block(256);
   if (out_dtype == TAD_BF16)
-    hipLaunchKernelGGL((attn_fwd_kernel<true>), grid, block, 0, (hipStream_t)stream, qkv, out, lse, N, H, scale);
+    hipLaunchKernelGGL((attn_fwd_kernel<true>), grid, block, 0, (hipStream_t)stream, qkv, out, lse, N, H, B, scale);
   else
-    hipLaunchKernelGGL((attn_fwd_kernel<false>), grid, block, 0, (hipStream_t)stream, qkv, out, lse, N, H, scale);
+    hipLaunchKernelGGL((attn_fwd_kernel<false>), grid, block, 0, (hipStream_t)stream, qkv, out, lse, N, H, B, scale);
   return check_launch("attn_fwd");
 }

@@ -29,21 +29,52 @@ def main():
     ap.add_argument("--fetch")
     ap.add_argument("--write")
     ap.add_argument("--steps", type=int, default=13, help="steps+warmup of the kernel-trace run")
+    ap.add_argument("--warmup", type=int, default=3, help="warm-up steps of the kernel-trace run")
     ap.add_argument("--pmc-steps", type=int, default=3)
     ap.add_argument("--out", default="profiles")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     summary = {"round": a.round}
     if a.kt:
-        f = glob.glob(os.path.join(a.kt, "*", "*kernel_stats.csv"))[0]
+        # Per-dispatch begin/end from the kernel trace (the --stats table of the same run is kept for reference: it is built from
+        # the same dispatches, but one first-use dispatch can carry a multi-millisecond outlier there -- see profiles/README.md).
+        tf = glob.glob(os.path.join(a.kt, "*", "*kernel_trace.csv"))
         agg = collections.OrderedDict()
         total = 0.0
-        for r in csv.DictReader(open(f)):
-            k = short(r["Name"])
-            d = agg.setdefault(k, {"calls": 0, "total_ns": 0.0})
-            d["calls"] += int(r["Calls"])
-            d["total_ns"] += float(r["TotalDurationNs"])
-            total += float(r["TotalDurationNs"])
+        if tf:
+            nt = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+                        for r in csv.DictReader(open(tf[0])) if short(r["Kernel_Name"]) == "tad::gemm_nt_kernel")
+            if nt:  # the timed steps only (what bench.py's live HIP-event figure covers): drop the warm-up steps' launches
+                skip = len(nt) * a.warmup // a.steps
+                timed = [d for _, d in nt[skip:]]
+                summary["gemm_nt_timed_steps"] = {"calls": len(timed), "avg_launch_us": sum(timed) / len(timed) / 1e3,
+                                                  "ms_per_step": sum(timed) / 1e6 / (a.steps - a.warmup)}
+            for r in csv.DictReader(open(tf[0])):
+                k = short(r["Kernel_Name"])
+                d = agg.setdefault(k, {"calls": 0, "total_ns": 0.0})
+                d["calls"] += 1
+                d["total_ns"] += float(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+                total += float(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        else:
+            f = glob.glob(os.path.join(a.kt, "*", "*kernel_stats.csv"))[0]
+            for r in csv.DictReader(open(f)):
+                k = short(r["Name"])
+                d = agg.setdefault(k, {"calls": 0, "total_ns": 0.0})
+                d["calls"] += int(r["Calls"])
+                d["total_ns"] += float(r["TotalDurationNs"])
+                total += float(r["TotalDurationNs"])
+        sf = glob.glob(os.path.join(a.kt, "*", "*kernel_stats.csv"))
+        if sf:
+            st = {"calls": 0, "total_ns": 0.0, "max_ns": 0.0}
+            for r in csv.DictReader(open(sf[0])):
+                if short(r["Name"]) == "tad::gemm_nt_kernel":
+                    st["calls"] += int(r["Calls"])
+                    st["total_ns"] += float(r["TotalDurationNs"])
+                    st["max_ns"] = max(st["max_ns"], float(r["MaxNs"]))
+            if st["calls"]:
+                summary["gemm_nt_stats_table"] = {"calls": st["calls"], "avg_launch_us": st["total_ns"] / st["calls"] / 1e3,
+                                                  "max_launch_us": st["max_ns"] / 1e3,
+                                                  "avg_launch_us_without_max": (st["total_ns"] - st["max_ns"]) / (st["calls"] - 1) / 1e3}
         rows = sorted(agg.items(), key=lambda kv: -kv[1]["total_ns"])
         lines = [f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline   ({a.steps} steps incl. warm-up)",
                  f"# total kernel time {total / 1e6:.1f} ms = {total / 1e6 / a.steps:.2f} ms/step",
