@@ -71,6 +71,16 @@ int tad_im2col_tubelets(const float* x, uint16_t* cols, int B, int C, int T, int
 int tad_patch_embed_fwd(const float* x, const uint16_t* w_bf16, const float* bias, const float* pos,
                         float* out, uint16_t* cols, int B, int C, int T, int H, int W, int tubelet,
                         int patch, int D, tad_stream_t stream);
+/* Input stage: the same patch matrix straight from uint8 frames [B,T,H,W,3] (decoder / cv2 layout) with the
+ * reference's normalisation v = (u8/255 - mean[c]) / std[c] in f32 (run_inference.py:15-34 prepare_image; dota.py:443-460
+ * tensor_normalize) -- bit-identical to tad_im2col_tubelets on the normalised f32 clip.  mean3 / std3: HOST arrays in RGB order;
+ * bgr != 0: channel c is stored at position 2-c (cv2 frames, replaces cv2.cvtColor(BGR2RGB)); t_offset: frame t of the clip is
+ * slot (t + t_offset) % T of the buffer (ring buffer for the sliding window of run_inference.py:86-93). */
+int tad_im2col_tubelets_u8(const uint8_t* frames, uint16_t* cols, int B, int T, int H, int W, int tubelet, int patch,
+                           const float* mean3, const float* std3, int bgr, int t_offset, tad_stream_t stream);
+/* GEMM part of tad_patch_embed_fwd on an existing patch matrix: out = cols * w^T + bias (+ pos broadcast over the batch) */
+int tad_patch_embed_gemm(const uint16_t* cols, const uint16_t* w_bf16, const float* bias, const float* pos, float* out,
+                         int64_t M, int ntok, int D, int K, tad_stream_t stream);
 /* dW [D,K] f32 (overwritten), db [D] f32 (overwritten, nullable) from dy [B*N,D] bf16 and cols. */
 size_t tad_patch_embed_bwd_workspace_bytes(int64_t M, int D, int K);
 int tad_patch_embed_bwd(const uint16_t* dy_bf16, const uint16_t* cols, float* dW, float* db, void* ws,

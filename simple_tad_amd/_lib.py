@@ -21,6 +21,8 @@ SIGNATURES = {
     "tad_transpose_cast_f32_bf16": (_i, [_vp, _vp, _i, _i, _vp]),
     "tad_im2col_tubelets": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "tad_patch_embed_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "tad_im2col_tubelets_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, C.POINTER(_f), C.POINTER(_f), _i, _i, _vp]),
+    "tad_patch_embed_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
     "tad_patch_embed_bwd_workspace_bytes": (_sz, [_i64, _i, _i]),
     "tad_patch_embed_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i64, _i, _i, _vp]),
     "tad_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i64, _i, _f, _vp]),

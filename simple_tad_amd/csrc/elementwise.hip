@@ -85,6 +85,55 @@ __global__ __launch_bounds__(256) void transpose_bf16_batched_kernel(const uint1
   }
 }
 
+// ---------------------------------------------------------------- input stage: uint8 frames -> normalised bf16 patch matrix
+// frames [B,T,H,W,3] uint8 (decoder / cv2 layout) -> cols [B*N, 3*tub*p*p] bf16 with the reference's arithmetic
+//   v = (float(u8) / 255 - mean[c]) / std[c]      (run_inference.py:22-32 prepare_image; dota.py:443-460 tensor_normalize)
+// in f32 with IEEE divisions, then the same RNE cast to bf16 as the f32 path -- so the patch matrix is bit-identical to
+// im2col_tubelets(normalise(frames)) while reading 4x fewer bytes and skipping the f32 clip entirely.  ``bgr``: the channel in
+// memory is 2 - c (cv2 frames; the reference converts with cv2.cvtColor(BGR2RGB)).  ``t_offset``: frame t of the clip lives in
+// slot (t + t_offset) % T of the buffer (sliding-window ring buffer of run_inference.py:86-93 without shifting the frames).
+// One thread: 8 consecutive pixels of one row = 24 contiguous bytes in, three 16-byte chunks out (one per channel).
+__global__ void im2col_tubelets_u8_kernel(const uint8_t* __restrict__ frames, uint16_t* __restrict__ cols, int B, int T, int H, int W,
+                                          int tub, int p, float m0, float m1, float m2, float s0, float s1, float s2, int bgr,
+                                          int t_offset) {
+  const int W8 = W >> 3;
+  const int64_t total = (int64_t)B * T * H * W8;
+  const int Hp = H / p, Wp = W / p, Tp = T / tub;
+  const int K = 3 * tub * p * p;
+  const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    int64_t r = i;
+    const int w8 = (int)(r % W8); r /= W8;
+    const int h = (int)(r % H); r /= H;
+    const int t = (int)(r % T); r /= T;  // frame index inside the clip
+    const int b = (int)r;
+    int slot = t + t_offset;
+    slot = slot >= T ? slot - T : slot;
+    const uint8_t* src = frames + ((((int64_t)b * T + slot) * H + h) * W + (int64_t)w8 * 8) * 3;
+    uint32_t raw[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) raw[q] = reinterpret_cast<const uint32_t*>(src)[q];  // (W*3*8) % 4 == 0: 4-byte aligned
+    const int w = w8 * 8;
+    const int tp = t / tub, kt = t - tp * tub, hp = h / p, kh = h - hp * p, wp = w / p, kw = w - wp * p;
+    const int64_t n = ((int64_t)b * Tp + tp) * Hp * Wp + (int64_t)hp * Wp + wp;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int cm = bgr ? 2 - c : c;  // channel position in memory
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int byte = e * 3 + cm;
+        const float u = (float)((raw[byte >> 2] >> ((byte & 3) * 8)) & 0xffu);
+        v[e] = (u / 255.0f - mean[c]) / sd[c];
+      }
+      const int k = ((c * tub + kt) * p + kh) * p + kw;
+      *reinterpret_cast<uint4*>(cols + n * K + k) =
+          make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+    }
+  }
+}
+
 // ---------------------------------------------------------------- tubelet im2col
 // x [B,C,T,H,W] f32 -> cols [B*N, K] bf16, token n = (t'*H' + h')*W' + w', k = ((c*tub+kt)*p+kh)*p+kw.
 // One thread moves 8 consecutive w (32 B in, 16 B out); threads walk x in memory order -> coalesced reads.
@@ -356,6 +405,21 @@ int tad_im2col_tubelets(const float* x, uint16_t* cols, int B, int C, int T, int
   hipLaunchKernelGGL(im2col_tubelets_kernel, dim3(capped_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, cols, B, C, T,
                      H, W, tubelet, patch);
   return check_launch("im2col_tubelets");
+}
+
+int tad_im2col_tubelets_u8(const uint8_t* frames, uint16_t* cols, int B, int T, int H, int W, int tubelet, int patch, const float* mean3,
+                           const float* std3, int bgr, int t_offset, tad_stream_t stream) {
+  TAD_REQUIRE(frames && cols && mean3 && std3, "im2col_u8: null pointer");
+  TAD_REQUIRE(B > 0 && tubelet > 0 && patch > 0 && T % tubelet == 0 && H % patch == 0 && W % patch == 0,
+              "im2col_u8: T/H/W must be multiples of tubelet/patch (got T=%d H=%d W=%d tub=%d p=%d)", T, H, W, tubelet, patch);
+  TAD_REQUIRE(patch % 8 == 0, "im2col_u8: patch size must be a multiple of 8 (got %d)", patch);
+  TAD_REQUIRE(t_offset >= 0 && t_offset < T, "im2col_u8: t_offset=%d outside [0, %d)", t_offset, T);
+  TAD_REQUIRE(std3[0] != 0.f && std3[1] != 0.f && std3[2] != 0.f, "im2col_u8: zero std");
+  TAD_REQUIRE((((uintptr_t)frames) & 3) == 0 && (((uintptr_t)cols) & 15) == 0, "im2col_u8: misaligned buffers");
+  const int64_t total = (int64_t)B * T * H * (W / 8);
+  hipLaunchKernelGGL(im2col_tubelets_u8_kernel, dim3(capped_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, frames, cols, B, T, H,
+                     W, tubelet, patch, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], bgr ? 1 : 0, t_offset);
+  return check_launch("im2col_tubelets_u8");
 }
 
 int tad_meanpool_fwd(const float* x, float* y, float* ws, int B, int N, int D, tad_stream_t stream) {

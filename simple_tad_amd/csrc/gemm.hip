@@ -709,6 +709,21 @@ int tad_patch_embed_fwd(const float* x, const uint16_t* w_bf16, const float* bia
   return launch_gemm_nt(p, (hipStream_t)stream);
 }
 
+int tad_patch_embed_gemm(const uint16_t* cols, const uint16_t* w_bf16, const float* bias, const float* pos, float* out, int64_t M, int ntok,
+                         int D, int K, tad_stream_t stream) {
+  TAD_REQUIRE(cols && w_bf16 && out, "patch_embed_gemm: null pointer");
+  TAD_REQUIRE(M > 0 && M < (1ll << 31) && ntok > 0 && M % ntok == 0, "patch_embed_gemm: M=%lld must be a positive multiple of ntok=%d",
+              (long long)M, ntok);
+  GemmNT p{};
+  p.A = cols; p.B = w_bf16; p.C = out; p.bias = bias; p.c_bf16 = 0;
+  p.M = (int)M; p.N = D; p.K = K;
+  p.rows_per_scale = 1;
+  p.epi = EPI_RESIDUAL;
+  p.residual = pos;
+  p.res_mod = ntok;
+  return launch_gemm_nt(p, (hipStream_t)stream);
+}
+
 size_t tad_patch_embed_bwd_workspace_bytes(int64_t M, int D, int K) { return tad_linear_bwd_weight_workspace_bytes(M, D, K); }
 
 int tad_patch_embed_bwd(const uint16_t* dy_bf16, const uint16_t* cols, float* dW, float* db, void* ws, size_t ws_bytes, int64_t M, int D,

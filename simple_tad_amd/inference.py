@@ -1,0 +1,75 @@
+"""Frame-by-frame inference with a GPU-resident sliding window.
+
+Counterpart of run_inference.py:70-101.  The reference keeps a float32 [1,3,16,224,224] window on the GPU, and for every new frame
+normalises it on the CPU (prepare_image, :15-34), uploads 600 KB of f32, drops the oldest frame and ``torch.cat``s the window
+again (a 9.6 MB copy) before running the model.  Here the window is a uint8 ring buffer [1,T,H,W,3] in HBM: a new frame is ONE
+150 KB upload into the oldest slot, nothing is shifted, and the patch-embed kernel reads the ring in temporal order while applying
+the normalisation (``PatchEmbed.t_offset`` -> tad_im2col_tubelets_u8).  Results are identical to running the model on the
+reference's window: same arithmetic, same frame order.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from ._lib import TadError
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+class SlidingWindow:
+    def __init__(self, model: torch.nn.Module, mean=IMAGENET_MEAN, std=IMAGENET_STD, bgr: bool = True, device: Optional[torch.device] = None):
+        pe = model.patch_embed
+        self.model = model
+        self.T = int(model.num_frames)
+        self.H, self.W = int(pe.img_size[0]), int(pe.img_size[1])
+        self.device = device or next(model.parameters()).device
+        if self.device.type != "cuda":
+            raise TadError("SlidingWindow keeps its frames in HBM: the model must be on a GPU (no CPU path)")
+        pe.set_input_normalization(mean, std, bgr=bgr)
+        self.ring = torch.zeros((1, self.T, self.H, self.W, 3), dtype=torch.uint8, device=self.device)
+        self.count = 0   # frames pushed so far
+        self.start = 0   # ring slot of the oldest frame
+
+    @property
+    def full(self) -> bool:
+        return self.count >= self.T
+
+    def push(self, frame) -> None:
+        """frame: uint8 [H,W,3] (numpy from cv2.imread + cv2.resize, or a tensor), already resized to the model's input size"""
+        f = torch.from_numpy(np.ascontiguousarray(frame)) if isinstance(frame, np.ndarray) else frame
+        if f.dtype != torch.uint8 or tuple(f.shape) != (self.H, self.W, 3):
+            raise TypeError(f"Input must be a uint8 image of shape {(self.H, self.W, 3)}, but got {f.dtype} {tuple(f.shape)}")
+        if self.count < self.T:
+            slot = self.count
+        else:  # overwrite the oldest frame; the window now starts one slot later
+            slot = self.start
+            self.start = (self.start + 1) % self.T
+        self.ring[0, slot].copy_(f, non_blocking=True)
+        self.count += 1
+
+    @torch.no_grad()
+    def predict(self) -> torch.Tensor:
+        """raw logits [1, num_classes] for the current window (the model applies no softmax, run_inference.py:95-100)"""
+        if not self.full:
+            raise TadError(f"We need at least {self.T} frames! (have {self.count})")
+        self.model.eval()
+        self.model.patch_embed.t_offset = self.start
+        try:
+            return self.model(self.ring)
+        finally:
+            self.model.patch_embed.t_offset = 0
+
+    def window_f32(self) -> torch.Tensor:
+        """the reference's float window [1,3,T,H,W] rebuilt from the ring (debugging aid; torch arithmetic on the GPU, equal to the
+        reference's CPU values to 1 ulp -- the kernel path itself is bit-exact)"""
+        pe = self.model.patch_embed
+        order = [(self.start + t) % self.T for t in range(self.T)]
+        fr = self.ring[0, order].float()
+        if pe.input_bgr:
+            fr = fr.flip(-1)
+        fr = (fr / 255.0 - torch.tensor(pe.input_mean, device=fr.device)) / torch.tensor(pe.input_std, device=fr.device)
+        return fr.permute(3, 0, 1, 2).unsqueeze(0).contiguous()

@@ -183,6 +183,44 @@ def im2col_tubelets(x: torch.Tensor, tubelet: int, patch: int) -> torch.Tensor:
     return cols
 
 
+def im2col_tubelets_u8(frames: torch.Tensor, tubelet: int, patch: int, mean, std, bgr: bool = False, t_offset: int = 0) -> torch.Tensor:
+    """frames [B,T,H,W,3] uint8 -> normalised bf16 patch matrix [B*N, 3*tub*p*p] (tad_im2col_tubelets_u8)"""
+    import ctypes as C
+    _req(frames, torch.uint8, "im2col_u8.frames")
+    if frames.dim() != 5 or frames.shape[-1] != 3:
+        raise _lib.TadError(f"im2col_u8: frames must be [B,T,H,W,3] uint8, got {tuple(frames.shape)}")
+    B, T, H, W, _ = frames.shape
+    ntok = (T // tubelet) * (H // patch) * (W // patch)
+    cols = torch.empty((B * ntok, 3 * tubelet * patch * patch), dtype=torch.bfloat16, device=frames.device)
+    m = (C.c_float * 3)(*[float(v) for v in mean])
+    s = (C.c_float * 3)(*[float(v) for v in std])
+    with _timed("im2col_u8", 0.0, float(frames.numel()) + 2.0 * cols.numel()):
+        check(_lib.load().tad_im2col_tubelets_u8(frames.data_ptr(), cols.data_ptr(), B, T, H, W, tubelet, patch, m, s, int(bool(bgr)),
+                                                 int(t_offset), _stream()), "tad_im2col_tubelets_u8")
+    return cols
+
+
+def patch_embed_gemm(cols, w_bf16, bias, pos, ntok: int):
+    """cols [B*ntok, K] bf16 -> out [B, ntok, D] f32 = cols w^T + bias (+ pos [ntok, D] broadcast over the batch)"""
+    _req(cols, torch.bfloat16, "patch_embed_gemm.cols")
+    _req(w_bf16, torch.bfloat16, "patch_embed_gemm.w")
+    M, Kd = cols.shape
+    D, K2 = w_bf16.shape
+    if Kd != K2 or M % ntok:
+        raise _lib.TadError(f"patch_embed_gemm: cols {tuple(cols.shape)} vs weight {tuple(w_bf16.shape)}, ntok {ntok}")
+    if pos is not None:
+        _req(pos, torch.float32, "patch_embed_gemm.pos")
+        if tuple(pos.shape) != (ntok, D):
+            raise _lib.TadError(f"patch_embed_gemm: pos_embed shape {tuple(pos.shape)} != {(ntok, D)}")
+    if bias is not None:
+        _req(bias, torch.float32, "patch_embed_gemm.bias")
+    out = torch.empty((M // ntok, ntok, D), dtype=torch.float32, device=cols.device)
+    with _timed("patch_embed_fwd", 2.0 * M * D * Kd, 2.0 * M * Kd + 4.0 * M * D):
+        check(_lib.load().tad_patch_embed_gemm(cols.data_ptr(), w_bf16.data_ptr(), _p(bias), _p(pos), out.data_ptr(), M, ntok, D, Kd,
+                                               _stream()), "tad_patch_embed_gemm")
+    return out
+
+
 def patch_embed_fwd(x, w_bf16, bias, pos, tubelet: int, patch: int):
     """x [B,C,T,H,W] f32, w_bf16 [D,K], bias [D] f32|None, pos [N,D] f32|None -> (out [B,N,D] f32, cols [B*N,K] bf16)"""
     _req(x, torch.float32, "patch_embed.x")

@@ -219,7 +219,28 @@ class PatchEmbed(nn.Module):
                               kernel_size=(self.tubelet_size, patch_size[0], patch_size[1]),
                               stride=(self.tubelet_size, patch_size[0], patch_size[1]))
 
+    # ---- input stage: uint8 frames straight into the patch matrix
+    input_mean = (0.485, 0.456, 0.406)  # ImageNet statistics, the values every reference entry point passes
+    input_std = (0.229, 0.224, 0.225)   # (run_inference.py:60-61, 76; dota.py:312-314)
+    input_bgr = False                   # True: frames come from cv2 (BGR), as in run_inference.py:21
+    t_offset = 0                        # ring-buffer start slot (inference.SlidingWindow)
+
+    def set_input_normalization(self, mean, std, bgr=False):
+        self.input_mean, self.input_std, self.input_bgr = tuple(float(v) for v in mean), tuple(float(v) for v in std), bool(bgr)
+
+    def _forward_u8(self, frames, pos_embed):
+        """frames [B,T,H,W,3] uint8 (decoder layout): normalisation of prepare_image / tensor_normalize fused into the im2col"""
+        B, T, H, W, C = frames.shape
+        assert C == 3 and H == self.img_size[0] and W == self.img_size[1], \
+            f"Input image size ({H}*{W}) doesn't match model ({self.img_size[0]}*{self.img_size[1]})."
+        if ops.get_precision() == "precise":
+            raise TadError('precision "precise" takes the normalised f32 clip (the uint8 input stage feeds the bf16 path)')
+        return ops.PatchEmbedU8Fn.apply(frames, self.proj.weight, self.proj.bias, pos_embed, self.tubelet_size, self.patch_size[0],
+                                        self.input_mean, self.input_std, self.input_bgr, int(self.t_offset))
+
     def forward(self, x, pos_embed=None, **kwargs):
+        if x.dtype == torch.uint8:
+            return self._forward_u8(x, pos_embed)
         B, C, T, H, W = x.shape
         assert H == self.img_size[0] and W == self.img_size[1], \
             f"Input image size ({H}*{W}) doesn't match model ({self.img_size[0]}*{self.img_size[1]})."

@@ -284,6 +284,30 @@ class PatchEmbedFn(torch.autograd.Function):
         return None, (None if dW is None else dW.reshape(weight.shape)), db, None, None, None
 
 
+class PatchEmbedU8Fn(torch.autograd.Function):
+    """PatchEmbed on uint8 frames [B,T,H,W,3]: normalisation (run_inference.py:15-34; dota.py:443-460) fused into the im2col."""
+
+    @staticmethod
+    def forward(ctx, frames, weight, bias, pos, tubelet, patch, mean, std, bgr, t_offset):
+        _need_gpu(frames, "PatchEmbed")
+        fr = frames if frames.is_contiguous() else frames.contiguous()
+        B, T, H, W, _ = fr.shape
+        cols = K.im2col_tubelets_u8(fr, tubelet, patch, mean, std, bgr, t_offset)
+        ntok = (T // tubelet) * (H // patch) * (W // patch)
+        out = K.patch_embed_gemm(cols, w_bf16(weight, any(ctx.needs_input_grad)), _f32c(bias), _f32c(pos), ntok)
+        ctx.save_for_backward(cols)
+        ctx.params = (weight, bias)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (cols,) = ctx.saved_tensors
+        weight, bias = ctx.params
+        dyb = K.cast_bf16(_f32c(dy).reshape(-1, dy.shape[-1]))
+        dW, db = linear_dw(dyb, cols, weight, bias)
+        return None, (None if dW is None else dW.reshape(weight.shape)), db, None, None, None, None, None, None, None
+
+
 # --------------------------------------------------------------------------- attention / mlp cores (2-D tensors)
 def _attn_fwd_core(xn, qkv_w, q_bias, v_bias, B, N, H, scale, train):
     qkv, _ = K.linear_fwd(xn, w_bf16(qkv_w, train), _qkv_bias(q_bias, v_bias), out_dtype=torch.bfloat16)

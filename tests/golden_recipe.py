@@ -27,6 +27,13 @@ def tensor_for(tag: str, shape: Iterable[int], seed: int = 0, scale: float = 1.0
     return (torch.randn(*shape, generator=g, dtype=torch.float32) * scale + shift).to(dtype)
 
 
+def uint8_for(tag: str, shape: Iterable[int], seed: int = 0) -> torch.Tensor:
+    """seeded uint8 image data (every byte value occurs)"""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(_seed_for(tag, seed))
+    return torch.randint(0, 256, tuple(shape), generator=g, dtype=torch.uint8)
+
+
 def params_for(shapes: Dict[str, Tuple[int, ...]], seed: int = 0) -> Dict[str, torch.Tensor]:
     """Weights: N(0, 0.02) for matrices/conv kernels, N(0, 0.02) biases (so that
     biases are exercised), N(1, 0.02) for LayerNorm / layer-scale weights."""

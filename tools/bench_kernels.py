@@ -105,6 +105,18 @@ def main():
         rows.append(("patch_embed_fwd", ms, 2.0 * M * D * 1536 / ms / 1e9))
         ms = timeit(lambda: K.im2col_tubelets(xv, 2, 16), a.iters)
         rows.append((f"  im2col alone ({(4.0 * xv.numel() + 2.0 * M * 1536) / ms / 1e6:.0f} GB/s)", ms, 0.0))
+        fr = torch.randint(0, 256, (B, 16, 224, 224, 3), dtype=torch.uint8, device=dev)
+        ms = timeit(lambda: K.im2col_tubelets_u8(fr, 2, 16, (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)), a.iters)
+        rows.append((f"  im2col from uint8 frames ({(1.0 * fr.numel() + 2.0 * M * 1536) / ms / 1e6:.0f} GB/s)", ms, 0.0))
+    if want("adamw"):
+        n = 86_228_738 // 4096 * 4096 + 4096 * 152
+        bufs = [torch.randn(n, device=dev) for _ in range(2)] + [torch.zeros(n, device=dev) for _ in range(2)]
+        mirror = torch.zeros(n, dtype=torch.bfloat16, device=dev)
+        cg = torch.zeros(n // 4096, dtype=torch.uint8, device=dev)
+        part = torch.zeros(n // 4096, device=dev)
+        ms = timeit(lambda: K.adamw_step(bufs[0], bufs[1], bufs[2], bufs[3], cg, [1e-3], [0.05], [1], 0.9, 0.999, 1e-8, param_bf16=mirror,
+                                         sumsq_partials=part), a.iters)
+        rows.append((f"adamw_step 86M params (+bf16 mirror, +norm) ({30.0 * n / ms / 1e6:.0f} GB/s)", ms, 0.0))
     print(f"{'kernel':48s} {'ms':>9s} {'TFLOP/s':>9s}")
     for name, ms, tf in rows:
         print(f"{name:48s} {ms:9.3f} {tf:9.1f}")

@@ -345,6 +345,34 @@ def g6(mg):
     save("g6_tube_mask", **arrs)
 
 
+def g7(ris):
+    """Input stage: the reference's per-frame normalisation, run on seeded uint8 frames.
+    * run_inference_simple.prepare_image (== run_inference.py:15-34): its single OpenCV call, cv2.cvtColor(img, COLOR_BGR2RGB),
+      is served by a channel-reversal stand-in (OpenCV is not installed); everything else is the reference's own torch code.
+    * tensor_normalize (ssv2.py:346-362, same text in dota.py:443-460 / kinetics.py / dada.py): imported from ssv2.py with
+      MagicMock modules for the loaders' third-party imports (torchvision, decord), which the function does not touch."""
+    import unittest.mock as mock
+    cv2 = sys.modules["cv2"]
+    cv2.COLOR_BGR2RGB = 4
+    cv2.cvtColor = lambda img, code: np.ascontiguousarray(img[..., ::-1])
+    arrs = {}
+    frame = R.uint8_for("g7.frame", (32, 48, 3))            # one BGR frame, HWC
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    arrs["prepare_image"] = ris.prepare_image(frame.numpy().copy(), mean, std).numpy()   # [3,H,W] f32, RGB
+    arrs["prepare_image_center"] = ris.prepare_image(frame.numpy().copy(), (0.5, 0.5, 0.5), (0.5, 0.5, 0.5)).numpy()
+    for name in ("torchvision", "torchvision.transforms", "torchvision.transforms.functional", "decord", "PIL", "PIL.Image",
+                 "video_transforms", "volume_transforms", "random_erasing", "rand_augment"):
+        sys.modules.setdefault(name, mock.MagicMock())   # (the last four are the reference's augmentation files: they need torchvision/PIL)
+    import ssv2
+    clip = R.uint8_for("g7.clip", (4, 16, 16, 3))            # [T,H,W,C] RGB, the loaders' buffer layout
+    arrs["tensor_normalize"] = ssv2.tensor_normalize(clip.clone(), list(mean), list(std)).numpy()   # [T,H,W,C] f32
+    # all 256 byte values through both paths (the complete truth table of the arithmetic, per channel)
+    ramp = torch.arange(256, dtype=torch.uint8).view(1, 256, 1).repeat(1, 1, 3)   # [1,256,3]
+    arrs["ramp_prepare_image"] = ris.prepare_image(ramp.numpy().copy(), mean, std).numpy()
+    arrs["ramp_tensor_normalize"] = ssv2.tensor_normalize(ramp.view(1, 1, 256, 3).clone(), list(mean), list(std)).numpy()
+    save("g7_input_stage", **arrs)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -352,7 +380,7 @@ def main():
     torch.set_num_threads(8)
     ris, mf, mg = import_reference()
     jobs = {"g1": lambda: g1(mf), "g2": lambda: g2(mf), "g3": lambda: g3(mf), "g4": lambda: g4(mf, ris),
-            "g5": g5, "g6": lambda: g6(mg)}
+            "g5": g5, "g6": lambda: g6(mg), "g7": lambda: g7(ris)}
     for k, fn in jobs.items():
         if a.only and a.only != k:
             continue
