@@ -181,6 +181,26 @@ int tad_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_a
                    const int32_t* group_step, float beta1, float beta2, float eps, const float* grad_scale,
                    float* sumsq_partials, tad_stream_t stream);
 
+/* ---- MAE pre-training path: what modeling_pretrain.py / engine_for_pretraining.py add around the Block stack ----
+ * Rows are D f32, D % 4 == 0.  idx arrays are int32 on the device. */
+/* out[r] = src[idx[r]], r < n_out: x[~mask].reshape(B,-1,C) (modeling_pretrain.py:98) with idx = b*N + visible token */
+int tad_gather_rows_f32(const float* src, const int32_t* idx, float* out, int64_t n_out, int D, tad_stream_t stream);
+/* out[idx[r]] = src[r], r < n_in (unique indices; the caller zero-fills out): backward of the gather */
+int tad_scatter_rows_f32(const float* src, const int32_t* idx, float* out, int64_t n_in, int D, tad_stream_t stream);
+/* decoder input (modeling_pretrain.py:283-288): out [B, n_vis+n_mask, D] = cat(x_vis + pos[vis_idx], mask_token + pos[mask_idx]);
+ * x_vis [B*n_vis, D], mask_token [D], pos [N, D], vis_idx [B*n_vis] / mask_idx [B*n_mask] = token index inside the clip */
+int tad_mae_assemble(const float* x_vis, const float* mask_token, const float* pos, const int32_t* vis_idx, const int32_t* mask_idx,
+                     float* out, int B, int n_vis, int n_mask, int D, tad_stream_t stream);
+/* reconstruction target (engine_for_pretraining.py:51-66): videos [B,3,T,H,W] f32 (normalised clip) -> labels [B*n_mask,
+ * tub*p*p*3] for the masked tokens: v = x*std + mean, patch layout 'b n (p0 p1 p2) c', and with normalize_target each
+ * (patch, channel) is standardised over its pixels: (v - mean) / (sqrt(unbiased var) + 1e-6).  mean3 / std3: HOST arrays. */
+int tad_mae_target(const float* videos, const int32_t* mask_idx, float* labels, int B, int n_mask, int T, int H, int W, int tubelet,
+                   int patch, const float* mean3, const float* std3, int normalize_target, tad_stream_t stream);
+/* nn.MSELoss() (engine_for_pretraining.py:27,70): partials[tad_mse_loss_blocks(n)] = block sums of (pred-target)^2 (the loss is
+ * their sum / n); grad (nullable) = 2 (pred - target) / n */
+int tad_mse_loss_blocks(int64_t n);
+int tad_mse_loss(const float* pred, const float* target, int64_t n, float* partials, float* grad, tad_stream_t stream);
+
 /* ---- "precise" mode (parity gate, not throughput): f32-accurate Linear via split-bf16 operands, f32 attention ----------
  * x = hi + lo (bf16 each).  concat mode: out [M,3K] = [hi|hi|lo] (role_b=0) or [hi|lo|hi] (role_b=1); stack mode: out [3M,K]
  * with the three parts stacked along rows.  Feeding tad_linear_* with both operands split this way (K or M tripled) gives the

@@ -43,6 +43,12 @@ SIGNATURES = {
     "tad_transpose_bf16_batched": (_i, [_vp, _vp, _vp, _i, _vp]),
     "tad_adamw_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(_f), C.POINTER(_f), _i, C.POINTER(C.c_int32), _f, _f, _f, _vp, _vp,
                        _vp]),
+    "tad_gather_rows_f32": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
+    "tad_scatter_rows_f32": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
+    "tad_mae_assemble": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "tad_mae_target": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_f), C.POINTER(_f), _i, _vp]),
+    "tad_mse_loss_blocks": (_i, [_i64]),
+    "tad_mse_loss": (_i, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "tad_split_bf16x3": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp]),
     "tad_im2col_tubelets_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "tad_attn_fwd_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),

@@ -454,6 +454,87 @@ def adamw_step(param, grad, exp_avg, exp_avg_sq, chunk_group, group_lr, group_wd
                                          _p(grad_scale), _p(sumsq_partials), _stream()), "tad_adamw_step")
 
 
+# ----------------------------------------------------------------------------- MAE pre-training path
+def _idx(t, name):
+    if not t.is_cuda or t.dtype != torch.int32 or not t.is_contiguous():
+        raise _lib.TadError(f"{name}: expected a contiguous int32 GPU tensor")
+    return t
+
+
+def gather_rows(src, idx, bound_check=True):
+    """out[r] = src[idx[r]]; src [R,D] f32, idx [n] int32"""
+    _req(src, torch.float32, "gather_rows.src")
+    _idx(idx, "gather_rows.idx")
+    R, D = src.shape
+    out = torch.empty((idx.numel(), D), dtype=torch.float32, device=src.device)
+    with _timed("gather", 0.0, 8.0 * idx.numel() * D):
+        check(_lib.load().tad_gather_rows_f32(src.data_ptr(), idx.data_ptr(), out.data_ptr(), idx.numel(), D, _stream()), "tad_gather_rows_f32")
+    return out
+
+
+def scatter_rows(src, idx, n_rows):
+    """out [n_rows, D] zeros except out[idx[r]] = src[r] (unique indices)"""
+    _req(src, torch.float32, "scatter_rows.src")
+    _idx(idx, "scatter_rows.idx")
+    n, D = src.shape
+    assert idx.numel() == n
+    out = torch.zeros((n_rows, D), dtype=torch.float32, device=src.device)
+    with _timed("gather", 0.0, 8.0 * n * D):
+        check(_lib.load().tad_scatter_rows_f32(src.data_ptr(), idx.data_ptr(), out.data_ptr(), n, D, _stream()), "tad_scatter_rows_f32")
+    return out
+
+
+def mae_assemble(x_vis, mask_token, pos, vis_idx, mask_idx, B):
+    """decoder input [B, Nv+Nm, D] = cat(x_vis + pos[vis], mask_token + pos[masked])"""
+    _req(x_vis, torch.float32, "mae_assemble.x_vis")
+    _req(mask_token, torch.float32, "mae_assemble.mask_token")
+    _req(pos, torch.float32, "mae_assemble.pos")
+    _idx(vis_idx, "mae_assemble.vis_idx")
+    _idx(mask_idx, "mae_assemble.mask_idx")
+    D = x_vis.shape[-1]
+    Nv, Nm = vis_idx.numel() // B, mask_idx.numel() // B
+    if x_vis.numel() != B * Nv * D or mask_token.numel() != D or pos.shape[-1] != D or pos.numel() // D < Nv + Nm:
+        raise _lib.TadError("mae_assemble: inconsistent shapes")
+    out = torch.empty((B, Nv + Nm, D), dtype=torch.float32, device=x_vis.device)
+    with _timed("gather", 0.0, 12.0 * out.numel()):
+        check(_lib.load().tad_mae_assemble(x_vis.data_ptr(), mask_token.data_ptr(), pos.data_ptr(), vis_idx.data_ptr(), mask_idx.data_ptr(),
+                                           out.data_ptr(), B, Nv, Nm, D, _stream()), "tad_mae_assemble")
+    return out
+
+
+def mae_target(videos, mask_idx, tubelet, patch, mean, std, normalize_target=True):
+    """videos [B,3,T,H,W] f32 (normalised) -> labels [B, Nm, tub*p*p*3] f32 for the masked tokens (engine_for_pretraining.py:51-66)"""
+    import ctypes as C
+    _req(videos, torch.float32, "mae_target.videos")
+    _idx(mask_idx, "mae_target.mask_idx")
+    B, Cc, T, H, W = videos.shape
+    if Cc != 3:
+        raise _lib.TadError("mae_target: clips must have 3 channels")
+    Nm = mask_idx.numel() // B
+    labels = torch.empty((B, Nm, tubelet * patch * patch * 3), dtype=torch.float32, device=videos.device)
+    m = (C.c_float * 3)(*[float(v) for v in mean])
+    s = (C.c_float * 3)(*[float(v) for v in std])
+    with _timed("mae_target", 0.0, 8.0 * labels.numel()):
+        check(_lib.load().tad_mae_target(videos.data_ptr(), mask_idx.data_ptr(), labels.data_ptr(), B, Nm, T, H, W, tubelet, patch, m, s,
+                                         int(bool(normalize_target)), _stream()), "tad_mae_target")
+    return labels
+
+
+def mse_loss(pred, target, want_grad=True):
+    """returns (loss scalar tensor, grad|None) of nn.MSELoss()(pred, target)"""
+    _req(pred, torch.float32, "mse.pred")
+    _req(target, torch.float32, "mse.target")
+    n = pred.numel()
+    if target.numel() != n:
+        raise _lib.TadError("mse_loss: pred and target differ in size")
+    lib = _lib.load()
+    partials = torch.empty(lib.tad_mse_loss_blocks(n), dtype=torch.float32, device=pred.device)
+    grad = torch.empty_like(pred) if want_grad else None
+    with _timed("mse", 0.0, (12.0 if want_grad else 8.0) * n):
+        check(lib.tad_mse_loss(pred.data_ptr(), target.data_ptr(), n, partials.data_ptr(), _p(grad), _stream()), "tad_mse_loss")
+    return partials.sum() / n, grad
+
+
 def device_info():
     import ctypes as C
     cu, clk, ldsb = C.c_int(), C.c_int(), C.c_int()

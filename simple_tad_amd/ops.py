@@ -443,6 +443,88 @@ class BlockFn(torch.autograd.Function):
                 None)
 
 
+# --------------------------------------------------------------------------- plain Linear (f32 rows in / out)
+class LinearFn(torch.autograd.Function):
+    """nn.Linear on f32 rows through the bf16 MFMA GEMM (encoder_to_decoder and the decoder head, modeling_pretrain.py:163,269)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _need_gpu(x, "Linear")
+        shp = x.shape
+        train = any(ctx.needs_input_grad)
+        xb = K.cast_bf16(_f32c(x).reshape(-1, shp[-1]))
+        y, _ = K.linear_fwd(xb, w_bf16(weight, train), _f32c(bias), out_dtype=torch.float32)
+        if train:
+            ctx.save_for_backward(xb)
+        ctx.params = (weight, bias)
+        ctx.shp = shp
+        return y.reshape(*shp[:-1], -1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (xb,) = ctx.saved_tensors
+        weight, bias = ctx.params
+        dyb = K.cast_bf16(_f32c(dy).reshape(-1, dy.shape[-1]))
+        dx = K.linear_bwd_input(dyb, wT_bf16(weight, True), out_dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        dW, db = linear_dw(dyb, xb, weight, bias)
+        return (None if dx is None else dx.reshape(ctx.shp)), dW, db
+
+
+# --------------------------------------------------------------------------- MAE pre-training path (SURVEY 8f-2)
+class GatherRowsFn(torch.autograd.Function):
+    """x[~mask].reshape(B, -1, C) (modeling_pretrain.py:98) with precomputed row indices (b*N + visible token)."""
+
+    @staticmethod
+    def forward(ctx, x, idx, B):
+        _need_gpu(x, "token gather")
+        Bx, N, D = x.shape
+        ctx.save_for_backward(idx)
+        ctx.shape = (Bx, N, D)
+        return K.gather_rows(_f32c(x).reshape(Bx * N, D), idx).reshape(B, -1, D)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        Bx, N, D = ctx.shape
+        return K.scatter_rows(_f32c(g).reshape(-1, D), idx, Bx * N).reshape(Bx, N, D), None, None
+
+
+class MaeAssembleFn(torch.autograd.Function):
+    """cat([x_vis + pos[vis], mask_token + pos[masked]], dim=1) (modeling_pretrain.py:283-287); the positional table is a constant"""
+
+    @staticmethod
+    def forward(ctx, x_vis, mask_token, pos, vis_idx, mask_idx):
+        _need_gpu(x_vis, "MAE decoder input")
+        B, Nv, D = x_vis.shape
+        ctx.meta = (B, Nv, mask_idx.numel() // B, D)
+        return K.mae_assemble(_f32c(x_vis).reshape(B * Nv, D), _f32c(mask_token).reshape(-1), _f32c(pos).reshape(-1, D), vis_idx, mask_idx, B)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, Nv, Nm, D = ctx.meta
+        g = _f32c(g)
+        d_xv = g[:, :Nv].contiguous()
+        d_tok = K.colsum_f32(g[:, Nv:].reshape(B * Nm, D).contiguous()).reshape(1, 1, D)
+        return d_xv, d_tok, None, None, None
+
+
+class MseLossFn(torch.autograd.Function):
+    """nn.MSELoss()(outputs, labels) (engine_for_pretraining.py:27,70): loss and d(loss)/d(outputs) in one pass"""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        _need_gpu(pred, "MSE loss")
+        loss, grad = K.mse_loss(_f32c(pred), _f32c(target), want_grad=ctx.needs_input_grad[0])
+        ctx.save_for_backward(grad)
+        ctx.shape = pred.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return (grad * g).reshape(ctx.shape), None
+
+
 # --------------------------------------------------------------------------- mean-pool
 class MeanPoolFn(torch.autograd.Function):
     """x.mean(1) over tokens (modeling_finetune.py:325-326)."""

@@ -1,0 +1,170 @@
+"""MAE pre-training path.  CPU: oracle restatement against golden G8 = the REAL reference model driven by the REAL
+engine_for_pretraining.train_one_epoch for one step (outputs, labels, loss, every gradient), module surface, tube mask.
+GPU: the new kernels against the oracle, the drop-in model against G8, the engine loop."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import golden_recipe as R
+from oracle import vit_oracle as O
+
+CFG = dict(enc_depth=2, enc_heads=2, dec_depth=1, dec_heads=1, tubelet=2, patch=16)
+
+
+def rell2(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def setup(golden):
+    g = golden("g8_pretrain")
+    keys = [str(k) for k in g["keys"]]
+    import simple_tad_amd.modeling_pretrain as mp
+    m = mp.PretrainVisionTransformer(img_size=32, patch_size=16, encoder_embed_dim=128, encoder_depth=2, encoder_num_heads=2,
+                                     decoder_num_classes=1536, decoder_embed_dim=64, decoder_depth=1, decoder_num_heads=1, mlp_ratio=4,
+                                     qkv_bias=True, norm_layer=__import__("functools").partial(torch.nn.LayerNorm, eps=1e-6), init_values=0.,
+                                     tubelet_size=2)
+    P = R.params_for({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=8)
+    x = R.tensor_for("g8.x", (2, 3, 16, 32, 32), seed=8)
+    mask = torch.from_numpy(g["mask"]).bool()
+    return g, keys, m, P, x, mask
+
+
+def test_oracle_matches_reference_engine_step(golden):
+    g, keys, m, P, x, mask = setup(golden)
+    assert list(m.state_dict().keys()) == keys  # same parameter names, same order as the reference's module tree
+    Pd = {k: v.double().requires_grad_() for k, v in P.items()}
+    out = O.pretrain_forward(x.double(), mask, Pd, **CFG)
+    labels = O.mae_target(x.double(), mask, tubelet=2, patch=16)
+    assert out.shape == (2, 24, 1536) and rell2(out.detach(), g["outputs"]) < 1e-10
+    assert np.allclose(labels.numpy(), g["labels"], rtol=0, atol=1e-10)
+    assert np.allclose(O.mae_target(x.double(), mask, tubelet=2, patch=16, normalize_target=False).numpy(), g["labels_raw"], rtol=0, atol=1e-12)
+    loss = F.mse_loss(out, labels)
+    assert abs(loss.item() - float(g["loss"])) < 1e-10
+    loss.backward()
+    for k in keys:
+        R.check_summary(Pd[k].grad, g, "grad." + k, rtol=2e-6)
+
+
+def test_tube_mask_generator_matches_reference(golden):
+    from simple_tad_amd.masking_generator import TubeMaskingGenerator
+    g = golden("g6_tube_mask")
+    np.random.seed(0)
+    gen = TubeMaskingGenerator((8, 14, 14), 0.75)
+    assert np.array_equal(gen().astype(np.uint8), g["mask_8_14_14_075"])
+    assert gen.total_masks == int(g["total_masks"]) and gen.num_masks_per_frame == int(g["per_frame"])
+    assert TubeMaskingGenerator((8, 14, 14), 0.9).num_masks_per_frame == int(g["per_frame_09"])
+
+
+def test_module_surface_and_factories():
+    import simple_tad_amd as T
+    import simple_tad_amd.modeling_pretrain as mp  # noqa: F401  (registers the factories)
+    assert {"pretrain_videomae_small_patch16_224", "pretrain_videomae_base_patch16_224", "pretrain_videomae_large_patch16_224",
+            "pretrain_videomae_huge_patch16_224"} <= set(T.list_models())
+    m = T.create_model("pretrain_videomae_small_patch16_224", pretrained=False, drop_path_rate=0.0, decoder_depth=2, use_checkpoint=False)
+    sd = m.state_dict()
+    assert sd["encoder_to_decoder.weight"].shape == (192, 384) and sd["mask_token"].shape == (1, 1, 192)
+    assert sd["decoder.head.weight"].shape == (1536, 192) and "pos_embed" not in sd and len(m.decoder.blocks) == 2
+    assert m.no_weight_decay() == {"pos_embed", "cls_token", "mask_token"} and m.encoder.patch_embed.num_patches == 1568
+    assert float(m.mask_token.abs().max()) <= 0.02  # trunc_normal_ at +-std (modeling_pretrain.py:14-15)
+    with pytest.raises(Exception, match="no CPU fallback"):
+        m(torch.zeros(1, 3, 16, 224, 224), torch.zeros(1, 1568, dtype=torch.bool))
+
+
+# ------------------------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_mae_kernels_vs_oracle():
+    from simple_tad_amd import kernels as K
+    torch.manual_seed(0)
+    B, N, D, Nm = 3, 40, 72, 28
+    x = torch.randn(B, N, D)
+    mask = torch.zeros(B, N, dtype=torch.bool)
+    for b in range(B):
+        mask[b, torch.randperm(N)[:Nm]] = True
+    from simple_tad_amd.modeling_pretrain import token_indices
+    vis, msk = token_indices(mask.cuda(), Nm)
+    assert torch.equal(vis.cpu().long(), torch.stack([(~mask[b]).nonzero().flatten() for b in range(B)]))   # ascending, as x[~mask]
+    assert torch.equal(msk.cpu().long(), torch.stack([mask[b].nonzero().flatten() for b in range(B)]))
+    rows = (vis + (torch.arange(B, device="cuda", dtype=torch.int32) * N).unsqueeze(1)).reshape(-1).contiguous()
+    got = K.gather_rows(x.cuda().reshape(B * N, D), rows)
+    assert torch.equal(got.cpu().reshape(B, -1, D), x[~mask].reshape(B, -1, D))                              # bit-exact row moves
+    back = K.scatter_rows(got, rows, B * N).cpu().reshape(B, N, D)
+    assert torch.equal(back[~mask], x[~mask]) and float(back[mask].abs().sum()) == 0.0
+    tok, pos = torch.randn(D), torch.randn(N, D)
+    xv = torch.randn(B, N - Nm, D)
+    full = K.mae_assemble(xv.cuda().reshape(-1, D), tok.cuda(), pos.cuda(), vis.reshape(-1), msk.reshape(-1), B).cpu()
+    pe = pos.expand(B, -1, -1)
+    want = torch.cat([xv + pe[~mask].reshape(B, -1, D), tok + pe[mask].reshape(B, -1, D)], dim=1)
+    assert torch.equal(full, want)
+    # reconstruction target and MSE
+    vids = torch.randn(2, 3, 4, 32, 48)
+    m2 = torch.zeros(2, 2 * 2 * 3, dtype=torch.bool)
+    m2[:, [1, 2, 5, 7, 8, 10, 11]] = True
+    _, mt = token_indices(m2.cuda(), 7)
+    for norm in (True, False):
+        lab = K.mae_target(vids.cuda(), mt.reshape(-1), 2, 16, (0.485, 0.456, 0.406), (0.229, 0.224, 0.225), norm).cpu()
+        ref = O.mae_target(vids.double(), m2, tubelet=2, patch=16, normalize_target=norm)
+        assert lab.shape == ref.shape and rell2(lab, ref) < 2e-6, norm
+    pred, tgt = torch.randn(5, 7, 64), torch.randn(5, 7, 64)
+    loss, grad = K.mse_loss(pred.cuda().contiguous(), tgt.cuda().contiguous())
+    pr = pred.double().requires_grad_()
+    lr = F.mse_loss(pr, tgt.double())
+    lr.backward()
+    assert abs(loss.item() - lr.item()) < 1e-6 * lr.item() and rell2(grad, pr.grad) < 1e-6
+
+
+@pytest.mark.gpu
+def test_pretrain_model_forward_backward_vs_reference_golden(golden):
+    """fast (bf16-operand) mode against the fp64 run of the real reference: same yardstick as the fine-tuning model tests."""
+    from simple_tad_amd import ops
+    g, keys, m, P, x, mask = setup(golden)
+    m.load_state_dict(P)
+    m = m.cuda().train()
+    out = m(x.cuda(), mask.cuda())
+    assert out.shape == (2, 24, 1536) and rell2(out, g["outputs"]) < 8e-3, rell2(out, g["outputs"])
+    from simple_tad_amd.engine_pretrain import reconstruction_target
+    labels = reconstruction_target(x.cuda(), mask.cuda())
+    assert rell2(labels, g["labels"]) < 2e-6
+    loss = ops.MseLossFn.apply(out, labels)
+    assert abs(loss.item() - float(g["loss"])) < 5e-3 * float(g["loss"])
+    loss.backward()
+    worst = 0.0
+    for k, p in m.named_parameters():
+        head = torch.from_numpy(g[f"grad.{k}.head"]).double()
+        got = p.grad.detach().double().cpu().flatten()[: head.numel()]
+        e = ((got - head).norm() / head.norm().clamp_min(1e-12)).item()
+        worst = max(worst, e)
+        assert e < 4e-2, (k, e)
+        sq = float(g[f"grad.{k}.sqsum"])
+        assert abs((p.grad.double() ** 2).sum().item() - sq) < 4e-2 * sq, k
+    print("pretrain worst grad rel-l2", worst)
+
+
+@pytest.mark.gpu
+def test_pretrain_engine_loop_loss_falls(golden):
+    from simple_tad_amd import engine as E, engine_pretrain as EP
+    from simple_tad_amd.masking_generator import TubeMaskingGenerator
+    from simple_tad_amd.parallel import DataParallel
+    g, keys, m, P, x, mask = setup(golden)
+    m.load_state_dict(P)
+    m = m.cuda()
+    dp = DataParallel(m)
+    opt = E.create_optimizer(dp, lr=2e-2, weight_decay=0.05)
+    scaler = E.NativeScalerWithGradNormCount(dp)
+    np.random.seed(1)
+    gen = TubeMaskingGenerator((8, 2, 2), 0.75)
+    # learnable synthetic clips: one pattern with the period of a patch (every masked patch has the same normalised target, so
+    # the decoder can fit it within a few dozen Adam steps) + a little noise
+    yy, xx = torch.meshgrid(torch.arange(32.0), torch.arange(32.0), indexing="ij")
+    pattern = torch.stack([torch.sin(2 * math.pi * xx / 16 + c) * torch.cos(2 * math.pi * yy / 16) for c in range(3)]).unsqueeze(1).repeat(1, 16, 1, 1)
+    torch.manual_seed(1)
+    data = [(pattern.unsqueeze(0) + 0.05 * torch.randn(4, 3, 16, 32, 32), torch.from_numpy(np.stack([gen() for _ in range(4)])))
+            for _ in range(40)]
+    lr = E.cosine_scheduler(2e-2, 1e-4, 1, len(data), warmup_epochs=0)
+    stats = EP.train_one_epoch(dp, data, opt, torch.device("cuda"), 0, scaler, max_norm=0.02 * 50, patch_size=16, lr_schedule_values=lr)
+    first, last = sum(stats["loss"][:3]) / 3, sum(stats["loss"][-3:]) / 3
+    assert all(math.isfinite(v) for v in stats["loss"]) and all(v is not None and v > 0 for v in stats["grad_norm"])
+    assert last < 0.7 * first, (first, last)

@@ -373,6 +373,92 @@ def g7(ris):
     save("g7_input_stage", **arrs)
 
 
+def g8(mf):
+    """MAE pre-training path: the real modeling_pretrain.PretrainVisionTransformer (tiny, fp64) driven by the real
+    engine_for_pretraining.train_one_epoch for ONE step on CPU.  The engine's module-level imports that this image lacks (utils ->
+    tensorboardX..., timm.data.constants) are satisfied by MagicMock / the published ImageNet constants; ``nn.MSELoss`` is wrapped to
+    record the (outputs, labels) pair the engine builds, ``torch.cuda.*`` calls are no-ops on CPU."""
+    import contextlib
+    import unittest.mock as mock
+    tdc = types.ModuleType("timm.data.constants")
+    tdc.IMAGENET_DEFAULT_MEAN, tdc.IMAGENET_DEFAULT_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)  # timm's published constants
+    tdata = types.ModuleType("timm.data")
+    tdata.constants = tdc
+    sys.modules.update({"timm.data": tdata, "timm.data.constants": tdc})
+    um = mock.MagicMock()
+
+    class _Logger:
+        def __init__(self, **kw):
+            pass
+
+        def add_meter(self, *a, **k):
+            pass
+
+        def log_every(self, it, *a, **k):
+            yield from it
+
+        def update(self, **k):
+            pass
+
+        def synchronize_between_processes(self):
+            pass
+
+        meters = {}
+
+    um.MetricLogger = _Logger
+    # diagnostics only (per-head gradient norms for plots); the engine asserts that they are non-zero after the loop
+    um.collect_grad_norms_pretrain = lambda *a, **k: (np.ones((12, 6, 5)), np.ones((12, 6)), np.ones((2,)))
+    sys.modules["utils"] = um
+    import modeling_pretrain as mp
+    import engine_for_pretraining as efp
+    torch.manual_seed(0)
+    model = mp.PretrainVisionTransformer(img_size=32, patch_size=16, encoder_embed_dim=128, encoder_depth=2, encoder_num_heads=2,
+                                         decoder_num_classes=1536, decoder_embed_dim=64, decoder_depth=1, decoder_num_heads=1,
+                                         mlp_ratio=4, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), init_values=0.,
+                                         use_flash_attn=False, tubelet_size=2).double()
+    P = R.params_for({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=8)
+    model.load_state_dict({k: v.double() for k, v in P.items()})
+    x = R.tensor_for("g8.x", (2, 3, 16, 32, 32), seed=8).double()     # PatchEmbed's default num_frames=16 -> 32 tokens
+    rng = np.random.RandomState(8)
+    per = np.hstack([np.zeros(1), np.ones(3)])                         # tube mask 0.75 on a 2x2 grid, 8 temporal slots
+    masks = []
+    for _ in range(2):
+        rng.shuffle(per)
+        masks.append(np.tile(per, (8, 1)).flatten())
+    mask = torch.from_numpy(np.stack(masks)).bool()
+    captured = {}
+
+    class _MSE(nn.MSELoss):
+        def forward(self, input, target):
+            captured["outputs"], captured["labels"] = input.detach().clone(), target.detach().clone()
+            return super().forward(input, target)
+
+    def scaler(loss, optimizer, clip_grad=None, parameters=None, create_graph=False):
+        loss.backward()
+        captured["loss"] = loss.detach().clone()
+        return 0.0
+
+    scaler.state_dict = lambda: {"scale": 1.0}
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)
+    with mock.patch.object(efp.nn, "MSELoss", _MSE), mock.patch("torch.cuda.empty_cache"), mock.patch("torch.cuda.synchronize"), \
+            mock.patch("torch.cuda.amp.autocast", lambda *a, **k: contextlib.nullcontext()):
+        efp.train_one_epoch(model, [(x, mask)], opt, torch.device("cpu"), 0, scaler, max_norm=0, patch_size=16, normlize_target=True,
+                            start_steps=0)
+    arrs = {"mask": mask.numpy(), "outputs": captured["outputs"].numpy(), "labels": captured["labels"].numpy(),
+            "loss": np.array(captured["loss"].item()), "keys": np.array(list(P.keys()))}
+    for k, p in model.named_parameters():
+        for kk, v in R.summarize(p.grad.float()).items():
+            arrs[f"grad.{k}.{kk}"] = v
+    # un-normalised (normlize_target=False) labels as well
+    captured.clear()
+    with mock.patch.object(efp.nn, "MSELoss", _MSE), mock.patch("torch.cuda.empty_cache"), mock.patch("torch.cuda.synchronize"), \
+            mock.patch("torch.cuda.amp.autocast", lambda *a, **k: contextlib.nullcontext()):
+        efp.train_one_epoch(model, [(x, mask)], opt, torch.device("cpu"), 0, scaler, max_norm=0, patch_size=16, normlize_target=False,
+                            start_steps=0)
+    arrs["labels_raw"] = captured["labels"].numpy()
+    save("g8_pretrain", **arrs)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -380,7 +466,7 @@ def main():
     torch.set_num_threads(8)
     ris, mf, mg = import_reference()
     jobs = {"g1": lambda: g1(mf), "g2": lambda: g2(mf), "g3": lambda: g3(mf), "g4": lambda: g4(mf, ris),
-            "g5": g5, "g6": lambda: g6(mg), "g7": lambda: g7(ris)}
+            "g5": g5, "g6": lambda: g6(mg), "g7": lambda: g7(ris), "g8": lambda: g8(mf)}
     for k, fn in jobs.items():
         if a.only and a.only != k:
             continue
