@@ -201,6 +201,15 @@ int tad_mae_target(const float* videos, const int32_t* mask_idx, float* labels, 
 int tad_mse_loss_blocks(int64_t n);
 int tad_mse_loss(const float* pred, const float* target, int64_t n, float* partials, float* grad, tad_stream_t stream);
 
+/* ---- evaluation path -----------------------------------------------------------------------------------------
+ * Exact integer counts behind every thresholded metric of engine_for_frame_finetuning.calculate_metrics (:593-636) and
+ * anaysis/metrics.calculate_MORE_metrics (:127-208), which test `pred >= t` for t in np.arange(0, 1.001, 0.01).
+ * thresholds: ascending f32 [n_thresholds <= 255] (device); labels int32 (non-zero = positive);
+ * hist int64 [2][n_thresholds+1] (device, overwritten): hist[l][k] = number of samples with label l and k = #{t : p >= t}.
+ * The confusion matrix at threshold index i is then  TP = sum_{k>i} hist[1][k], FN = sum_{k<=i} hist[1][k], FP / TN likewise. */
+int tad_threshold_histogram(const float* probs, const int32_t* labels, const float* thresholds, int n_thresholds, int64_t n,
+                            int64_t* hist, tad_stream_t stream);
+
 /* ---- "precise" mode (parity gate, not throughput): f32-accurate Linear via split-bf16 operands, f32 attention ----------
  * x = hi + lo (bf16 each).  concat mode: out [M,3K] = [hi|hi|lo] (role_b=0) or [hi|lo|hi] (role_b=1); stack mode: out [3M,K]
  * with the three parts stacked along rows.  Feeding tad_linear_* with both operands split this way (K or M tripled) gives the

@@ -49,6 +49,7 @@ SIGNATURES = {
     "tad_mae_target": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_f), C.POINTER(_f), _i, _vp]),
     "tad_mse_loss_blocks": (_i, [_i64]),
     "tad_mse_loss": (_i, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "tad_threshold_histogram": (_i, [_vp, _vp, _vp, _i, _i64, _vp, _vp]),
     "tad_split_bf16x3": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp]),
     "tad_im2col_tubelets_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "tad_attn_fwd_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),

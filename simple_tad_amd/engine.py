@@ -227,3 +227,52 @@ def train_one_epoch(model: torch.nn.Module, criterion, data_loader: Iterable, op
         if log is not None:
             log(epoch, data_iter_step, stats)
     return stats
+
+
+# ----------------------------------------------------------------------------------------------------------------- evaluation
+def gather_predictions(tensors, world_size=None):
+    """utils.gather_predictions_nontensor (utils.py:791-810) for lists of per-batch tensors: concatenate locally, all-gather the
+    (equal-shaped or padded) result across ranks; single process: the local concatenation."""
+    import torch.distributed as dist
+    local = torch.cat([t.detach() for t in tensors], dim=0)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local
+    world = dist.get_world_size()
+    n = torch.tensor([local.shape[0]], device=local.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    m = int(max(int(s) for s in sizes))
+    pad = torch.zeros((m,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    out = [torch.zeros_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad)
+    return torch.cat([o[: int(s)] for o, s in zip(out, sizes)], dim=0)
+
+
+@torch.no_grad()
+def validation_one_epoch(data_loader, model, device):
+    """engine_for_frame_finetuning.validation_one_epoch (:282-383) without the TTC / smoothed-label / plotting branches: eval-mode
+    forward over the loader, CE loss and top-1 per batch, predictions gathered across ranks, then ``metrics.calculate_metrics``."""
+    from . import metrics as M
+    criterion = torch.nn.CrossEntropyLoss()
+    model.eval()
+    preds, labels, losses, correct, seen = [], [], [], 0, 0
+    for batch in data_loader:
+        videos = batch[0].to(device, non_blocking=True)
+        target = batch[1].to(device, non_blocking=True)
+        output = model(videos)
+        losses.append(criterion(output, target).item())
+        correct += int((output.max(-1)[1] == target).sum())
+        seen += videos.shape[0]
+        preds.append(output.detach())
+        labels.append(target.detach())
+    all_preds, all_labels = gather_predictions(preds), gather_predictions(labels)
+    acc, recall, precision, f1, confmat, auroc, ap, pr_curve, roc_curve, mcc = M.calculate_metrics(all_preds, all_labels)
+    values = torch.nn.functional.softmax(all_preds, dim=1)[:, 1]
+    my = {"metr_acc": acc, "recall": recall, "precision": precision, "f1": f1, "auroc": auroc, "ap": ap, "mcc_auc": mcc[0],
+          "mcc_max": mcc[1], "mcc_max_thresh": mcc[2], "mcc_05": mcc[3],
+          "logitsP_mean": all_preds[:, 1].mean().item(), "logitsP_std": all_preds[:, 1].std().item(),
+          "logitsP_median": all_preds[:, 1].median().item(), "logitsN_mean": all_preds[:, 0].mean().item(),
+          "logitsN_std": all_preds[:, 0].std().item(), "logitsN_median": all_preds[:, 0].median().item(),
+          "probs_mean": values.mean().item(), "probs_std": values.std().item(), "probs_median": values.median().item()}
+    return {"loss": float(np.mean(losses)), "acc": 100.0 * correct / max(seen, 1)}, my, {"confmat": confmat, "pr_curve": pr_curve, "roc_curve": roc_curve}

@@ -34,6 +34,20 @@ def uint8_for(tag: str, shape: Iterable[int], seed: int = 0) -> torch.Tensor:
     return torch.randint(0, 256, tuple(shape), generator=g, dtype=torch.uint8)
 
 
+def eval_probs_labels(tag: str, n: int, seed: int = 0):
+    """class-1 probabilities (float32 numpy, informative but noisy; a third of them rounded to the 0.01 grid so that scores tie
+    with each other and with the thresholds) and binary labels"""
+    import numpy as np
+    g = torch.Generator(device="cpu")
+    g.manual_seed(_seed_for(tag, seed))
+    labels = (torch.rand(n, generator=g) < 0.3).long()
+    logit = torch.randn(n, generator=g) * 1.5 + (labels.float() * 2.0 - 1.0)
+    probs = torch.sigmoid(logit)
+    grid = torch.rand(n, generator=g) < 0.33
+    probs = torch.where(grid, (probs * 100).round() / 100, probs).float()
+    return probs.numpy().astype(np.float32), labels.numpy()
+
+
 def params_for(shapes: Dict[str, Tuple[int, ...]], seed: int = 0) -> Dict[str, torch.Tensor]:
     """Weights: N(0, 0.02) for matrices/conv kernels, N(0, 0.02) biases (so that
     biases are exercised), N(1, 0.02) for LayerNorm / layer-scale weights."""

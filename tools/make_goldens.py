@@ -459,6 +459,23 @@ def g8(mf):
     save("g8_pretrain", **arrs)
 
 
+def g9():
+    """Evaluation metrics: the reference's anaysis/metrics.py (numpy + scikit-learn 1.7.2, both installed here) on
+    seeded class-1 probabilities with ties on the threshold grid."""
+    sys.path.insert(0, REF)
+    from anaysis import metrics as am
+    probs, labels = R.eval_probs_labels("g9", 4000)
+    (acc, precision, recall, f1, ap, auroc, confmat, pr_curve, roc_curve, mcc, p_t, r_t, acc_t, f1_t) = am.calculate_MORE_metrics(probs, labels)
+    arrs = {"at05": np.array([acc, precision, recall, f1]), "ap": np.array(ap), "auroc": np.array(auroc), "confmat": np.array(confmat),
+            "mcc": np.array(mcc), "precision_t": np.array(p_t), "recall_t": np.array(r_t), "acc_t": np.array(acc_t), "f1_t": np.array(f1_t),
+            "thresholds": np.array(am.THRESHOLDS)}
+    a2 = am.calculate_metrics(probs, labels)     # (acc, precision, recall, f1, mAP, auc)
+    arrs["calculate_metrics"] = np.array(a2, dtype=np.float64)
+    from sklearn.metrics import auc as sk_auc
+    arrs["mcc_auc"] = np.array(sk_auc(am.THRESHOLDS, mcc))   # engine_for_frame_finetuning.py:635
+    save("g9_eval_metrics", **arrs)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -466,7 +483,7 @@ def main():
     torch.set_num_threads(8)
     ris, mf, mg = import_reference()
     jobs = {"g1": lambda: g1(mf), "g2": lambda: g2(mf), "g3": lambda: g3(mf), "g4": lambda: g4(mf, ris),
-            "g5": g5, "g6": lambda: g6(mg), "g7": lambda: g7(ris), "g8": lambda: g8(mf)}
+            "g5": g5, "g6": lambda: g6(mg), "g7": lambda: g7(ris), "g8": lambda: g8(mf), "g9": g9}
     for k, fn in jobs.items():
         if a.only and a.only != k:
             continue
