@@ -95,6 +95,11 @@ class DataParallel(nn.Module):
             while o >= self.buckets[bi]["hi"]:
                 bi += 1
             self._bucket_of[id(p)] = bi
+        # gloo with GPU tensors (debugging / single-GPU tests of the N > 1 path) stages through host memory and was observed to
+        # read the bucket before the kernels queued on the current stream had written it: drain the stream first.  RCCL ("nccl")
+        # orders its kernels after the current stream itself.
+        self._drain_first = bool(dist.is_initialized() and dist.get_backend(self.pg) == "gloo" and self.flat_grad.is_cuda)
+        self._announced = set()
         self._works = []
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in order]
         self.space.install_sinks(self._on_grad)  # GPU: dW GEMMs accumulate in place and call _on_grad themselves
@@ -105,12 +110,21 @@ class DataParallel(nn.Module):
         self.space.rehome_grad(p)  # someone called optimizer.zero_grad(set_to_none=True): autograd allocated a fresh tensor
         if self.world == 1 or not self.require_sync:
             return
+        # A parameter can be announced twice in one backward pass: by the kernel-side gradient sink (ops.linear_dw /
+        # layernorm_bwd_sunk, right after the in-place write) and again by autograd's post-accumulate hook, which torch also runs
+        # for inputs whose Function.backward returned None.  Count it once, or a bucket would be exchanged before its last
+        # gradient has been written.
+        if id(p) in self._announced:
+            return
+        self._announced.add(id(p))
         b = self.buckets[self._bucket_of[id(p)]]
         b["ready"] += 1
         if b["ready"] == b["n"]:
             b["ready"] = 0
             view = self.flat_grad[b["lo"]:b["hi"]]
             view.div_(self.world)  # mean; pre-division keeps the sum in range and works for gloo (no AVG op)
+            if self._drain_first:
+                torch.cuda.current_stream().synchronize()
             self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def forward(self, *args, **kwargs):
@@ -121,16 +135,20 @@ class DataParallel(nn.Module):
         for w in self._works:
             w.wait()
         self._works.clear()
+        self._announced.clear()
         for b in self.buckets:  # a parameter that received no gradient this step leaves its bucket incomplete
             if b["ready"]:
                 b["ready"] = 0
                 view = self.flat_grad[b["lo"]:b["hi"]]
                 view.div_(self.world)
+                if self._drain_first:
+                    torch.cuda.current_stream().synchronize()
                 dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg)
 
     def zero_grad(self, set_to_none: bool = False):
         """Gradients are views into the flat buffer and must stay allocated: zero in place."""
         self.flat_grad.zero_()
+        self._announced.clear()
 
     def grad_sumsq_buffer(self):
         return self.flat_grad

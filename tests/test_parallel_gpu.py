@@ -1,0 +1,108 @@
+"""world_size-2 run of the REAL training step on the GPU: two processes share cuda:0 and exchange gradients over gloo (RCCL needs one
+GPU per rank, the box has one).  Checks the N > 1 path end to end on the HIP kernels: parameter broadcast, gradient sinks feeding the
+bucket logic, bucketed all-reduce = mean over ranks, fused AdamW on the averaged gradients -- against a single-process step on the
+concatenated batch (mean of per-rank mean-loss gradients == gradient of the global mean loss)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model(seed):
+    import simple_tad_amd as T
+    torch.manual_seed(seed)
+    return T.VisionTransformer(img_size=32, patch_size=16, embed_dim=128, depth=2, num_heads=2, mlp_ratio=4, qkv_bias=True, all_frames=4,
+                               tubelet_size=2, num_classes=2, init_scale=1.0, drop_path_rate=0.0)
+
+
+def _data():
+    g = torch.Generator().manual_seed(7)
+    return torch.randn(8, 3, 4, 32, 32, generator=g), torch.randint(0, 2, (8,), generator=g)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    import torch.nn.functional as F
+    from simple_tad_amd import engine as E
+    from simple_tad_amd.parallel import DataParallel
+    dist.init_process_group(backend="gloo", init_method="env://", world_size=world, rank=rank)
+    try:
+        m = _model(seed=100 + rank).cuda()           # different init per rank: the broadcast must make them identical
+        dp = DataParallel(m, bucket_mb=0.25)          # several buckets
+        opt = E.create_optimizer(dp, lr=1e-2, weight_decay=0.05, layer_decay=0.75)
+        scaler = E.NativeScalerWithGradNormCount(dp)
+        x, y = _data()
+        xs, ys = x[rank * 4:(rank + 1) * 4].cuda(), y[rank * 4:(rank + 1) * 4].cuda()
+        w0 = {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}  # numpy: pickled by value through the queue
+        m.train()
+        dp.zero_grad()
+        loss = F.cross_entropy(dp(xs), ys)
+        loss.backward()
+        dp.finish()
+        grads = {k: p.grad.detach().cpu().numpy().copy() for k, p in m.named_parameters()}
+        dp.zero_grad()
+        norm = scaler(F.cross_entropy(dp(xs), ys), opt, parameters=list(m.parameters()))
+        w1 = {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}
+        q.put((rank, len(dp.buckets), w0, grads, float(norm), w1))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_match_single_process_step():
+    import torch.nn.functional as F
+    from simple_tad_amd import engine as E
+    from simple_tad_amd.parallel import DataParallel
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    t = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}  # noqa: E731
+    (_, nb0, w00, g0, n0, w10), (_, nb1, w01, g1, n1, w11) = [(r[0], r[1], t(r[2]), t(r[3]), r[4], t(r[5])) for r in res]
+    assert nb0 >= 3 and nb0 == nb1
+    for k in w00:
+        assert torch.equal(w00[k], w01[k]), k          # broadcast: replicas start identical (rank 0's weights)
+        assert torch.equal(g0[k], g1[k]) if k in g0 else True
+        assert torch.equal(w10[k], w11[k]), k          # and stay identical after the step
+    assert n0 == n1
+    # single-process reference on the full batch with rank 0's initial weights
+    m = _model(seed=100).cuda()
+    m.load_state_dict(w00)
+    dp = DataParallel(m)
+    opt = E.create_optimizer(dp, lr=1e-2, weight_decay=0.05, layer_decay=0.75)
+    scaler = E.NativeScalerWithGradNormCount(dp)
+    x, y = _data()
+    m.train()
+    dp.zero_grad()
+    F.cross_entropy(dp(x.cuda()), y.cuda()).backward()
+    errs = {}
+    for k, p in m.named_parameters():
+        ref = p.grad.detach().cpu()
+        errs[k] = ((g0[k] - ref).norm() / ref.norm().clamp_min(1e-12)).item()
+    bad = {k: round(e, 6) for k, e in errs.items() if e >= 1e-5}
+    assert not bad, bad   # the kernels are batch-invariant: mean of per-rank gradients == full-batch gradient to f32 rounding
+    dp.zero_grad()
+    norm = scaler(F.cross_entropy(dp(x.cuda()), y.cuda()), opt, parameters=list(m.parameters()))
+    assert abs(float(norm) - n0) < 1e-5 * n0
+    for k, v in m.state_dict().items():
+        d = (w10[k] - w00[k]).norm()
+        assert ((w10[k] - v.cpu()).norm() <= 1e-3 * d + 1e-7), k   # same update
