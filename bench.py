@@ -96,6 +96,8 @@ def main():
         if args.gpus > 1 and world == 1:
             sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the MI355X path has no CPU fallback)"
+    if os.environ.get("TAD_DIST_BACKEND") == "gloo":  # debugging aid: several ranks share the visible GPUs
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     _lib.load()

@@ -39,7 +39,8 @@ def init_distributed_mode(backend: Optional[str] = None):
         return False, 0, 1, int(env.get("LOCAL_RANK", 0))
     rank, world, local = int(env["RANK"]), int(env["WORLD_SIZE"]), int(env.get("LOCAL_RANK", 0))
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # TAD_DIST_BACKEND=gloo: debugging aid -- run the N > 1 path with several ranks on fewer GPUs (RCCL needs one GPU per rank)
+        backend = env.get("TAD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
         torch.cuda.set_device(local)
     env.setdefault("MASTER_ADDR", "127.0.0.1")
