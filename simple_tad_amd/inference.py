@@ -21,7 +21,8 @@ IMAGENET_STD = (0.229, 0.224, 0.225)
 
 
 class SlidingWindow:
-    def __init__(self, model: torch.nn.Module, mean=IMAGENET_MEAN, std=IMAGENET_STD, bgr: bool = True, device: Optional[torch.device] = None):
+    def __init__(self, model: torch.nn.Module, mean=IMAGENET_MEAN, std=IMAGENET_STD, bgr: bool = True, device: Optional[torch.device] = None,
+                 use_graph: bool = False):
         pe = model.patch_embed
         self.model = model
         self.T = int(model.num_frames)
@@ -33,6 +34,12 @@ class SlidingWindow:
         self.ring = torch.zeros((1, self.T, self.H, self.W, 3), dtype=torch.uint8, device=self.device)
         self.count = 0   # frames pushed so far
         self.start = 0   # ring slot of the oldest frame
+        # Batch-1 inference is launch-bound (~150 short launches per window): with use_graph the forward is captured once per ring
+        # offset into a HIP graph (the ring buffer is a static input; the offset is a launch constant, hence one graph per offset,
+        # all sharing one memory pool) and replayed afterwards.
+        self.use_graph = bool(use_graph)
+        self._graphs = {}
+        self._pool = None
 
     @property
     def full(self) -> bool:
@@ -59,7 +66,23 @@ class SlidingWindow:
         self.model.eval()
         self.model.patch_embed.t_offset = self.start
         try:
-            return self.model(self.ring)
+            if not self.use_graph:
+                return self.model(self.ring)
+            ent = self._graphs.get(self.start)
+            if ent is None:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):  # warm-up outside the capture (weight copies, workspaces, lazy init)
+                    self.model(self.ring)
+                torch.cuda.current_stream().wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                if self._pool is None:
+                    self._pool = torch.cuda.graph_pool_handle()
+                with torch.cuda.graph(g, pool=self._pool):
+                    out = self.model(self.ring)
+                ent = self._graphs[self.start] = (g, out)
+            ent[0].replay()
+            return ent[1].clone()
         finally:
             self.model.patch_embed.t_offset = 0
 

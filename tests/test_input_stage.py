@@ -79,6 +79,22 @@ def test_model_on_uint8_frames_and_sliding_window():
                 want = m(win.cuda())
             assert torch.equal(outs[-1], want), i    # same patch matrix bits -> same logits bits
     assert len(outs) == 6 and not torch.equal(outs[0], outs[-1])
+    # HIP-graph replay (one captured graph per ring offset): same bits as the eager path, also on the second lap of the ring
+    swg = SlidingWindow(m, MEAN, STD, bgr=True, use_graph=True)
+    got = []
+    for lap in range(2):
+        for f in frames[:8]:
+            swg.push(f)
+            if swg.full:
+                got.append(swg.predict())
+    swe = SlidingWindow(m, MEAN, STD, bgr=True)
+    want = []
+    for lap in range(2):
+        for f in frames[:8]:
+            swe.push(f)
+            if swe.full:
+                want.append(swe.predict())
+    assert len(got) == 13 and len(swg._graphs) == 4 and all(torch.equal(a, b) for a, b in zip(got, want))
     with pytest.raises(TypeError):
         sw.push(np.zeros((16, 16, 3), np.uint8))
     # training from uint8 clips (the loaders' [T,H,W,C] RGB buffers, dota.py:312): gradients equal the float path's
