@@ -84,29 +84,77 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 }
 
 // ---- fast-mode GELU for the GEMM epilogues: no transcendental, packed f32 math (v_pk_fma_f32 does two elements per issue).
-// The epilogues of the fc1 / fc2-dX GEMMs are VALU-bound (128 outputs per lane; the A-S form above costs ~76 issue cycles per
-// element = as long as half the K loop); these forms cost ~38.  Coefficients: tools/fit_gelu_poly.py (Chebyshev fit of
-// (f(x) - 0.5)/x in x^2 on |x| <= XMAX, Horner in t = 2x^2/XMAX^2 - 1).  Errors (f32 evaluation): |Phi| <= 3.9e-7, gelu <= 1.9e-6,
-// gelu' <= 7e-6 absolute -- three orders below the bf16 rounding of the values these epilogues read and write.  The precise mode
-// keeps the A-S form.
+// The epilogues of the fc1 / fc2-dX GEMMs are VALU-bound (128 outputs per lane).  Measured on gfx950 (tools/micro/valu_rate.hip):
+// a DEPENDENT v_pk_fma_f32 (or v_fma_f32) issues every 9 cycles per wave, independent ones every ~5.4, at one or two waves per
+// SIMD alike -- so the Horner recurrences of the 4 element pairs of a row are evaluated side by side (coefficient-major order),
+// never one chain after the other.  Coefficients: tools/fit_gelu_poly.py (Chebyshev fit of (f(x) - 0.5)/x in x^2 on |x| <= XMAX,
+// Horner in t = 2x^2/XMAX^2 - 1).  Errors (f32 evaluation): |Phi| <= 2.4e-5, gelu <= 2.4e-5 * max(1, |x|), gelu' <= 1.1e-4 absolute --
+// 20 to 100 times below the bf16 rounding (2^-9 relative) of the values these epilogues read and write.  The precise mode keeps
+// the A-S form above.
 typedef __attribute__((ext_vector_type(2))) float f32x2;
-constexpr float PHI_XMAX = 5.0f;
-constexpr float PHI_C[13] = {1.413638185e-01f, -7.029590887e-02f, 5.151792974e-02f, -4.045128240e-02f, 3.147675865e-02f, -2.321312828e-02f, 1.623608981e-02f, -1.130712491e-02f, 6.766527505e-03f, -2.526916729e-03f, 1.374596151e-03f, -1.676730979e-03f, 7.353763888e-04f};
-constexpr float DGELU_XMAX = 5.5f;
-constexpr float DGELU_C[14] = {1.287606817e-01f, -6.574511122e-02f, 5.352302286e-02f, -5.354277321e-02f, 6.254520933e-02f, -7.080669140e-02f, 6.123300602e-02f, -6.376653697e-02f, 1.008177666e-01f, -7.514079910e-02f, -9.145315790e-03f, 6.300958162e-04f, 4.666087374e-02f, -2.511548108e-02f};
+constexpr float PHI_XMAX = 4.0f;
+constexpr float PHI_C[9] = {1.759501642e-01f, -8.430131655e-02f, 5.591522291e-02f, -3.713346277e-02f, 2.266773498e-02f, -1.154668287e-02f, 5.828486749e-03f, -3.991263335e-03f, 1.605170928e-03f};
+constexpr float DGELU_XMAX = 4.5f;
+constexpr float DGELU_C[10] = {1.594574418e-01f, -9.003904569e-02f, 8.571837549e-02f, -9.350841452e-02f, 1.078448091e-01f, -9.557466143e-02f, 4.249439465e-02f, -3.356380937e-02f, 5.896066889e-02f, -3.068672777e-02f};
 
 __device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
-template <int N>
-__device__ __forceinline__ f32x2 half_plus_x_poly2(f32x2 x, const float (&c)[N], float xmax) {
-  const f32x2 xc = f32x2{__builtin_amdgcn_fmed3f(x[0], -xmax, xmax), __builtin_amdgcn_fmed3f(x[1], -xmax, xmax)};
-  const f32x2 t = __builtin_elementwise_fma(xc * xc, splat2(2.0f / (xmax * xmax)), splat2(-1.0f));
-  f32x2 r = splat2(c[N - 1]);
+// out[i] = 0.5 + xc[i] * P(t[i]) for W independent element pairs, coefficient-major so that the W recurrences interleave
+template <int N, int W>
+__device__ __forceinline__ void half_plus_x_poly2(const f32x2 (&x)[W], f32x2 (&out)[W], const float (&c)[N], float xmax) {
+  f32x2 xc[W], t[W], r[W];
 #pragma unroll
-  for (int i = N - 2; i >= 0; --i) r = __builtin_elementwise_fma(r, t, splat2(c[i]));
-  return __builtin_elementwise_fma(xc, r, splat2(0.5f));
+  for (int i = 0; i < W; ++i) {
+    xc[i] = f32x2{__builtin_amdgcn_fmed3f(x[i][0], -xmax, xmax), __builtin_amdgcn_fmed3f(x[i][1], -xmax, xmax)};
+    t[i] = __builtin_elementwise_fma(xc[i] * xc[i], splat2(2.0f / (xmax * xmax)), splat2(-1.0f));
+    r[i] = splat2(c[N - 1]);
+  }
+#pragma unroll
+  for (int k = N - 2; k >= 0; --k) {
+#pragma unroll
+    for (int i = 0; i < W; ++i) r[i] = __builtin_elementwise_fma(r[i], t[i], splat2(c[k]));
+  }
+#pragma unroll
+  for (int i = 0; i < W; ++i) out[i] = __builtin_elementwise_fma(xc[i], r[i], splat2(0.5f));
 }
-__device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) { return x * half_plus_x_poly2(x, PHI_C, PHI_XMAX); }
-__device__ __forceinline__ f32x2 gelu_grad_fast2(f32x2 x) { return half_plus_x_poly2(x, DGELU_C, DGELU_XMAX); }
+// v[0..2W) -> gelu(v) in place
+template <int W>
+__device__ __forceinline__ void gelu_fast_row(float* v) {
+  f32x2 x[W], ph[W];
+#pragma unroll
+  for (int i = 0; i < W; ++i) x[i] = f32x2{v[2 * i], v[2 * i + 1]};
+  half_plus_x_poly2(x, ph, PHI_C, PHI_XMAX);
+#pragma unroll
+  for (int i = 0; i < W; ++i) {
+    const f32x2 y = x[i] * ph[i];
+    v[2 * i] = y[0];
+    v[2 * i + 1] = y[1];
+  }
+}
+// v[0..2W) *= gelu'(h), h given as W packed bf16 pairs
+template <int W>
+__device__ __forceinline__ void gelu_grad_fast_row(float* v, const uint32_t* hw) {
+  f32x2 x[W], g[W];
+#pragma unroll
+  for (int i = 0; i < W; ++i) x[i] = f32x2{__uint_as_float(hw[i] << 16), __uint_as_float(hw[i] & 0xffff0000u)};
+  half_plus_x_poly2(x, g, DGELU_C, DGELU_XMAX);
+#pragma unroll
+  for (int i = 0; i < W; ++i) {
+    v[2 * i] *= g[i][0];
+    v[2 * i + 1] *= g[i][1];
+  }
+}
+__device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
+  const f32x2 xs[1] = {x};
+  f32x2 ph[1];
+  half_plus_x_poly2(xs, ph, PHI_C, PHI_XMAX);
+  return x * ph[0];
+}
+__device__ __forceinline__ f32x2 gelu_grad_fast2(f32x2 x) {
+  const f32x2 xs[1] = {x};
+  f32x2 g[1];
+  half_plus_x_poly2(xs, g, DGELU_C, DGELU_XMAX);
+  return g[0];
+}
 
 // Bijective XCD-aware block remap (8 XCDs, blocks dealt round-robin): consecutive logical ids land on one XCD.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -38,6 +38,9 @@ struct GemmNT {
   int epi;
   int M, N, K;
   int debug;  // ablation (TAD_GEMM_DEBUG, timing only, wrong results): 1 = no DMA inside the K loop, 2 = no MFMA, 4 = no epilogue
+  int stagger_ticks;  // persistent kernel: span (10 ns ticks of s_memrealtime) over which the workgroups of an XCD spread their start
+  int stagger_group;  // workgroups of an XCD start in groups of this many (power of two)
+  unsigned long long* stamps;  // debug timeline (tad_linear_debug_stamps): per workgroup 64 slots of 4 x s_memrealtime, or null
 };
 
 constexpr int BK = 64;             // K-tile depth (bf16 elements) -> 128-byte LDS rows
@@ -71,12 +74,24 @@ __device__ __forceinline__ void block_barrier() {
   asm volatile("" ::: "memory");
 }
 
+// barrier between LDS producers and consumers that leaves global stores / loads in flight
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
 // swizzle of the 16-byte chunk index for 64-byte LDS rows (K-tile depth 32): conflict-free for the same fragment reads
 __device__ __forceinline__ int sw_nt32(int row) { return ((row >> 3) & 1) << 1; }
 template <int BKT>
 __device__ __forceinline__ int sw_rows(int row) { return BKT == 64 ? sw_nt(row) : sw_nt32(row); }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int BKT, int MIN_WAVES, int EPI, bool OUT_BF16>
+// PERSIST: one workgroup per CU walks a strided list of tiles (see the comment at the tile loop).
+// DIRECT: the epilogue runs on the accumulator registers and stores straight from the MFMA layout (16 rows x 64 contiguous bytes
+// per store instruction); otherwise the accumulators are transposed through the LDS first (whole rows per instruction).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int BKT, int MIN_WAVES, int EPI, bool OUT_BF16, bool PERSIST, bool DIRECT>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kernel(const GemmNT p) {
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int ROWB = BKT * 2;               // bytes per LDS row
@@ -89,8 +104,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
   constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
   constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
   static_assert(BM % (RPP * NW) == 0 && BN % (RPP * NW) == 0, "tile rows must split into whole DMA pieces per wave");
-  constexpr int EPI_BYTES = (BM < 128 ? BM : 128) * (BN * 4 + 16);  // one epilogue chunk: 128 rows of f32, padded stride
-  constexpr int LDS_BYTES = STAGES * STAGE_BYTES > EPI_BYTES ? STAGES * STAGE_BYTES : EPI_BYTES;
+  // one epilogue chunk: CROWS rows of f32, padded stride.  The persistent kernel keeps ring slot 0 out of the epilogue's way
+  // (the next tile's first K-tile lands there meanwhile), so its chunks must fit the LDS behind slot 0.
+  constexpr int CROWS = BM < 128 ? BM : (((PERSIST && BN > 128) || NW == 4) ? 64 : 128);
+  constexpr int EPI_OFF = PERSIST ? STAGE_BYTES : 0;
+  constexpr int EPI_BYTES = DIRECT ? 0 : CROWS * (BN * 4 + 16);
+  constexpr int LDS_BYTES = STAGES * STAGE_BYTES > EPI_OFF + EPI_BYTES ? STAGES * STAGE_BYTES : EPI_OFF + EPI_BYTES;
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
   __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
 
   const int tid = threadIdx.x;
@@ -101,32 +121,62 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
   // Tile order: the XCD remap gives each XCD (private 4 MiB L2) a contiguous range of logical tile ids; inside that range the
   // ids sweep GROUP_M row-panels for one column-panel before moving to the next column-panel, so the ~32 workgroups that are
   // resident on an XCD at any time touch only GROUP_M A-panels and ~32/GROUP_M W-panels (both stay L2-resident).
+  //
+  // PERSIST: the grid is one workgroup per CU (a multiple of 8).  Workgroup (xcd = blockIdx & 7, j = blockIdx >> 3) walks the
+  // ids first + j, first + j + step, ... of its XCD's range, so at any time the XCD works on ~step consecutive ids as above.
+  // Two things are gained over one launch-scheduled workgroup per tile:
+  //  (1) the epilogue is HBM-bound when every CU reaches it at the same time (all K loops have the same length, so a plain
+  //      grid stays in lock-step: 64 MB of stores per round of fc1 tiles at ~5 TB/s while the matrix pipes idle, then a K loop
+  //      during which HBM idles).  The workgroups therefore start `stagger` apart and keep that phase difference, which spreads
+  //      the store bursts over the K loops of the other CUs.  Later starters are the ones with fewer tiles in their list.
+  //  (2) the first K-tile of the next tile is fetched under the epilogue.
   constexpr int GROUP_M = 8;
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
-  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   const int per_group = GROUP_M * tiles_n;
-  const int grp = tile / per_group;
-  const int first_m = grp * GROUP_M;
-  const int gsz = min(tiles_m - first_m, GROUP_M);
-  const int in_grp = tile - grp * per_group;
-  const int tm = first_m + in_grp % gsz, tn = in_grp / gsz;
-  const int m0 = tm * BM, n0 = tn * BN;
+  int t_cur, t_end, t_step;
+  if (PERSIST) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    t_cur = xcd_remap(xcd, tiles_m * tiles_n) + j;  // first id of this XCD's range (+ j)
+    t_end = xcd_remap(xcd, tiles_m * tiles_n) + (tiles_m * tiles_n >> 3) + ((xcd < ((tiles_m * tiles_n) & 7)) ? 1 : 0);
+    t_step = gridDim.x >> 3;
+    if (p.stagger_ticks > 0) {
+      const int ph = j & ~(p.stagger_group - 1);
+      const uint64_t wait = (uint64_t)p.stagger_ticks * ph / t_step;
+      const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+      while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+    }
+  } else {
+    t_cur = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    t_end = t_cur + 1;
+    t_step = 1;
+  }
+  int m0, n0;
+#define DECODE_TILE(tile)                                  \
+  {                                                        \
+    const int grp = (tile) / per_group;                    \
+    const int first_m = grp * GROUP_M;                     \
+    const int gsz = min(tiles_m - first_m, GROUP_M);       \
+    const int in_grp = (tile) - grp * per_group;           \
+    m0 = (first_m + in_grp % gsz) * BM;                    \
+    n0 = (in_grp / gsz) * BN;                              \
+  }
 
-    const int a_bytes = (int)((int64_t)p.M * p.K * 2), b_bytes = (int)((int64_t)p.N * p.K * 2);
+  const int a_bytes = (int)((int64_t)p.M * p.K * 2), b_bytes = (int)((int64_t)p.N * p.K * 2);
 
   // ---- DMA addressing: one wave-instruction fills RPP LDS rows (1 KiB); lane -> (row lane/CPR, physical chunk lane%CPR)
   const int drow = lane / CPR, dchunk = lane % CPR;
   uint32_t a_off[BM / (RPP * NW)], b_off[BN / (RPP * NW)];
-#pragma unroll
-  for (int i = 0; i < BM / (RPP * NW); ++i) {
-    const int row = (i * NW + wave) * RPP + drow;
-    a_off[i] = (uint32_t)(m0 + row) * (uint32_t)(p.K * 2) + (uint32_t)((dchunk ^ sw_rows<BKT>(row)) * 16);
-  }
-#pragma unroll
-  for (int i = 0; i < BN / (RPP * NW); ++i) {
-    const int row = (i * NW + wave) * RPP + drow;
-    b_off[i] = (uint32_t)(n0 + row) * (uint32_t)(p.K * 2) + (uint32_t)((dchunk ^ sw_rows<BKT>(row)) * 16);
+#define TILE_OFFSETS()                                                                                                 \
+  {                                                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < BM / (RPP * NW); ++i) {                                                      \
+      const int row = (i * NW + wave) * RPP + drow;                                                                    \
+      a_off[i] = (uint32_t)(m0 + row) * (uint32_t)(p.K * 2) + (uint32_t)((dchunk ^ sw_rows<BKT>(row)) * 16);           \
+    }                                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < BN / (RPP * NW); ++i) {                                                      \
+      const int row = (i * NW + wave) * RPP + drow;                                                                    \
+      b_off[i] = (uint32_t)(n0 + row) * (uint32_t)(p.K * 2) + (uint32_t)((dchunk ^ sw_rows<BKT>(row)) * 16);           \
+    }                                                                                                                  \
   }
 #define STAGE_NT(buf, kt) \
   stage_tile<BM / (RPP * NW), NW>(p.A, a_bytes, lds + (buf) * STAGE_BYTES, a_off, (uint32_t)(kt) * ROWB, wave); \
@@ -158,20 +208,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
     b_sw[j] = sw_rows<BKT>(row);
   }
 
-  // accumulators start from the bias (a per-column constant = per (j, kq, r) constant in this layout): no bias add later
-  f32x4 acc[MREP][NREP];
-#pragma unroll
-  for (int j = 0; j < NREP; ++j) {
-    const int nc = n0 + wn * WTN + (OUT_BF16 ? (32 * (j >> 1) + 8 * kq + 4 * (j & 1)) : (16 * j + 4 * kq));
-    f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (EPI != EPI_DGELU && p.bias && nc < p.N) {
-      const float4 t = *reinterpret_cast<const float4*>(p.bias + nc);
-      b4 = f32x4{t.x, t.y, t.z, t.w};
-    }
-#pragma unroll
-    for (int i = 0; i < MREP; ++i) acc[i][j] = b4;
-  }
-
   const int nk = p.K / BKT;
 #define FRAG_A(dst, base, ks) \
   _Pragma("unroll") for (int i = 0; i < MREP; ++i)  \
@@ -189,16 +225,139 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
     _Pragma("unroll") for (int j = 0; j < NREP; ++j) asm volatile("" ::"v"(bfr_[j]));                    \
   }
   const bool late = wave >= NW / 2;  // wave-uniform (scalar branches); the MFMA code is shared by both halves
-  {
+
+  // epilogue geometry (see the epilogue below)
+  constexpr int MREP_C = CROWS / (16 * WAVES_M);     // m-fragments each wave contributes to a chunk
+  constexpr int NCHUNK = MREP / MREP_C;
+  constexpr int CSTRIDE = BN * 4 + 16;               // padded row stride (bytes): conflict-free 16-byte writes
+  constexpr int CPL = OUT_BF16 ? 8 : 4;              // columns per lane in the row pass (16-byte stores)
+  constexpr int LPR = BN / CPL, RPI = 64 / LPR;      // lanes per row, rows per wave-instruction
+  constexpr int NR = CROWS / (NW * RPI);             // row-instructions per wave per chunk
+  constexpr int BATCH_MAX = 4;  // rows of LDS reads in flight per lane (register budget: the other chunks' accumulators are live)
+  constexpr int BATCH = NR < BATCH_MAX ? NR : BATCH_MAX;
+  static_assert(MREP % MREP_C == 0 && MREP_C >= 1 && CROWS % (NW * RPI) == 0 && NR % BATCH == 0, "chunking");
+  char* const epi_lds = lds + EPI_OFF;
+
+  DECODE_TILE(t_cur);
+  TILE_OFFSETS();
+  if (0 < nk) { STAGE_NT(0, 0); }
+  int stamp_i = 0;
+  bool first_tile = true;
+#define STAMP(k) \
+  if (p.stamps && tid == 0 && stamp_i < 64) p.stamps[((size_t)blockIdx.x * 64 + stamp_i) * 16 + (k)] = __builtin_amdgcn_s_memrealtime()
+  for (;;) {
+  STAMP(0);
+  const int em0 = m0, en0 = n0;  // this tile; (m0, n0) move on to the next one when its first K-tile is prefetched
+  // Global accesses of the epilogue's row pass are raw buffer loads / stores: rows >= M fall outside the descriptor (loads return
+  // 0, stores are dropped), columns >= N get an out-of-range offset explicitly.  No per-lane branches, and the barriers of the
+  // epilogue wait for LDS traffic only (lgkmcnt) -- a __syncthreads() would also drain every store issued so far (vmcnt(0)).
+  constexpr uint32_t OOB = 0x80000000u;  // >= any descriptor size accepted by the launcher
+  constexpr int ESZ = OUT_BF16 ? 2 : 4;
+  const uint32_t mn_elems = (uint32_t)p.M * (uint32_t)p.N;
+  const auto c_rs = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)(mn_elems * ESZ), 0x00020000);
+  const auto pre_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.preact, 0, (int)(mn_elems * 2), 0x00020000);
+  const auto h_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.dgelu_h, 0, (int)(mn_elems * 2), 0x00020000);
+  const auto res_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.residual, 0, (int)((p.res_mod > 0 ? (uint32_t)p.res_mod * (uint32_t)p.N : mn_elems) * 4), 0x00020000);
+  const int col = CPL * (lane % LPR);
+  const int n = en0 + col;
+  const bool nvalid = n < p.N;
+  const bool full = (n + CPL <= p.N);             // N % 4 == 0: a bf16 lane has either 8 or 4 valid columns
+  const bool n8 = CPL == 4 || (p.N & 7) == 0;     // uniform: every valid lane is a full lane -> one 16-byte access per row
+  // What the epilogue READS besides the accumulators (f32 residual rows / bf16 pre-activation rows) is fetched one chunk ahead:
+  // chunk 0 during the last K-tile of the main loop, chunk q + 1 while chunk q is processed.  Fetched on demand, each batch of
+  // rows exposed a full HBM latency (4 batches x ~3 us per 256 x 128 f32 tile: longer than that tile's K loop at K = 768).
+  constexpr bool HAS_EXTRA = (EPI == EPI_RESIDUAL || EPI == EPI_DGELU);
+  constexpr int EXW = (EPI == EPI_RESIDUAL) ? CPL / 4 : 1;
+  constexpr int NJ = OUT_BF16 ? NREP / 2 : NREP;  // DIRECT: 16-byte column groups per lane and m-fragment
+  u32x4 extra[2][HAS_EXTRA ? (DIRECT ? NJ : NR) : 1][EXW];
+  // DIRECT addressing: acc[i][j] of lane (c, kq) = out[em0 + wm*WTM + 16i + c][en0 + wn*WTN + cg(j) .. +3], cg as in the LDS path
+#define DIRECT_COL(jj) (en0 + wn * WTN + (OUT_BF16 ? 32 * (jj) + 8 * kq : 16 * (jj) + 4 * kq))
+#define ISSUE_EXTRA_D(i, buf)                                                                                           \
+  if (HAS_EXTRA && (EPI != EPI_RESIDUAL || p.residual)) {                                                               \
+    const int m = em0 + wm * WTM + 16 * (i) + c;                                                                        \
+    _Pragma("unroll") for (int jj = 0; jj < NJ; ++jj) {                                                                 \
+      const int nn = DIRECT_COL(jj);                                                                                    \
+      const bool fulld = nn + CPL <= p.N;                                                                               \
+      uint32_t o = nn < p.N ? (uint32_t)m * (uint32_t)p.N + (uint32_t)nn : OOB;                                         \
+      if (EPI == EPI_RESIDUAL) {                                                                                        \
+        if (p.res_mod > 0) o = (nn < p.N && m < p.M) ? (uint32_t)(m % p.res_mod) * (uint32_t)p.N + (uint32_t)nn : OOB;  \
+        const uint32_t rb = o == OOB ? OOB : o * 4;                                                                     \
+        extra[buf][jj][0] = __builtin_amdgcn_raw_buffer_load_b128(res_rs, rb, 0, 0);                                    \
+        if (CPL == 8) extra[buf][jj][EXW - 1] = __builtin_amdgcn_raw_buffer_load_b128(res_rs, fulld ? rb + 16 : OOB, 0, 0); \
+      } else {                                                                                                          \
+        const uint32_t hb = o == OOB ? OOB : o * 2;                                                                     \
+        if (CPL == 8) {                                                                                                 \
+          if (n8) extra[buf][jj][0] = __builtin_amdgcn_raw_buffer_load_b128(h_rs, hb, 0, 0);                            \
+          else {                                                                                                        \
+            const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(h_rs, hb, 0, 0);                                      \
+            const u32x2 hi = __builtin_amdgcn_raw_buffer_load_b64(h_rs, fulld ? hb + 8 : OOB, 0, 0);                    \
+            extra[buf][jj][0] = u32x4{lo[0], lo[1], hi[0], hi[1]};                                                      \
+          }                                                                                                             \
+        } else {                                                                                                        \
+          const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(h_rs, hb, 0, 0);                                        \
+          extra[buf][jj][0] = u32x4{lo[0], lo[1], 0u, 0u};                                                              \
+        }                                                                                                               \
+      }                                                                                                                 \
+    }                                                                                                                   \
+  }
+#define ISSUE_EXTRA(q, buf)                                                                                             \
+  if (HAS_EXTRA && (EPI != EPI_RESIDUAL || p.residual)) {                                                               \
+    _Pragma("unroll") for (int r = 0; r < NR; ++r) {                                                                    \
+      const int lr = (r * NW + wave) * RPI + lane / LPR;                                                                \
+      const int m = em0 + (lr / (16 * MREP_C)) * WTM + 16 * MREP_C * (q) + lr % (16 * MREP_C);                          \
+      uint32_t o = nvalid ? (uint32_t)m * (uint32_t)p.N + (uint32_t)n : OOB;                                            \
+      if (EPI == EPI_RESIDUAL) {                                                                                        \
+        if (p.res_mod > 0) o = (nvalid && m < p.M) ? (uint32_t)(m % p.res_mod) * (uint32_t)p.N + (uint32_t)n : OOB;     \
+        const uint32_t rb = o == OOB ? OOB : o * 4;                                                                     \
+        extra[buf][r][0] = __builtin_amdgcn_raw_buffer_load_b128(res_rs, rb, 0, 0);                                     \
+        if (CPL == 8) extra[buf][r][EXW - 1] = __builtin_amdgcn_raw_buffer_load_b128(res_rs, full ? rb + 16 : OOB, 0, 0); \
+      } else {                                                                                                          \
+        const uint32_t hb = o == OOB ? OOB : o * 2;                                                                     \
+        if (CPL == 8) {                                                                                                 \
+          if (n8) extra[buf][r][0] = __builtin_amdgcn_raw_buffer_load_b128(h_rs, hb, 0, 0);                             \
+          else {                                                                                                        \
+            const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(h_rs, hb, 0, 0);                                      \
+            const u32x2 hi = __builtin_amdgcn_raw_buffer_load_b64(h_rs, full ? hb + 8 : OOB, 0, 0);                     \
+            extra[buf][r][0] = u32x4{lo[0], lo[1], hi[0], hi[1]};                                                       \
+          }                                                                                                             \
+        } else {                                                                                                        \
+          const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(h_rs, hb, 0, 0);                                        \
+          extra[buf][r][0] = u32x4{lo[0], lo[1], 0u, 0u};                                                               \
+        }                                                                                                               \
+      }                                                                                                                 \
+    }                                                                                                                   \
+  }
+  // accumulators start from the bias (a per-column constant = per (j, kq, r) constant in this layout): no bias add later
+  f32x4 acc[MREP][NREP];
 #pragma unroll
-    for (int st = 0; st < STAGES - 1; ++st)
-      if (st < nk) { STAGE_NT(st, st); }
+  for (int j = 0; j < NREP; ++j) {
+    const int nc = n0 + wn * WTN + (OUT_BF16 ? (32 * (j >> 1) + 8 * kq + 4 * (j & 1)) : (16 * j + 4 * kq));
+    f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (EPI != EPI_DGELU && p.bias && nc < p.N) {
+      const float4 t = *reinterpret_cast<const float4*>(p.bias + nc);
+      b4 = f32x4{t.x, t.y, t.z, t.w};
+    }
+#pragma unroll
+    for (int i = 0; i < MREP; ++i) acc[i][j] = b4;
+  }
+  {
+    // K-tile 0 is already on its way (issued before the loop, or under the previous tile's epilogue); with the DIRECT epilogue
+    // (which leaves the LDS alone) so are the other prologue stages of every tile but the first
+    if (!DIRECT || first_tile) {
+#pragma unroll
+      for (int st = 1; st < STAGES - 1; ++st)
+        if (st < nk) { STAGE_NT(st, st); }
+    }
+    first_tile = false;
     int rd = 0, wr = STAGES - 1;
     for (int kt = 0; kt < nk; ++kt) {
       // tile kt has landed once all but the younger stages' DMAs of this wave are done; the barrier then (a) publishes every
       // wave's part of tile kt and (b) proves all waves finished reading tile kt-1, whose buffer the next DMA overwrites
       wait_stage<LOADS>(min(STAGES - 2, nk - 1 - kt));
       block_barrier();
+      if (HAS_EXTRA && kt == nk - 1) {
+        if (DIRECT) { ISSUE_EXTRA_D(0, 0); } else { ISSUE_EXTRA(0, 0); }
+      }
       const char* sa = lds + rd * STAGE_BYTES;
       const char* sb = sa + A_BYTES;
       const bool more = kt + STAGES - 1 < nk;
@@ -228,24 +387,91 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
   // a wave covers whole contiguous rows (512 B - 1 KiB runs).  The epilogue is VALU-bound (128 outputs per lane), so the
   // variant (EPI, OUT_BF16) is a template parameter, offsets are 32-bit, and loads are issued BATCH rows ahead because the CU
   // has only NW waves to cover HBM latency.
-  if ((p.debug & 4) && p.M > 1) return;
-  constexpr int CROWS = BM < 128 ? BM : 128;         // tile rows per chunk
-  constexpr int MREP_C = CROWS / (16 * WAVES_M);     // m-fragments each wave contributes to a chunk
-  constexpr int NCHUNK = MREP / MREP_C;
-  constexpr int CSTRIDE = BN * 4 + 16;               // padded row stride (bytes): conflict-free 16-byte writes
-  constexpr int CPL = OUT_BF16 ? 8 : 4;              // columns per lane in the row pass (16-byte stores)
-  constexpr int LPR = BN / CPL, RPI = 64 / LPR;      // lanes per row, rows per wave-instruction
-  constexpr int NR = CROWS / (NW * RPI);             // row-instructions per wave per chunk
-  constexpr int BATCH = NR < 8 ? NR : 8;
-  static_assert(MREP % MREP_C == 0 && MREP_C >= 1 && CROWS % (NW * RPI) == 0 && NR % BATCH == 0, "chunking");
-  const int col = CPL * (lane % LPR);
-  const int n = n0 + col;
-  const bool nvalid = n < p.N;
-  const bool full = (n + CPL <= p.N);  // N % 4 == 0: a bf16 lane has either 8 or 4 valid columns
+  t_cur += t_step;
+  const bool has_next = PERSIST && t_cur < t_end;
+  block_barrier();  // every wave is done with the ring (its LDS reads were consumed by the MFMAs above)
+  STAMP(1);
+  if (has_next) {
+    DECODE_TILE(t_cur);
+    TILE_OFFSETS();
+    if (0 < nk) { STAGE_NT(0, 0); }
+    if (DIRECT) {
+#pragma unroll
+      for (int st = 1; st < STAGES - 1; ++st)
+        if (st < nk) { STAGE_NT(st, st); }
+    }
+  }
+  if (DIRECT && !((p.debug & 4) && p.M > 1)) {
+    float gam[CPL];
+#pragma unroll
+    for (int i = 0; i < MREP; ++i) {
+      if (i + 1 < MREP) { ISSUE_EXTRA_D(i + 1, (i + 1) & 1); }
+      const int m = em0 + wm * WTM + 16 * i + c;
+      float rsc = 1.f;
+      if (EPI == EPI_RESIDUAL && p.rowscale && m < p.M) rsc = p.rowscale[m / p.rows_per_scale];
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) {
+        const int nn = DIRECT_COL(jj);
+        const bool fulld = nn + CPL <= p.N;
+        const uint32_t o = nn < p.N ? (uint32_t)m * (uint32_t)p.N + (uint32_t)nn : OOB;
+        const uint32_t ob = o == OOB ? OOB : o * ESZ;
+        float v[CPL];
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) v[e] = OUT_BF16 ? acc[i][2 * jj + (e >> 2)][e & 3] : acc[i][jj][e & 3];
+        if (EPI == EPI_GELU) {
+          if (p.preact) {
+            const uint32_t pb = o == OOB ? OOB : o * 2;
+            const u32x2 lo = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            if (CPL == 8) {
+              const u32x2 hi = u32x2{pack_bf16x2(v[CPL - 4], v[CPL - 3]), pack_bf16x2(v[CPL - 2], v[CPL - 1])};
+              if (n8) __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[0], lo[1], hi[0], hi[1]}, pre_rs, pb, 0, 0);
+              else {
+                __builtin_amdgcn_raw_buffer_store_b64(lo, pre_rs, pb, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(hi, pre_rs, fulld ? pb + 8 : OOB, 0, 0);
+              }
+            } else {
+              __builtin_amdgcn_raw_buffer_store_b64(lo, pre_rs, pb, 0, 0);
+            }
+          }
+          gelu_fast_row<CPL / 2>(v);
+        } else if (EPI == EPI_DGELU) {
+          const u32x4 hh = extra[i & 1][jj][0];
+          const uint32_t hw[4] = {hh[0], hh[1], hh[2], hh[3]};
+          gelu_grad_fast_row<CPL / 2>(v, hw);
+        } else if (EPI == EPI_RESIDUAL) {
+          if (p.gamma || p.rowscale) {
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) gam[e] = (p.gamma && nn < p.N && (e < 4 || fulld)) ? p.gamma[nn + e] : 1.f;
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) v[e] *= gam[e] * rsc;
+          }
+          if (p.residual) {
+#pragma unroll
+            for (int e4 = 0; e4 < CPL / 4; ++e4) {
+              const u32x4 rr = extra[i & 1][jj][e4 < EXW ? e4 : 0];
+              v[4 * e4 + 0] += __uint_as_float(rr[0]); v[4 * e4 + 1] += __uint_as_float(rr[1]);
+              v[4 * e4 + 2] += __uint_as_float(rr[2]); v[4 * e4 + 3] += __uint_as_float(rr[3]);
+            }
+          }
+        }
+        if (OUT_BF16) {
+          const u32x2 lo = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          const u32x2 hi = u32x2{pack_bf16x2(v[CPL - 4], v[CPL - 3]), pack_bf16x2(v[CPL - 2], v[CPL - 1])};
+          if (n8) __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[0], lo[1], hi[0], hi[1]}, c_rs, ob, 0, 0);
+          else {
+            __builtin_amdgcn_raw_buffer_store_b64(lo, c_rs, ob, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(hi, c_rs, fulld ? ob + 8 : OOB, 0, 0);
+          }
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, c_rs, ob, 0, 0);
+        }
+      }
+    }
+  }
+  if (!DIRECT && !((p.debug & 4) && p.M > 1)) {
   float gam[CPL];
 #pragma unroll
   for (int e = 0; e < CPL; ++e) gam[e] = (EPI == EPI_RESIDUAL && p.gamma && nvalid && (e < 4 || full)) ? p.gamma[n + e] : 1.f;
-  __syncthreads();
 #pragma unroll
   for (int q = 0; q < NCHUNK; ++q) {
     // (1) every wave drops its MREP_C x NREP fragments of this chunk
@@ -255,91 +481,95 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
 #pragma unroll
       for (int j = 0; j < NREP; ++j) {
         const int cc = wn * WTN + (OUT_BF16 ? (32 * (j >> 1) + 8 * kq + 4 * (j & 1)) : (16 * j + 4 * kq));
-        *reinterpret_cast<f32x4*>(lds + lr * CSTRIDE + cc * 4) = acc[q * MREP_C + ii][j];
+        *reinterpret_cast<f32x4*>(epi_lds + lr * CSTRIDE + cc * 4) = acc[q * MREP_C + ii][j];
       }
     }
-    __syncthreads();
+    lds_barrier();
+    STAMP(4 + 2 * q);
+    if (q + 1 < NCHUNK) { ISSUE_EXTRA(q + 1, (q + 1) & 1); }
     // (2) row-contiguous pass: local row lr <-> tile row (lr / (16*MREP_C))*WTM + 16*MREP_C*q + lr % (16*MREP_C)
 #pragma unroll
     for (int r0 = 0; r0 < NR; r0 += BATCH) {
       float v[BATCH][CPL];
-      float4 res[BATCH][CPL / 4];
-      uint4 hh[BATCH];
-      int off[BATCH];  // element offset m*N + n, or -1
+      uint32_t off[BATCH];  // element offset m*N + n, or OOB
 #pragma unroll
       for (int b = 0; b < BATCH; ++b) {
         const int lr = ((r0 + b) * NW + wave) * RPI + lane / LPR;
-        const int m = m0 + (lr / (16 * MREP_C)) * WTM + 16 * MREP_C * q + lr % (16 * MREP_C);
-        off[b] = (m < p.M && nvalid) ? m * p.N + n : -1;
+        const int m = em0 + (lr / (16 * MREP_C)) * WTM + 16 * MREP_C * q + lr % (16 * MREP_C);
+        off[b] = nvalid ? (uint32_t)m * (uint32_t)p.N + (uint32_t)n : OOB;
 #pragma unroll
         for (int e4 = 0; e4 < CPL / 4; ++e4) {
-          const f32x4 t = *reinterpret_cast<const f32x4*>(lds + lr * CSTRIDE + col * 4 + 16 * e4);
+          const f32x4 t = *reinterpret_cast<const f32x4*>(epi_lds + lr * CSTRIDE + col * 4 + 16 * e4);
           v[b][4 * e4 + 0] = t[0]; v[b][4 * e4 + 1] = t[1]; v[b][4 * e4 + 2] = t[2]; v[b][4 * e4 + 3] = t[3];
-          res[b][e4] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        hh[b] = make_uint4(0, 0, 0, 0);
-        if (off[b] >= 0) {
-          if (EPI == EPI_RESIDUAL && p.residual) {
-            const int ro = p.res_mod > 0 ? (m % p.res_mod) * p.N + n : off[b];
-            res[b][0] = *reinterpret_cast<const float4*>(p.residual + ro);
-            if (CPL == 8 && full) res[b][CPL / 4 - 1] = *reinterpret_cast<const float4*>(p.residual + ro + 4);
-          } else if (EPI == EPI_DGELU) {
-            if (CPL == 8 && full) hh[b] = *reinterpret_cast<const uint4*>(p.dgelu_h + off[b]);
-            else { const uint2 t = *reinterpret_cast<const uint2*>(p.dgelu_h + off[b]); hh[b].x = t.x; hh[b].y = t.y; }
-          }
         }
       }
 #pragma unroll
       for (int b = 0; b < BATCH; ++b) {
-        if (off[b] < 0) continue;
-        const int o = off[b];
+        const uint32_t ob = off[b] == OOB ? OOB : off[b] * ESZ;  // byte offset into C
         if (EPI == EPI_GELU) {
           if (p.preact) {
-            if (CPL == 8 && full) {
-              *reinterpret_cast<uint4*>(p.preact + o) = make_uint4(pack_bf16x2(v[b][0], v[b][1]), pack_bf16x2(v[b][2], v[b][3]),
-                                                                  pack_bf16x2(v[b][CPL - 4], v[b][CPL - 3]), pack_bf16x2(v[b][CPL - 2], v[b][CPL - 1]));
+            const uint32_t pb = off[b] == OOB ? OOB : off[b] * 2;
+            const u32x2 lo = u32x2{pack_bf16x2(v[b][0], v[b][1]), pack_bf16x2(v[b][2], v[b][3])};
+            if (CPL == 8) {
+              const u32x2 hi = u32x2{pack_bf16x2(v[b][CPL - 4], v[b][CPL - 3]), pack_bf16x2(v[b][CPL - 2], v[b][CPL - 1])};
+              if (n8) __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[0], lo[1], hi[0], hi[1]}, pre_rs, pb, 0, 0);
+              else {
+                __builtin_amdgcn_raw_buffer_store_b64(lo, pre_rs, pb, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(hi, pre_rs, full ? pb + 8 : OOB, 0, 0);
+              }
             } else {
-              *reinterpret_cast<uint2*>(p.preact + o) = make_uint2(pack_bf16x2(v[b][0], v[b][1]), pack_bf16x2(v[b][2], v[b][3]));
+              __builtin_amdgcn_raw_buffer_store_b64(lo, pre_rs, pb, 0, 0);
             }
           }
-#pragma unroll
-          for (int e = 0; e < CPL; e += 2) {
-            const f32x2 y2 = gelu_fast2(f32x2{v[b][e], v[b][e + 1]});
-            v[b][e] = y2[0];
-            v[b][e + 1] = y2[1];
-          }
+          gelu_fast_row<CPL / 2>(v[b]);
         } else if (EPI == EPI_DGELU) {
-          const uint32_t hw[4] = {hh[b].x, hh[b].y, hh[b].z, hh[b].w};
-#pragma unroll
-          for (int e = 0; e < CPL / 2; ++e) {
-            const f32x2 g2 = gelu_grad_fast2(f32x2{__uint_as_float(hw[e] << 16), __uint_as_float(hw[e] & 0xffff0000u)});
-            v[b][2 * e] *= g2[0];
-            v[b][2 * e + 1] *= g2[1];
-          }
+          const u32x4 hh = extra[q & 1][r0 + b][0];
+          const uint32_t hw[4] = {hh[0], hh[1], hh[2], hh[3]};
+          gelu_grad_fast_row<CPL / 2>(v[b], hw);
         } else if (EPI == EPI_RESIDUAL) {
           if (p.gamma || p.rowscale) {
-            const float rsc = p.rowscale ? p.rowscale[(o / p.N) / p.rows_per_scale] : 1.f;
+            const int lr = ((r0 + b) * NW + wave) * RPI + lane / LPR;
+            const int m = em0 + (lr / (16 * MREP_C)) * WTM + 16 * MREP_C * q + lr % (16 * MREP_C);
+            const float rsc = (p.rowscale && m < p.M) ? p.rowscale[m / p.rows_per_scale] : 1.f;
 #pragma unroll
             for (int e = 0; e < CPL; ++e) v[b][e] *= gam[e] * rsc;
           }
+          if (p.residual) {
 #pragma unroll
-          for (int e4 = 0; e4 < CPL / 4; ++e4) {
-            v[b][4 * e4 + 0] += res[b][e4].x; v[b][4 * e4 + 1] += res[b][e4].y;
-            v[b][4 * e4 + 2] += res[b][e4].z; v[b][4 * e4 + 3] += res[b][e4].w;
+            for (int e4 = 0; e4 < CPL / 4; ++e4) {
+              const u32x4 rr = extra[q & 1][r0 + b][e4 < EXW ? e4 : 0];
+              v[b][4 * e4 + 0] += __uint_as_float(rr[0]); v[b][4 * e4 + 1] += __uint_as_float(rr[1]);
+              v[b][4 * e4 + 2] += __uint_as_float(rr[2]); v[b][4 * e4 + 3] += __uint_as_float(rr[3]);
+            }
           }
         }
         if (OUT_BF16) {
-          uint16_t* cp = (uint16_t*)p.C + o;
-          if (full) *reinterpret_cast<uint4*>(cp) = make_uint4(pack_bf16x2(v[b][0], v[b][1]), pack_bf16x2(v[b][2], v[b][3]),
-                                                             pack_bf16x2(v[b][CPL - 4], v[b][CPL - 3]), pack_bf16x2(v[b][CPL - 2], v[b][CPL - 1]));
-          else *reinterpret_cast<uint2*>(cp) = make_uint2(pack_bf16x2(v[b][0], v[b][1]), pack_bf16x2(v[b][2], v[b][3]));
+          const u32x2 lo = u32x2{pack_bf16x2(v[b][0], v[b][1]), pack_bf16x2(v[b][2], v[b][3])};
+          const u32x2 hi = u32x2{pack_bf16x2(v[b][CPL - 4], v[b][CPL - 3]), pack_bf16x2(v[b][CPL - 2], v[b][CPL - 1])};
+          if (n8) __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[0], lo[1], hi[0], hi[1]}, c_rs, ob, 0, 0);
+          else {
+            __builtin_amdgcn_raw_buffer_store_b64(lo, c_rs, ob, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(hi, c_rs, full ? ob + 8 : OOB, 0, 0);
+          }
         } else {
-          *reinterpret_cast<float4*>((float*)p.C + o) = make_float4(v[b][0], v[b][1], v[b][2], v[b][3]);
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[b][0]), __float_as_uint(v[b][1]), __float_as_uint(v[b][2]), __float_as_uint(v[b][3])},
+                                                 c_rs, ob, 0, 0);
         }
       }
     }
-    if (q + 1 < NCHUNK) __syncthreads();
+    STAMP(5 + 2 * q);
+    if (q + 1 < NCHUNK) lds_barrier();
   }
+  }  // epilogue
+  STAMP(2);
+  if (p.stamps) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(3);
+  }
+  ++stamp_i;
+  if (!has_next) break;
+  if (!DIRECT) lds_barrier();  // epilogue reads of the LDS are done before the next tile's DMAs overwrite it
+  }  // tile loop
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -528,32 +758,72 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(const Ge
 }
 
 // ------------------------------------------------------------------------------------------------------------
+
 static int env_int(const char* name) {
   const char* v = getenv(name);
   return v ? atoi(v) : 0;
 }
+static int cu_count();
+
+// scheduling knobs (tad_linear_tuning; initial values from TAD_GEMM_NO_PERSIST / TAD_GEMM_STAGGER / TAD_GEMM_STAGGER_GROUP)
+static int g_nt_persist = !env_int("TAD_GEMM_NO_PERSIST");
+static int g_nt_stagger_pct = getenv("TAD_GEMM_STAGGER") ? env_int("TAD_GEMM_STAGGER") : 0;  // % of one tile's K-loop time
+static int g_nt_stagger_group = getenv("TAD_GEMM_STAGGER_GROUP") ? env_int("TAD_GEMM_STAGGER_GROUP") : 1;
+static int g_nt_direct = getenv("TAD_GEMM_DIRECT_EPI") ? env_int("TAD_GEMM_DIRECT_EPI") : 1;
+
+static unsigned long long* g_nt_stamps = nullptr;
 
 // Tile configurations.  NT: 1 = 256x256 (2x4 waves) 2 stages; 2 = 128x128 (2x2) 2 stages, 2 workgroups/CU;
 // 3 = 256x128 (4x2) 3 stages.  0 = auto.  The epilogue kind and output type are compile-time (the epilogue is VALU-bound).
+// Variants 1 and 3 run as persistent kernels (one workgroup per CU, staggered starts) once there are at least two tiles per CU.
 template <int EPI, bool OUT_BF16>
-static void launch_nt_variant(int v, const GemmNT& p, hipStream_t st) {
+static void launch_nt_variant(int v, GemmNT& p, hipStream_t st) {
   auto tiles = [&](int bm, int bn) { return ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
-  switch (v) {
-    case 1: hipLaunchKernelGGL((gemm_nt_kernel<256, 256, 2, 4, 2, 64, 1, EPI, OUT_BF16>), dim3(tiles(256, 256)), dim3(512), 0, st, p); break;
-    case 3: hipLaunchKernelGGL((gemm_nt_kernel<256, 128, 4, 2, 3, 64, 1, EPI, OUT_BF16>), dim3(tiles(256, 128)), dim3(512), 0, st, p); break;
-    default: hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 2, 2, 2, 64, 1, EPI, OUT_BF16>), dim3(tiles(128, 128)), dim3(256), 0, st, p); break;
+  const int no_persist = !g_nt_persist, stagger_pct = g_nt_stagger_pct, stagger_group = g_nt_stagger_group;
+  if (EPI == EPI_RESIDUAL && v == 1) v = 3;  // the 256 x 256 tile has no registers left for the prefetched residual rows
+  const int grid_p = cu_count() & ~7;
+  const int bn = v == 1 ? 256 : 128;
+  const bool persist = !no_persist && (v == 1 || v == 3) && grid_p >= 8 && tiles(256, bn) >= 2 * grid_p;
+  if (persist) {
+    // one K-tile (64 deep) of a 256 x bn tile at ~1.15 PFLOP/s chip-wide: 1.87 us for bn = 256
+    const double ktile_us = 2.0 * 256.0 * bn * 64.0 / (1.15e15 / cu_count()) * 1e6;
+    p.stagger_ticks = (int)(ktile_us * (p.K / 64) * 100.0 * stagger_pct / 100.0);
+    p.stagger_group = stagger_group > 0 ? stagger_group : 1;
   }
+#define NT_LAUNCH(BM_, BN_, WM_, WN_, ST_, PER_, DIR_, GRID_, THREADS_) \
+  hipLaunchKernelGGL((gemm_nt_kernel<BM_, BN_, WM_, WN_, ST_, 64, 1, EPI, OUT_BF16, PER_, DIR_>), dim3(GRID_), dim3(THREADS_), 0, st, p)
+  // measured per shape (tools/exp_epilogue.py): storing straight from the MFMA layout wins only for the bias-only bf16 epilogue
+  // (nothing to fetch, no arithmetic); the others keep the LDS transposition.  g_nt_direct: 0 = never, 1 = auto, 2 = always.
+  const bool direct = g_nt_direct == 2 || (g_nt_direct == 1 && EPI == EPI_PLAIN && OUT_BF16);
+  switch (v) {
+    case 1:
+      if constexpr (EPI != EPI_RESIDUAL) {
+        if (persist) { if (direct) NT_LAUNCH(256, 256, 2, 4, 2, true, true, grid_p, 512); else NT_LAUNCH(256, 256, 2, 4, 2, true, false, grid_p, 512); }
+        else { if (direct) NT_LAUNCH(256, 256, 2, 4, 2, false, true, tiles(256, 256), 512); else NT_LAUNCH(256, 256, 2, 4, 2, false, false, tiles(256, 256), 512); }
+      }
+      break;
+    case 3:
+      if (persist) { if (direct) NT_LAUNCH(256, 128, 4, 2, 3, true, true, grid_p, 512); else NT_LAUNCH(256, 128, 4, 2, 3, true, false, grid_p, 512); }
+      else { if (direct) NT_LAUNCH(256, 128, 4, 2, 3, false, true, tiles(256, 128), 512); else NT_LAUNCH(256, 128, 4, 2, 3, false, false, tiles(256, 128), 512); }
+      break;
+    default:
+      if (direct) NT_LAUNCH(128, 128, 2, 2, 2, false, true, tiles(128, 128), 256); else NT_LAUNCH(128, 128, 2, 2, 2, false, false, tiles(128, 128), 256);
+      break;
+  }
+#undef NT_LAUNCH
 }
 
-int launch_gemm_nt(const GemmNT& p, hipStream_t st) {
+int launch_gemm_nt(const GemmNT& p_in, hipStream_t st) {
+  GemmNT p = p_in;
   if (!(p.M > 0 && p.N > 0 && p.K > 0)) { set_error("gemm_nt: empty problem"); return TAD_EINVAL; }
   if (p.K % BK) { set_error("gemm_nt: K=%d must be a multiple of %d", p.K, BK); return TAD_EINVAL; }
   if (p.N % 4) { set_error("gemm_nt: N=%d must be a multiple of 4", p.N); return TAD_EINVAL; }
   if ((int64_t)p.M * p.K * 2 >= (1ll << 32) || (int64_t)p.N * p.K * 2 >= (1ll << 32)) { set_error("gemm_nt: operand exceeds 4 GiB"); return TAD_EINVAL; }
-  if ((int64_t)(p.M + 256) * p.N >= (1ll << 31)) { set_error("gemm_nt: output exceeds 2^31 elements"); return TAD_EINVAL; }
+  if ((int64_t)(p.M + 256) * p.N * 4 >= (1ll << 31)) { set_error("gemm_nt: output exceeds 2 GiB (f32) / 2^29 elements"); return TAD_EINVAL; }
   static const int forced = env_int("TAD_GEMM_NT_VARIANT");
   static const int debug = env_int("TAD_GEMM_DEBUG");
-  const_cast<GemmNT&>(p).debug = debug;
+  p.debug = debug;
+  p.stamps = g_nt_stamps;
   int v = forced;
   // measured on MI355X (tools/bench_kernels.py): 256x256 wins when N has many column panels, 256x128 for N <= 1024
   if (v == 0) v = (p.M < 2048 || p.N < 128) ? 2 : ((p.N >= 1536 && p.N % 256 == 0) ? 1 : 3);
@@ -666,6 +936,22 @@ int tad_linear_fwd(const uint16_t* x, const uint16_t* w, const float* bias, void
   else if (epilogue == TAD_EPI_BIAS_RESIDUAL) { p.epi = EPI_RESIDUAL; p.residual = residual; p.gamma = gamma; p.rowscale = rowscale; }
   else p.epi = EPI_PLAIN;
   return launch_gemm_nt(p, (hipStream_t)stream);
+}
+
+int tad_linear_tuning(int persistent, int stagger_pct, int stagger_group, int direct_epilogue) {
+  TAD_REQUIRE(stagger_group < 0 || (stagger_group >= 1 && stagger_group <= 32 && (stagger_group & (stagger_group - 1)) == 0),
+              "linear_tuning: stagger_group=%d must be a power of two in 1..32", stagger_group);
+  TAD_REQUIRE(stagger_pct <= 400, "linear_tuning: stagger_pct=%d out of range", stagger_pct);
+  if (persistent >= 0) g_nt_persist = persistent != 0;
+  if (stagger_pct >= 0) g_nt_stagger_pct = stagger_pct;
+  if (stagger_group >= 0) g_nt_stagger_group = stagger_group;
+  if (direct_epilogue >= 0) g_nt_direct = direct_epilogue > 2 ? 2 : direct_epilogue;
+  return TAD_OK;
+}
+
+int tad_linear_debug_stamps(void* buf) {
+  g_nt_stamps = (unsigned long long*)buf;
+  return TAD_OK;
 }
 
 int tad_linear_bwd_input(const uint16_t* dy, const uint16_t* wT, void* dx, int dx_dtype, const uint16_t* gelu_preact, int64_t M, int N,

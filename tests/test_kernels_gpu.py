@@ -304,3 +304,67 @@ def test_attention_f32_fwd_bwd(K, B, N, H):
     check(out.reshape(B, N, -1), ref, tol=1e-5, what="attn f32 fwd")
     dqkv = K.attn_bwd_f32(dev(qkv), out, dev(dout), lse, B, N, H, scale)
     check(dqkv.reshape(B, N, -1), ref_dqkv, tol=1e-5, what="attn f32 bwd")
+
+
+DEFAULT_TUNING = (1, 0, 1, 1)  # csrc/gemm.hip defaults: persistent, no stagger, epilogue on the accumulator registers
+
+
+# ---- persistent (one workgroup per CU, staggered starts) vs one-workgroup-per-tile scheduling of the Linear GEMMs.
+# Neither scheduling nor the epilogue's store path (straight from the MFMA layout / transposed through the LDS) may change a
+# single bit: same tiles, same K order, same epilogue arithmetic.  Shapes are large enough
+# for the persistent path (>= 2 tiles per CU) and include ragged M / N edges.
+@pytest.mark.parametrize("M,N,Kd,mode", [
+    (12544 + 77, 3072, 768, "gelu"), (25088 + 130, 768, 768, "res"), (25088, 768, 3072, "res"), (25088 + 5, 2304, 768, "plain"),
+    (12544 + 200, 3072, 768, "dgelu"), (25088, 768 + 4, 128, "plain_f32")])
+def test_linear_persistent_schedule_is_bit_identical(K, M, N, Kd, mode):
+    from simple_tad_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + N)
+    x = dev(torch.randn(M, Kd, generator=g)).to(torch.bfloat16)
+    w = dev(torch.randn(N, Kd, generator=g) * 0.05).to(torch.bfloat16)
+    bias = dev(torch.randn(N, generator=g))
+    res = dev(torch.randn(M, N, generator=g)) if mode == "res" else None
+    h = dev(torch.randn(M, N, generator=g)).to(torch.bfloat16) if mode == "dgelu" else None
+
+    def run():
+        if mode == "gelu":
+            return K.linear_fwd(x, w, bias, epilogue=K.EPI_BIAS_GELU, want_preact=True)
+        if mode == "res":
+            return K.linear_fwd(x, w, bias, out_dtype=torch.float32, epilogue=K.EPI_BIAS_RESIDUAL, residual=res)
+        if mode == "dgelu":
+            return (K.linear_bwd_input(x, w, gelu_preact=h), None)
+        if mode == "plain_f32":
+            return K.linear_fwd(x, w, bias, out_dtype=torch.float32)
+        return K.linear_fwd(x, w, bias)
+
+    outs = {}
+    try:
+        for name, cfg in [("tile", (0, 0, 1, 0)), ("tile_direct", (0, 0, 1, 2)), ("persist", (1, 100, 1, 0)), ("persist_grouped", (1, 50, 8, 2)),
+                          ("persist_direct", (1, 0, 1, 2)), ("default", DEFAULT_TUNING)]:
+            assert lib.tad_linear_tuning(*cfg) == 0
+            y, pre = run()
+            torch.cuda.synchronize()
+            outs[name] = (y.clone(), None if pre is None else pre.clone())
+    finally:
+        lib.tad_linear_tuning(*DEFAULT_TUNING)
+    y0, p0 = outs["tile"]
+    for name in ("tile_direct", "persist", "persist_grouped", "persist_direct", "default"):
+        y1, p1 = outs[name]
+        assert torch.equal(y0, y1), f"{name}: output differs from per-tile scheduling"
+        if p0 is not None:
+            assert torch.equal(p0, p1), f"{name}: pre-activation differs"
+    # and the result is right: sampled rows against an f64 product of the same bf16 operands
+    rows = torch.randint(0, M, (64,), generator=g).tolist() + [0, M - 1]
+    ref = x[rows].double() @ w.double().t()
+    if mode == "dgelu":
+        hh = h[rows].double()
+        ref = ref * (0.5 * (1 + torch.erf(hh / math.sqrt(2))) + hh * torch.exp(-hh * hh / 2) / math.sqrt(2 * math.pi))
+    else:
+        ref = ref + bias.double()
+        if mode == "gelu":
+            ref = torch.nn.functional.gelu(ref)
+        if mode == "res":
+            ref = ref + res[rows].double()
+    got = y0[rows].double()
+    tol = TOL if y0.dtype == torch.float32 else 2 * BF16_ULP
+    assert float((got - ref).abs().max() / ref.abs().max()) < tol

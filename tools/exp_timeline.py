@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""In-kernel timeline of one gemm_nt launch (tad_linear_debug_stamps): per tile K-loop / epilogue / store-drain durations and
+the spread of the workgroups' phases.   python tools/exp_timeline.py [--shape fc1] [--config 1,100,1]"""
+import argparse, os, sys, torch, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from simple_tad_amd import kernels as K, _lib
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--shape", default="fc1")
+ap.add_argument("--configs", default="1,0,1,0;1,0,1,1")
+a = ap.parse_args()
+lib = _lib.load()
+dev, bf, D, M = "cuda", torch.bfloat16, 768, 50176
+n, k, mode = {"fc1": (3072, 768, "gelu"), "proj": (768, 768, "res"), "qkv": (2304, 768, "plain"), "fc2": (768, 3072, "res")}[a.shape]
+x = torch.randn(M, k, device=dev).to(bf)
+w = (torch.randn(n, k, device=dev) * 0.02).to(bf)
+bias = torch.randn(n, device=dev)
+res = torch.randn(M, n, device=dev) if mode == "res" else None
+if mode == "gelu":
+    fn = lambda: K.linear_fwd(x, w, bias, epilogue=1, want_preact=True)
+elif mode == "res":
+    fn = lambda: K.linear_fwd(x, w, bias, out_dtype=torch.float32, epilogue=2, residual=res)
+else:
+    fn = lambda: K.linear_fwd(x, w, bias)
+for cfg in a.configs.split(";"):
+    c = tuple(int(v) for v in cfg.split(","))
+    lib.tad_linear_tuning(*c)
+    for _ in range(3):
+        fn()
+    nwg = 4096
+    buf = torch.zeros(nwg * 64 * 16, dtype=torch.int64, device=dev)
+    lib.tad_linear_debug_stamps(buf.data_ptr())
+    fn()
+    torch.cuda.synchronize()
+    lib.tad_linear_debug_stamps(None)
+    s = buf.cpu().numpy().reshape(nwg, 64, 16).astype(np.float64)
+    used = s[:, :, 0] > 0
+    t0 = s[:, :, 0][used].min()
+    s = (s - t0) / 100.0  # us
+    kloop = (s[:, :, 1] - s[:, :, 0])[used]
+    epi = (s[:, :, 2] - s[:, :, 1])[used]
+    drain = (s[:, :, 3] - s[:, :, 2])[used]
+    print(f"config {c}: {int(used.sum())} tiles on {int(used.any(axis=1).sum())} workgroups; end {s[:, :, 3][used].max():.1f} us")
+    for name, v in (("K loop", kloop), ("epilogue", epi), ("drain", drain)):
+        print(f"   {name:9s} mean {v.mean():6.2f}  p10 {np.percentile(v, 10):6.2f}  p50 {np.percentile(v, 50):6.2f}  p90 {np.percentile(v, 90):6.2f}  max {v.max():6.2f} us")
+    prev = s[:, :, 1]
+    for q in range(4):
+        if not (s[:, :, 4 + 2 * q][used] > 0).any():
+            break
+        a1, a2 = s[:, :, 4 + 2 * q], s[:, :, 5 + 2 * q]
+        print(f"   chunk {q}: transpose+barrier {np.mean((a1 - prev)[used]):5.2f} us, row pass {np.mean((a2 - a1)[used]):5.2f} us")
+        prev = a2
+    if c[0]:
+        # phase spread: epilogue start times of the 3rd tile of each workgroup, and how many workgroups are inside an epilogue over time
+        st = s[:, 2, 1][used[:, 2]]
+        print(f"   start of 3rd epilogue: min {st.min():.1f} p25 {np.percentile(st, 25):.1f} p50 {np.percentile(st, 50):.1f} p75 {np.percentile(st, 75):.1f} max {st.max():.1f} us")
+    ts = np.arange(0, s[:, :, 3][used].max(), 2.0)
+    inside = [(int(((s[:, :, 1] <= t) & (s[:, :, 3] > t) & used).sum())) for t in ts]
+    print("   workgroups inside an epilogue every 2 us:", " ".join(str(v) for v in inside[:120]))

@@ -39,7 +39,7 @@ def eval32(mono, xmax, x):
 if __name__ == "__main__":
     rng = np.random.RandomState(0)
     xs = np.concatenate([np.linspace(-9, 9, 600001), rng.randn(300000) * 1.5])
-    for name, fun, xmax, deg in (("PHI", Phi, 5.0, 12), ("DGELU", dgelu, 5.5, 13)):
+    for name, fun, xmax, deg in (("PHI", Phi, 4.0, 8), ("DGELU", dgelu, 4.5, 9)):
         mono = fit(fun, xmax, deg)
         got = eval32(mono, xmax, xs).astype(np.float64)
         err = np.max(np.abs(got - fun(xs)))
