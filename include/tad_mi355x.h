@@ -117,14 +117,17 @@ int tad_linear_fwd(const uint16_t* x, const uint16_t* w, const float* bias, void
  * colscale [N] / rowscale are applied to dy on the fly is NOT supported; scale dy beforehand. */
 int tad_linear_bwd_input(const uint16_t* dy, const uint16_t* wT, void* dx, int dx_dtype,
                          const uint16_t* gelu_preact, int64_t M, int N, int K, tad_stream_t stream);
-/* Scheduling knobs of the Linear GEMMs (process-wide; results never depend on them, only timing).  A negative value leaves a
- * knob unchanged.  persistent: 1 = one workgroup per CU walks the tile list (default), 0 = one workgroup per tile.
- * stagger_pct: span over which the workgroups of a persistent launch spread their start, in % of one tile's K-loop time.
- * stagger_group: workgroups of an XCD start in groups of this many (power of two).
- * direct_epilogue: 2 = epilogue on the accumulator registers, stores straight from the MFMA layout; 0 = accumulators
- *                  transposed through the LDS first (whole rows per store instruction); 1 = chosen per epilogue kind (default). */
-int tad_linear_tuning(int persistent, int stagger_pct, int stagger_group, int direct_epilogue);
-/* Debug timeline of the Linear GEMM kernels: while buf (device memory, >= gridDim * 64 * 16 * 8 bytes, caller-owned) is set,
+/* Scheduling knobs of the Linear GEMMs (process-wide; results never depend on them, only timing): tad_linear_tuning(key, value).
+ *   "persistent"      1 = one workgroup per CU walks the tile list (default), 0 = one workgroup per tile
+ *   "stagger_pct"     span over which the workgroups of a persistent launch spread their start, in % of one tile's K-loop
+ *                     time (default 0)
+ *   "stagger_group"   workgroups of an XCD start in groups of this many (power of two, default 1)
+ *   "direct_epilogue" 2 = epilogue on the accumulator registers, stores straight from the MFMA layout; 0 = accumulators
+ *                     transposed through the LDS first (whole rows per store instruction); 1 = per epilogue kind (default)
+ *   "split_tail"      1 = a Linear whose 256 x 256 tiles do not fill whole rounds of one workgroup per CU may run as two
+ *                     launches (whole rounds + remaining rows) when the cost model says so (default); 0 = never; 2 = always */
+int tad_linear_tuning(const char* key, int value);
+/* Debug timeline of the Linear GEMM kernels: while buf (device memory, >= gridDim * 64 * 32 * 8 bytes, caller-owned) is set,
  * every workgroup records s_memrealtime (100 MHz) for each of its first 64 tiles: slot 0 tile start, 1 K-loop end, 2 epilogue
  * issued, 3 stores acknowledged, 4 + 2q / 5 + 2q epilogue chunk q transposed / stored.  NULL switches it off (default).  Costs a store drain per tile: never leave it on. */
 int tad_linear_debug_stamps(void* buf);

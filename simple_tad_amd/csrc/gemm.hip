@@ -13,14 +13,18 @@
 // lanes, so that each lane ends up holding 4*NREP *consecutive* output columns of one output row: the epilogue
 // (bias / GELU / residual / layer-scale / drop-path scale / GELU-backward) runs on registers and stores 16-byte
 // vectors straight to HBM without an LDS round trip.
+#include <math.h>
 #include <stdlib.h>
+#include <string>
 #include "common.h"
 
 namespace tad {
 
 int launch_reduce_partials(const float* partial, float* out, int splits, int64_t n, int accumulate, hipStream_t st);
 
-enum { EPI_PLAIN = 0, EPI_GELU = 1, EPI_RESIDUAL = 2, EPI_DGELU = 3 };
+// EPI_RESMOD = EPI_RESIDUAL with the residual row taken modulo res_mod ("+ pos_embed" of the patch embedding): a variant of its
+// own so that the integer division stays out of the Linear kernels
+enum { EPI_PLAIN = 0, EPI_GELU = 1, EPI_RESIDUAL = 2, EPI_DGELU = 3, EPI_RESMOD = 4 };
 
 struct GemmNT {
   const uint16_t* A;  // [M,K]
@@ -33,7 +37,8 @@ struct GemmNT {
   uint16_t* preact;        // [M,N] bf16 or null (EPI_GELU)
   const uint16_t* dgelu_h; // [M,N] bf16 (EPI_DGELU)
   int rows_per_scale;
-  int res_mod;  // >0: residual row index = m % res_mod (pos_embed broadcast over the batch)
+  int res_mod;  // >0: residual row index = (row_base + m) % res_mod (pos_embed broadcast over the batch)
+  int row_base;  // row of the whole problem that this launch's row 0 is (a launch may cover a row range of a Linear): rowscale / res_mod
   int c_bf16;
   int epi;
   int M, N, K;
@@ -60,13 +65,14 @@ __device__ __forceinline__ void stage_tile(const void* gbase, int gbytes, char* 
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(tile + (i * NW + wave) * 1024), 16, off[i] + add, 0, 0, 0);
 }
 
-// wait until at most `stages_in_flight` later stages (LOADS DMA instructions each, per wave) are still outstanding
-template <int LOADS>
+// wait until at most `stages_in_flight` later stages (LOADS DMA instructions each, per wave) plus EXTRA younger vector-memory
+// instructions are still outstanding
+template <int LOADS, int EXTRA = 0>
 __device__ __forceinline__ void wait_stage(int stages_in_flight) {
-  static_assert(2 * LOADS <= 63, "vmcnt immediate is 6 bits");
-  if (stages_in_flight >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
-  else if (stages_in_flight == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  static_assert(2 * LOADS + EXTRA <= 63, "vmcnt immediate is 6 bits");
+  if (stages_in_flight >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS + EXTRA) : "memory");
+  else if (stages_in_flight == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS + EXTRA) : "memory");
+  else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EXTRA) : "memory");
 }
 __device__ __forceinline__ void block_barrier() {
   asm volatile("" ::: "memory");
@@ -94,6 +100,7 @@ __device__ __forceinline__ int sw_rows(int row) { return BKT == 64 ? sw_nt(row) 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int BKT, int MIN_WAVES, int EPI, bool OUT_BF16, bool PERSIST, bool DIRECT>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kernel(const GemmNT p) {
   constexpr int NW = WAVES_M * WAVES_N;
+  constexpr bool IS_RES = (EPI == EPI_RESIDUAL || EPI == EPI_RESMOD);
   constexpr int ROWB = BKT * 2;               // bytes per LDS row
   constexpr int RPP = 1024 / ROWB;            // rows per 1-KiB DMA piece
   constexpr int CPR = ROWB / 16;              // 16-byte chunks per row
@@ -106,7 +113,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
   static_assert(BM % (RPP * NW) == 0 && BN % (RPP * NW) == 0, "tile rows must split into whole DMA pieces per wave");
   // one epilogue chunk: CROWS rows of f32, padded stride.  The persistent kernel keeps ring slot 0 out of the epilogue's way
   // (the next tile's first K-tile lands there meanwhile), so its chunks must fit the LDS behind slot 0.
-  constexpr int CROWS = BM < 128 ? BM : (((PERSIST && BN > 128) || NW == 4) ? 64 : 128);
+  constexpr int CROWS = BM < 128 ? BM : ((BN > 128 && IS_RES && !OUT_BF16) ? 32 : (((PERSIST && BN > 128) || NW == 4) ? 64 : 128));
   constexpr int EPI_OFF = PERSIST ? STAGE_BYTES : 0;
   constexpr int EPI_BYTES = DIRECT ? 0 : CROWS * (BN * 4 + 16);
   constexpr int LDS_BYTES = STAGES * STAGE_BYTES > EPI_OFF + EPI_BYTES ? STAGES * STAGE_BYTES : EPI_OFF + EPI_BYTES;
@@ -233,7 +240,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
   constexpr int CPL = OUT_BF16 ? 8 : 4;              // columns per lane in the row pass (16-byte stores)
   constexpr int LPR = BN / CPL, RPI = 64 / LPR;      // lanes per row, rows per wave-instruction
   constexpr int NR = CROWS / (NW * RPI);             // row-instructions per wave per chunk
-  constexpr int BATCH_MAX = 4;  // rows of LDS reads in flight per lane (register budget: the other chunks' accumulators are live)
+  constexpr int BATCH_MAX = (IS_RES && BN > 128) ? 2 : 4;  // rows of LDS reads in flight per lane (register budget: the other chunks' accumulators are live)
   constexpr int BATCH = NR < BATCH_MAX ? NR : BATCH_MAX;
   static_assert(MREP % MREP_C == 0 && MREP_C >= 1 && CROWS % (NW * RPI) == 0 && NR % BATCH == 0, "chunking");
   char* const epi_lds = lds + EPI_OFF;
@@ -244,7 +251,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
   int stamp_i = 0;
   bool first_tile = true;
 #define STAMP(k) \
-  if (p.stamps && tid == 0 && stamp_i < 64) p.stamps[((size_t)blockIdx.x * 64 + stamp_i) * 16 + (k)] = __builtin_amdgcn_s_memrealtime()
+  if (p.stamps && tid == 0 && stamp_i < 64) p.stamps[((size_t)blockIdx.x * 64 + stamp_i) * 32 + (k)] = __builtin_amdgcn_s_memrealtime()
   for (;;) {
   STAMP(0);
   const int em0 = m0, en0 = n0;  // this tile; (m0, n0) move on to the next one when its first K-tile is prefetched
@@ -257,7 +264,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
   const auto c_rs = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)(mn_elems * ESZ), 0x00020000);
   const auto pre_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.preact, 0, (int)(mn_elems * 2), 0x00020000);
   const auto h_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.dgelu_h, 0, (int)(mn_elems * 2), 0x00020000);
-  const auto res_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.residual, 0, (int)((p.res_mod > 0 ? (uint32_t)p.res_mod * (uint32_t)p.N : mn_elems) * 4), 0x00020000);
+  const auto res_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.residual, 0, (int)((EPI == EPI_RESMOD ? (uint32_t)p.res_mod * (uint32_t)p.N : mn_elems) * 4), 0x00020000);
   const int col = CPL * (lane % LPR);
   const int n = en0 + col;
   const bool nvalid = n < p.N;
@@ -266,21 +273,21 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
   // What the epilogue READS besides the accumulators (f32 residual rows / bf16 pre-activation rows) is fetched one chunk ahead:
   // chunk 0 during the last K-tile of the main loop, chunk q + 1 while chunk q is processed.  Fetched on demand, each batch of
   // rows exposed a full HBM latency (4 batches x ~3 us per 256 x 128 f32 tile: longer than that tile's K loop at K = 768).
-  constexpr bool HAS_EXTRA = (EPI == EPI_RESIDUAL || EPI == EPI_DGELU);
-  constexpr int EXW = (EPI == EPI_RESIDUAL) ? CPL / 4 : 1;
+  constexpr bool HAS_EXTRA = (IS_RES || EPI == EPI_DGELU);
+  constexpr int EXW = (IS_RES) ? CPL / 4 : 1;
   constexpr int NJ = OUT_BF16 ? NREP / 2 : NREP;  // DIRECT: 16-byte column groups per lane and m-fragment
   u32x4 extra[2][HAS_EXTRA ? (DIRECT ? NJ : NR) : 1][EXW];
   // DIRECT addressing: acc[i][j] of lane (c, kq) = out[em0 + wm*WTM + 16i + c][en0 + wn*WTN + cg(j) .. +3], cg as in the LDS path
 #define DIRECT_COL(jj) (en0 + wn * WTN + (OUT_BF16 ? 32 * (jj) + 8 * kq : 16 * (jj) + 4 * kq))
 #define ISSUE_EXTRA_D(i, buf)                                                                                           \
-  if (HAS_EXTRA && (EPI != EPI_RESIDUAL || p.residual)) {                                                               \
+  if (HAS_EXTRA && (!IS_RES || p.residual)) {                                                               \
     const int m = em0 + wm * WTM + 16 * (i) + c;                                                                        \
     _Pragma("unroll") for (int jj = 0; jj < NJ; ++jj) {                                                                 \
       const int nn = DIRECT_COL(jj);                                                                                    \
       const bool fulld = nn + CPL <= p.N;                                                                               \
       uint32_t o = nn < p.N ? (uint32_t)m * (uint32_t)p.N + (uint32_t)nn : OOB;                                         \
-      if (EPI == EPI_RESIDUAL) {                                                                                        \
-        if (p.res_mod > 0) o = (nn < p.N && m < p.M) ? (uint32_t)(m % p.res_mod) * (uint32_t)p.N + (uint32_t)nn : OOB;  \
+      if (IS_RES) {                                                                                        \
+        if (EPI == EPI_RESMOD) o = (nn < p.N && m < p.M) ? (uint32_t)((m + p.row_base) % p.res_mod) * (uint32_t)p.N + (uint32_t)nn : OOB;  \
         const uint32_t rb = o == OOB ? OOB : o * 4;                                                                     \
         extra[buf][jj][0] = __builtin_amdgcn_raw_buffer_load_b128(res_rs, rb, 0, 0);                                    \
         if (CPL == 8) extra[buf][jj][EXW - 1] = __builtin_amdgcn_raw_buffer_load_b128(res_rs, fulld ? rb + 16 : OOB, 0, 0); \
@@ -301,13 +308,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
     }                                                                                                                   \
   }
 #define ISSUE_EXTRA(q, buf)                                                                                             \
-  if (HAS_EXTRA && (EPI != EPI_RESIDUAL || p.residual)) {                                                               \
+  if (HAS_EXTRA && (!IS_RES || p.residual)) {                                                               \
     _Pragma("unroll") for (int r = 0; r < NR; ++r) {                                                                    \
       const int lr = (r * NW + wave) * RPI + lane / LPR;                                                                \
       const int m = em0 + (lr / (16 * MREP_C)) * WTM + 16 * MREP_C * (q) + lr % (16 * MREP_C);                          \
       uint32_t o = nvalid ? (uint32_t)m * (uint32_t)p.N + (uint32_t)n : OOB;                                            \
-      if (EPI == EPI_RESIDUAL) {                                                                                        \
-        if (p.res_mod > 0) o = (nvalid && m < p.M) ? (uint32_t)(m % p.res_mod) * (uint32_t)p.N + (uint32_t)n : OOB;     \
+      if (IS_RES) {                                                                                        \
+        if (EPI == EPI_RESMOD) o = (nvalid && m < p.M) ? (uint32_t)((m + p.row_base) % p.res_mod) * (uint32_t)p.N + (uint32_t)n : OOB;     \
         const uint32_t rb = o == OOB ? OOB : o * 4;                                                                     \
         extra[buf][r][0] = __builtin_amdgcn_raw_buffer_load_b128(res_rs, rb, 0, 0);                                     \
         if (CPL == 8) extra[buf][r][EXW - 1] = __builtin_amdgcn_raw_buffer_load_b128(res_rs, full ? rb + 16 : OOB, 0, 0); \
@@ -408,7 +415,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
       if (i + 1 < MREP) { ISSUE_EXTRA_D(i + 1, (i + 1) & 1); }
       const int m = em0 + wm * WTM + 16 * i + c;
       float rsc = 1.f;
-      if (EPI == EPI_RESIDUAL && p.rowscale && m < p.M) rsc = p.rowscale[m / p.rows_per_scale];
+      if (IS_RES && p.rowscale && m < p.M) rsc = p.rowscale[(m + p.row_base) / p.rows_per_scale];
 #pragma unroll
       for (int jj = 0; jj < NJ; ++jj) {
         const int nn = DIRECT_COL(jj);
@@ -438,7 +445,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
           const u32x4 hh = extra[i & 1][jj][0];
           const uint32_t hw[4] = {hh[0], hh[1], hh[2], hh[3]};
           gelu_grad_fast_row<CPL / 2>(v, hw);
-        } else if (EPI == EPI_RESIDUAL) {
+        } else if (IS_RES) {
           if (p.gamma || p.rowscale) {
 #pragma unroll
             for (int e = 0; e < CPL; ++e) gam[e] = (p.gamma && nn < p.N && (e < 4 || fulld)) ? p.gamma[nn + e] : 1.f;
@@ -471,7 +478,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
   if (!DIRECT && !((p.debug & 4) && p.M > 1)) {
   float gam[CPL];
 #pragma unroll
-  for (int e = 0; e < CPL; ++e) gam[e] = (EPI == EPI_RESIDUAL && p.gamma && nvalid && (e < 4 || full)) ? p.gamma[n + e] : 1.f;
+  for (int e = 0; e < CPL; ++e) gam[e] = (IS_RES && p.gamma && nvalid && (e < 4 || full)) ? p.gamma[n + e] : 1.f;
 #pragma unroll
   for (int q = 0; q < NCHUNK; ++q) {
     // (1) every wave drops its MREP_C x NREP fragments of this chunk
@@ -526,11 +533,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
           const u32x4 hh = extra[q & 1][r0 + b][0];
           const uint32_t hw[4] = {hh[0], hh[1], hh[2], hh[3]};
           gelu_grad_fast_row<CPL / 2>(v[b], hw);
-        } else if (EPI == EPI_RESIDUAL) {
+        } else if (IS_RES) {
           if (p.gamma || p.rowscale) {
             const int lr = ((r0 + b) * NW + wave) * RPI + lane / LPR;
             const int m = em0 + (lr / (16 * MREP_C)) * WTM + 16 * MREP_C * q + lr % (16 * MREP_C);
-            const float rsc = (p.rowscale && m < p.M) ? p.rowscale[m / p.rows_per_scale] : 1.f;
+            const float rsc = (p.rowscale && m < p.M) ? p.rowscale[(m + p.row_base) / p.rows_per_scale] : 1.f;
 #pragma unroll
             for (int e = 0; e < CPL; ++e) v[b][e] *= gam[e] * rsc;
           }
@@ -770,6 +777,7 @@ static int g_nt_persist = !env_int("TAD_GEMM_NO_PERSIST");
 static int g_nt_stagger_pct = getenv("TAD_GEMM_STAGGER") ? env_int("TAD_GEMM_STAGGER") : 0;  // % of one tile's K-loop time
 static int g_nt_stagger_group = getenv("TAD_GEMM_STAGGER_GROUP") ? env_int("TAD_GEMM_STAGGER_GROUP") : 1;
 static int g_nt_direct = getenv("TAD_GEMM_DIRECT_EPI") ? env_int("TAD_GEMM_DIRECT_EPI") : 1;
+static int g_nt_split = getenv("TAD_GEMM_SPLIT_TAIL") ? env_int("TAD_GEMM_SPLIT_TAIL") : 1;
 
 static unsigned long long* g_nt_stamps = nullptr;
 
@@ -780,7 +788,7 @@ template <int EPI, bool OUT_BF16>
 static void launch_nt_variant(int v, GemmNT& p, hipStream_t st) {
   auto tiles = [&](int bm, int bn) { return ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
   const int no_persist = !g_nt_persist, stagger_pct = g_nt_stagger_pct, stagger_group = g_nt_stagger_group;
-  if (EPI == EPI_RESIDUAL && v == 1) v = 3;  // the 256 x 256 tile has no registers left for the prefetched residual rows
+  if (((EPI == EPI_RESIDUAL && OUT_BF16) || EPI == EPI_RESMOD) && v == 1) v = 3;  // (not instantiated: no registers / never needed)
   const int grid_p = cu_count() & ~7;
   const int bn = v == 1 ? 256 : 128;
   const bool persist = !no_persist && (v == 1 || v == 3) && grid_p >= 8 && tiles(256, bn) >= 2 * grid_p;
@@ -797,7 +805,7 @@ static void launch_nt_variant(int v, GemmNT& p, hipStream_t st) {
   const bool direct = g_nt_direct == 2 || (g_nt_direct == 1 && EPI == EPI_PLAIN && OUT_BF16);
   switch (v) {
     case 1:
-      if constexpr (EPI != EPI_RESIDUAL) {
+      if constexpr (!(EPI == EPI_RESIDUAL && OUT_BF16) && EPI != EPI_RESMOD) {
         if (persist) { if (direct) NT_LAUNCH(256, 256, 2, 4, 2, true, true, grid_p, 512); else NT_LAUNCH(256, 256, 2, 4, 2, true, false, grid_p, 512); }
         else { if (direct) NT_LAUNCH(256, 256, 2, 4, 2, false, true, tiles(256, 256), 512); else NT_LAUNCH(256, 256, 2, 4, 2, false, false, tiles(256, 256), 512); }
       }
@@ -813,6 +821,58 @@ static void launch_nt_variant(int v, GemmNT& p, hipStream_t st) {
 #undef NT_LAUNCH
 }
 
+static int launch_gemm_nt_one(GemmNT p, int v, hipStream_t st) {
+  if (p.epi == EPI_RESIDUAL && p.residual && p.res_mod > 0) p.epi = EPI_RESMOD;
+#define NT_CASE(E)                                                       \
+  case E:                                                                \
+    if (p.c_bf16) launch_nt_variant<E, true>(v, p, st);                  \
+    else launch_nt_variant<E, false>(v, p, st);                          \
+    break;
+  switch (p.epi) {
+    NT_CASE(EPI_PLAIN)
+    NT_CASE(EPI_GELU)
+    NT_CASE(EPI_RESIDUAL)
+    NT_CASE(EPI_DGELU)
+    NT_CASE(EPI_RESMOD)
+    default: set_error("gemm_nt: bad epilogue %d", p.epi); return TAD_EINVAL;
+  }
+#undef NT_CASE
+  return check_launch("gemm_nt");
+}
+
+// rows [r0, r0 + rows) of the problem as a problem of its own
+static GemmNT row_range(const GemmNT& p, int r0, int rows) {
+  GemmNT q = p;
+  const size_t esz = p.c_bf16 ? 2 : 4;
+  q.M = rows;
+  q.row_base = p.row_base + r0;
+  q.A = p.A + (size_t)r0 * p.K;
+  q.C = (char*)p.C + (size_t)r0 * p.N * esz;
+  if (p.residual && p.res_mod <= 0) q.residual = p.residual + (size_t)r0 * p.N;
+  if (p.preact) q.preact = p.preact + (size_t)r0 * p.N;
+  if (p.dgelu_h) q.dgelu_h = p.dgelu_h + (size_t)r0 * p.N;
+  return q;
+}
+
+// Rough cost (us) of one launch on MI355X, from the in-kernel timelines (tools/exp_timeline.py): K-tile of a 256 x 256 tile
+// 1.65 us, of a 256 x 128 tile 1.06 us; epilogue per tile by kind.  Only used to rank plans.
+static double nt_cost(int v, int epi, int c_bf16, int M, int N, int K) {
+  const int cus = cu_count();
+  const double nk = K / 64;
+  if (v == 1) {
+    const double epi_us = (epi == EPI_GELU || epi == EPI_DGELU) ? 9.0 : (epi == EPI_RESIDUAL ? 12.5 : 4.5);
+    const int64_t tiles = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
+    return (double)((tiles + cus - 1) / cus) * (nk * 1.65 + epi_us) + 3.0;
+  }
+  if (v == 3) {
+    const double epi_us = (epi == EPI_GELU || epi == EPI_DGELU) ? 5.5 : (epi == EPI_RESIDUAL ? 6.5 : 3.0);
+    const int64_t tiles = (int64_t)((M + 255) / 256) * ((N + 127) / 128);
+    return (double)((tiles + cus - 1) / cus) * (nk * 1.06 + epi_us) + 3.0;
+  }
+  const int64_t tiles = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
+  return (double)((tiles + 2 * cus - 1) / (2 * cus)) * (nk * 1.3 + 5.0) + 3.0;
+}
+
 int launch_gemm_nt(const GemmNT& p_in, hipStream_t st) {
   GemmNT p = p_in;
   if (!(p.M > 0 && p.N > 0 && p.K > 0)) { set_error("gemm_nt: empty problem"); return TAD_EINVAL; }
@@ -824,23 +884,38 @@ int launch_gemm_nt(const GemmNT& p_in, hipStream_t st) {
   static const int debug = env_int("TAD_GEMM_DEBUG");
   p.debug = debug;
   p.stamps = g_nt_stamps;
-  int v = forced;
-  // measured on MI355X (tools/bench_kernels.py): 256x256 wins when N has many column panels, 256x128 for N <= 1024
-  if (v == 0) v = (p.M < 2048 || p.N < 128) ? 2 : ((p.N >= 1536 && p.N % 256 == 0) ? 1 : 3);
-#define NT_CASE(E)                                                       \
-  case E:                                                                \
-    if (p.c_bf16) launch_nt_variant<E, true>(v, p, st);                  \
-    else launch_nt_variant<E, false>(v, p, st);                          \
-    break;
-  switch (p.epi) {
-    NT_CASE(EPI_PLAIN)
-    NT_CASE(EPI_GELU)
-    NT_CASE(EPI_RESIDUAL)
-    NT_CASE(EPI_DGELU)
-    default: set_error("gemm_nt: bad epilogue %d", p.epi); return TAD_EINVAL;
+  if (forced) return launch_gemm_nt_one(p, forced, st);
+  if (p.M < 2048 || p.N < 128) return launch_gemm_nt_one(p, 2, st);
+  const bool v1_ok = !(p.epi == EPI_RESIDUAL && (p.c_bf16 || p.res_mod > 0));  // (those instantiations do not exist)
+  // Plans: (a) 256 x 128 tiles, (b) 256 x 256 tiles, (c) 256 x 256 tiles for as many row panels as fill whole rounds of one
+  // workgroup per CU, the remaining rows as a second launch with whatever suits that smaller problem.  (c) is what lets the
+  // N = 768 Linears of ViT-B use the (27 % faster per flop) 256 x 256 tile: 196 x 3 tiles are 2.3 rounds of 256 workgroups.
+  const double cost_a = nt_cost(3, p.epi, p.c_bf16, p.M, p.N, p.K);
+  const double cost_b = v1_ok ? nt_cost(1, p.epi, p.c_bf16, p.M, p.N, p.K) : 1e300;
+  double cost_c = 1e300;
+  int main_rows = 0;
+  if (v1_ok && g_nt_split) {
+    const int tiles_n = (p.N + 255) / 256, tiles_m = (p.M + 255) / 256;
+    const int grid = cu_count() & ~7;
+    const int rounds = (int)((int64_t)tiles_m * tiles_n / grid);
+    const int panels = rounds > 0 ? (int)((int64_t)rounds * grid / tiles_n) : 0;
+    if (panels > 0 && panels < tiles_m) {
+      main_rows = panels * 256;
+      const int tail = p.M - main_rows;
+      const double tail_cost = tail < 2048 ? nt_cost(2, p.epi, p.c_bf16, tail, p.N, p.K)
+                                           : fmin(nt_cost(3, p.epi, p.c_bf16, tail, p.N, p.K), nt_cost(1, p.epi, p.c_bf16, tail, p.N, p.K));
+      cost_c = nt_cost(1, p.epi, p.c_bf16, main_rows, p.N, p.K) + tail_cost;
+    }
   }
-#undef NT_CASE
-  return check_launch("gemm_nt");
+  if (g_nt_split == 2 && main_rows > 0) cost_c = 0.0;  // forced (experiments)
+  if (cost_c < cost_a && cost_c < cost_b) {
+    int rc = launch_gemm_nt_one(row_range(p, 0, main_rows), 1, st);
+    if (rc) return rc;
+    const GemmNT t = row_range(p, main_rows, p.M - main_rows);
+    if (t.M < 2048) return launch_gemm_nt_one(t, 2, st);
+    return launch_gemm_nt_one(t, nt_cost(1, t.epi, t.c_bf16, t.M, t.N, t.K) < nt_cost(3, t.epi, t.c_bf16, t.M, t.N, t.K) ? 1 : 3, st);
+  }
+  return launch_gemm_nt_one(p, cost_b < cost_a ? 1 : 3, st);
 }
 
 // TN: 1 = 256x256 (2x4) 2 stages; 3 = 256x128 (4x2) 3 stages.  Splits over the reduction dim target ~1 workgroup per CU.
@@ -938,14 +1013,18 @@ int tad_linear_fwd(const uint16_t* x, const uint16_t* w, const float* bias, void
   return launch_gemm_nt(p, (hipStream_t)stream);
 }
 
-int tad_linear_tuning(int persistent, int stagger_pct, int stagger_group, int direct_epilogue) {
-  TAD_REQUIRE(stagger_group < 0 || (stagger_group >= 1 && stagger_group <= 32 && (stagger_group & (stagger_group - 1)) == 0),
-              "linear_tuning: stagger_group=%d must be a power of two in 1..32", stagger_group);
-  TAD_REQUIRE(stagger_pct <= 400, "linear_tuning: stagger_pct=%d out of range", stagger_pct);
-  if (persistent >= 0) g_nt_persist = persistent != 0;
-  if (stagger_pct >= 0) g_nt_stagger_pct = stagger_pct;
-  if (stagger_group >= 0) g_nt_stagger_group = stagger_group;
-  if (direct_epilogue >= 0) g_nt_direct = direct_epilogue > 2 ? 2 : direct_epilogue;
+int tad_linear_tuning(const char* key, int value) {
+  TAD_REQUIRE(key, "linear_tuning: null key");
+  const std::string k(key);
+  if (k == "persistent") g_nt_persist = value != 0;
+  else if (k == "stagger_pct") { TAD_REQUIRE(value >= 0 && value <= 400, "linear_tuning: stagger_pct=%d out of range", value); g_nt_stagger_pct = value; }
+  else if (k == "stagger_group") {
+    TAD_REQUIRE(value >= 1 && value <= 32 && (value & (value - 1)) == 0, "linear_tuning: stagger_group=%d must be a power of two in 1..32", value);
+    g_nt_stagger_group = value;
+  }
+  else if (k == "direct_epilogue") { TAD_REQUIRE(value >= 0 && value <= 2, "linear_tuning: direct_epilogue=%d not in 0..2", value); g_nt_direct = value; }
+  else if (k == "split_tail") { TAD_REQUIRE(value >= 0 && value <= 2, "linear_tuning: split_tail=%d not in 0..2", value); g_nt_split = value; }
+  else { set_error("linear_tuning: unknown key '%s'", key); return TAD_EINVAL; }
   return TAD_OK;
 }
 

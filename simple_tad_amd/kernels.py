@@ -322,6 +322,15 @@ def linear_fwd(x, w, bias=None, out_dtype=torch.bfloat16, epilogue=EPI_BIAS, wan
     return y, pre
 
 
+LINEAR_TUNING_DEFAULTS = dict(persistent=1, stagger_pct=0, stagger_group=1, direct_epilogue=1, split_tail=1)
+
+
+def linear_tuning(**knobs):
+    """Scheduling knobs of the Linear GEMMs (include/tad_mi355x.h: tad_linear_tuning); timing only, never results."""
+    for k, v in knobs.items():
+        check(_lib.load().tad_linear_tuning(k.encode(), int(v)), f"tad_linear_tuning({k}={v})")
+
+
 def linear_bwd_input(dy, wT, out_dtype=torch.bfloat16, gelu_preact=None):
     """dy [M,N] bf16, wT [K,N] bf16 -> dx [M,K]"""
     _req(dy, torch.bfloat16, "linear_bwd_input.dy")

@@ -306,11 +306,8 @@ def test_attention_f32_fwd_bwd(K, B, N, H):
     check(dqkv.reshape(B, N, -1), ref_dqkv, tol=1e-5, what="attn f32 bwd")
 
 
-DEFAULT_TUNING = (1, 0, 1, 1)  # csrc/gemm.hip defaults: persistent, no stagger, epilogue on the accumulator registers
-
-
 # ---- persistent (one workgroup per CU, staggered starts) vs one-workgroup-per-tile scheduling of the Linear GEMMs.
-# Neither scheduling nor the epilogue's store path (straight from the MFMA layout / transposed through the LDS) may change a
+# Neither scheduling (incl. running a Linear as two launches over row ranges) nor the epilogue's store path (straight from the MFMA layout / transposed through the LDS) may change a
 # single bit: same tiles, same K order, same epilogue arithmetic.  Shapes are large enough
 # for the persistent path (>= 2 tiles per CU) and include ragged M / N edges.
 @pytest.mark.parametrize("M,N,Kd,mode", [
@@ -339,16 +336,19 @@ def test_linear_persistent_schedule_is_bit_identical(K, M, N, Kd, mode):
 
     outs = {}
     try:
-        for name, cfg in [("tile", (0, 0, 1, 0)), ("tile_direct", (0, 0, 1, 2)), ("persist", (1, 100, 1, 0)), ("persist_grouped", (1, 50, 8, 2)),
-                          ("persist_direct", (1, 0, 1, 2)), ("default", DEFAULT_TUNING)]:
-            assert lib.tad_linear_tuning(*cfg) == 0
+        base = dict(persistent=0, stagger_pct=0, stagger_group=1, direct_epilogue=0, split_tail=0)
+        for name, cfg in [("tile", {}), ("tile_direct", dict(direct_epilogue=2)), ("persist", dict(persistent=1, stagger_pct=100)),
+                          ("persist_grouped", dict(persistent=1, stagger_pct=50, stagger_group=8, direct_epilogue=2)),
+                          ("persist_direct", dict(persistent=1, direct_epilogue=2)), ("split", dict(persistent=1, split_tail=2)),
+                          ("default", K.LINEAR_TUNING_DEFAULTS)]:
+            K.linear_tuning(**{**base, **cfg})
             y, pre = run()
             torch.cuda.synchronize()
             outs[name] = (y.clone(), None if pre is None else pre.clone())
     finally:
-        lib.tad_linear_tuning(*DEFAULT_TUNING)
+        K.linear_tuning(**K.LINEAR_TUNING_DEFAULTS)
     y0, p0 = outs["tile"]
-    for name in ("tile_direct", "persist", "persist_grouped", "persist_direct", "default"):
+    for name in ("tile_direct", "persist", "persist_grouped", "persist_direct", "split", "default"):
         y1, p1 = outs[name]
         assert torch.equal(y0, y1), f"{name}: output differs from per-tile scheduling"
         if p0 is not None:

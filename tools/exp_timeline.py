@@ -8,7 +8,7 @@ from simple_tad_amd import kernels as K, _lib
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--shape", default="fc1")
-ap.add_argument("--configs", default="1,0,1,0;1,0,1,1")
+ap.add_argument("--configs", default="persistent=1")
 a = ap.parse_args()
 lib = _lib.load()
 dev, bf, D, M = "cuda", torch.bfloat16, 768, 50176
@@ -24,17 +24,17 @@ elif mode == "res":
 else:
     fn = lambda: K.linear_fwd(x, w, bias)
 for cfg in a.configs.split(";"):
-    c = tuple(int(v) for v in cfg.split(","))
-    lib.tad_linear_tuning(*c)
+    c = dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in cfg.split(","))
+    K.linear_tuning(**{**K.LINEAR_TUNING_DEFAULTS, **c})
     for _ in range(3):
         fn()
     nwg = 4096
-    buf = torch.zeros(nwg * 64 * 16, dtype=torch.int64, device=dev)
+    buf = torch.zeros(nwg * 64 * 32, dtype=torch.int64, device=dev)
     lib.tad_linear_debug_stamps(buf.data_ptr())
     fn()
     torch.cuda.synchronize()
     lib.tad_linear_debug_stamps(None)
-    s = buf.cpu().numpy().reshape(nwg, 64, 16).astype(np.float64)
+    s = buf.cpu().numpy().reshape(nwg, 64, 32).astype(np.float64)
     used = s[:, :, 0] > 0
     t0 = s[:, :, 0][used].min()
     s = (s - t0) / 100.0  # us
@@ -45,13 +45,13 @@ for cfg in a.configs.split(";"):
     for name, v in (("K loop", kloop), ("epilogue", epi), ("drain", drain)):
         print(f"   {name:9s} mean {v.mean():6.2f}  p10 {np.percentile(v, 10):6.2f}  p50 {np.percentile(v, 50):6.2f}  p90 {np.percentile(v, 90):6.2f}  max {v.max():6.2f} us")
     prev = s[:, :, 1]
-    for q in range(4):
+    for q in range(8):
         if not (s[:, :, 4 + 2 * q][used] > 0).any():
             break
         a1, a2 = s[:, :, 4 + 2 * q], s[:, :, 5 + 2 * q]
         print(f"   chunk {q}: transpose+barrier {np.mean((a1 - prev)[used]):5.2f} us, row pass {np.mean((a2 - a1)[used]):5.2f} us")
         prev = a2
-    if c[0]:
+    if c.get('persistent', 1):
         # phase spread: epilogue start times of the 3rd tile of each workgroup, and how many workgroups are inside an epilogue over time
         st = s[:, 2, 1][used[:, 2]]
         print(f"   start of 3rd epilogue: min {st.min():.1f} p25 {np.percentile(st, 25):.1f} p50 {np.percentile(st, 50):.1f} p75 {np.percentile(st, 75):.1f} max {st.max():.1f} us")
