@@ -117,6 +117,15 @@ int tad_linear_fwd(const uint16_t* x, const uint16_t* w, const float* bias, void
  * colscale [N] / rowscale are applied to dy on the fly is NOT supported; scale dy beforehand. */
 int tad_linear_bwd_input(const uint16_t* dy, const uint16_t* wT, void* dx, int dx_dtype,
                          const uint16_t* gelu_preact, int64_t M, int N, int K, tad_stream_t stream);
+/* The qkv Linear of Attention (modeling_finetune.py:64-76, 89-92): bias = cat(q_bias, zeros, v_bias) without materialising it.
+ * N = 3 * all_head_dim; q_bias / v_bias [N/3] f32 (both or neither).  Forward: y = x W^T + bias.  Weight gradient: as
+ * tad_linear_bwd_weight, with the column sums of the first / last third of dy going to dq_bias / dv_bias (workspace: the same
+ * tad_linear_bwd_weight_workspace_bytes). */
+int tad_linear_fwd_qkv(const uint16_t* x, const uint16_t* w, const float* q_bias, const float* v_bias, void* y,
+                       int y_dtype, int64_t M, int N, int K, tad_stream_t stream);
+int tad_linear_bwd_weight_qkv(const uint16_t* dy, const uint16_t* x, float* dW, float* dq_bias, float* dv_bias,
+                              int accumulate, void* ws, size_t ws_bytes, int64_t M, int N, int K,
+                              tad_stream_t stream);
 /* Scheduling knobs of the Linear GEMMs (process-wide; results never depend on them, only timing): tad_linear_tuning(key, value).
  *   "persistent"      1 = one workgroup per CU walks the tile list (default), 0 = one workgroup per tile
  *   "stagger_pct"     span over which the workgroups of a persistent launch spread their start, in % of one tile's K-loop

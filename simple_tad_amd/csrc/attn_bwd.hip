@@ -1,11 +1,12 @@
 // Fused space-time attention backward (recompute, no N x N tensor), head_dim 64, gfx950.
 //
-// Three kernels, all deterministic (no atomics):
-//   1. attn_delta_kernel : delta[b,h,q] = sum_d dO[q,d] * O[q,d]
-//   2. attn_bwd_dq_kernel: one workgroup = 128 query rows, loops over 64-key tiles (structure of the forward kernel):
+// Two kernels, both deterministic (no atomics):
+//   1. attn_bwd_dq_kernel: one workgroup = 128 query rows, loops over 64-key tiles (structure of the forward kernel).  Its
+//        prologue computes delta[b,h,q] = sum_d dO[q,d] * O[q,d] for its own rows (the dO fragments are in registers anyway) and
+//        publishes it for kernel 2 -- a separate delta pass was one more launch and one more read of dO per layer.
 //        S^T = K Q^T, dP^T = V dO^T (query on the lane -> lse/delta are per-lane scalars),
 //        dS^T = P^T o (dP^T - delta), dQ^T += K^T dS^T (dS^T accumulator registers are the MFMA B operand).
-//   3. attn_bwd_dkv_kernel: one workgroup = 128 keys (32 per wave, K/V fragments pinned in registers), loops over
+//   2. attn_bwd_dkv_kernel: one workgroup = 128 keys (32 per wave, K/V fragments pinned in registers), loops over
 //        64-row query tiles: S = Q K^T and dP = dO V^T with the key on the lane and (-lse, -delta) preloaded as the
 //        initial accumulators, then dV^T += dO^T P and dK^T += Q^T dS with P / dS taken straight from the
 //        accumulator registers.
@@ -58,42 +59,11 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int s2) {
   return __builtin_bit_cast(bf16x8, r);
 }
 
-// ------------------------------------------------------------------------------------------------ delta
-__global__ void attn_delta_kernel(const uint16_t* __restrict__ o, const uint16_t* __restrict__ dout, float* __restrict__ delta,
-                                  int B, int N, int H) {
-  // one 8-lane group per (b, q, h) row of 64 elements
-  const int64_t rows = (int64_t)B * N * H;
-  const int64_t gid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x);
-  const int64_t row = gid >> 3;
-  const int sub = (int)(gid & 7);
-  float s = 0.f;
-  if (row < rows) {
-    const uint4 a = *reinterpret_cast<const uint4*>(o + row * BHD + sub * 8);
-    const uint4 g = *reinterpret_cast<const uint4*>(dout + row * BHD + sub * 8);
-    const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, gw[4] = {g.x, g.y, g.z, g.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      s += __uint_as_float(aw[i] << 16) * __uint_as_float(gw[i] << 16);
-      s += __uint_as_float(aw[i] & 0xffff0000u) * __uint_as_float(gw[i] & 0xffff0000u);
-    }
-  }
-  s += __shfl_xor(s, 1, 64);
-  s += __shfl_xor(s, 2, 64);
-  s += __shfl_xor(s, 4, 64);
-  if (row < rows && sub == 0) {
-    // row = (b*N + q)*H + h  ->  delta[b][h][q]
-    const int h = (int)(row % H);
-    const int64_t bq = row / H;
-    const int q = (int)(bq % N);
-    const int64_t b = bq / N;
-    delta[(b * H + h) * N + q] = s;
-  }
-}
-
 // ------------------------------------------------------------------------------------------------ dQ
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
-                                                          const float* __restrict__ lse, const float* __restrict__ delta,
-                                                          uint16_t* __restrict__ dqkv, int N, int H, int B, float scale) {
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out,
+                                                          const uint16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                          float* __restrict__ delta, uint16_t* __restrict__ dqkv, int N, int H, int B,
+                                                          float scale) {
   constexpr int TILE_BYTES = 64 * 128;
   __shared__ __attribute__((aligned(1024))) char lds[2 * 2 * TILE_BYTES];  // [buf][K|V]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -123,7 +93,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
     }
   }
   const float lse2 = lse[((int64_t)b * H + head) * N + qrow] * LOG2E;
-  const float dlt = delta[((int64_t)b * H + head) * N + qrow];
+  // delta = rowsum(dO o O): this lane holds half of its query row (the 8-element groups 2ks + h5), lane ^ 32 the other half
+  float dlt;
+  {
+    const uint16_t* op = out + (((int64_t)b * N + qrow) * H + head) * BHD + 8 * h5;
+    float part = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8 of = *reinterpret_cast<const bf16x8*>(op + 16 * ks);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) part = fmaf((float)of[e], (float)dof[ks][e], part);
+    }
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(part), __float_as_uint(part), false, false);
+    dlt = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    if (qvalid && h5 == 0) delta[((int64_t)b * H + head) * N + qrow] = dlt;
+  }
 
   // K/V tiles go global -> LDS by LDS-DMA (see attn_fwd.hip): 1-KiB piece = 8 keys x 128 B, wave w moves pieces w and w+4 of K and
   // of V; the swizzle is applied to the per-lane SOURCE chunk.  Reads past the tensor return zero; keys >= N are masked below.
@@ -363,13 +347,9 @@ extern "C" int tad_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint
   TAD_REQUIRE(B > 0 && N > 0 && H > 0 && H <= 65535 && B <= 65535, "attn_bwd: bad shape");
   TAD_REQUIRE(scale > 0.f, "attn_bwd: scale must be positive");
   hipStream_t st = (hipStream_t)stream;
-  const int64_t rows = (int64_t)B * N * H;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows * 8 + 255) / 256)), dim3(256), 0, st, out, dout, delta, B, N, H);
-  int rc = check_launch("attn_delta");
-  if (rc) return rc;
   const dim3 grid((unsigned)(((N + 127) / 128) * H * B)), block(256);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, block, 0, st, qkv, dout, lse, delta, dqkv, N, H, B, scale);
-  rc = check_launch("attn_bwd_dq");
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, block, 0, st, qkv, out, dout, lse, delta, dqkv, N, H, B, scale);
+  int rc = check_launch("attn_bwd_dq");
   if (rc) return rc;
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, block, 0, st, qkv, dout, lse, delta, dqkv, N, H, B, scale);
   return check_launch("attn_bwd_dkv");

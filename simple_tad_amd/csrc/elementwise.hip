@@ -278,29 +278,31 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partial, float*
 
 // Same reduction for the "many partial rows, few columns" case (LayerNorm dgamma/dbeta over ~1000 blocks, column sums):
 // one 1024-thread block per 256 columns; the 16 waves stride over the partial rows, 4 loads in flight each, then combine
-// through LDS.  blockIdx.y selects one of up to 3 (partial, out) pairs laid out [q][splits][n] so one launch serves all.
+// through LDS.  blockIdx.y selects one of up to 3 (partial, out) pairs so one launch serves all: pair q starts at
+// partial + q * q_stride and its partial rows are row_stride floats apart ([q][splits][n]: q_stride = splits * n, row_stride = n;
+// column ranges of one [splits][N] array: q_stride = distance between the ranges, row_stride = N).
 __global__ __launch_bounds__(1024) void reduce_cols_kernel(const float* __restrict__ partial, float* out0, float* out1, float* out2,
-                                                           int splits, int n, int accumulate) {
+                                                           int splits, int n, int accumulate, int64_t q_stride, int row_stride) {
   __shared__ float4 red[16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = blockIdx.y;
   float* out = q == 0 ? out0 : (q == 1 ? out1 : out2);
-  const float* base = partial + (int64_t)q * splits * n;
+  const float* base = partial + (int64_t)q * q_stride;
   const int c4 = blockIdx.x * 64 + lane;
   const int n4 = n >> 2;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c4 < n4) {
     int s = wave;
     for (; s + 48 < splits; s += 64) {
-      const float4 a = reinterpret_cast<const float4*>(base + (int64_t)s * n)[c4];
-      const float4 b = reinterpret_cast<const float4*>(base + (int64_t)(s + 16) * n)[c4];
-      const float4 c = reinterpret_cast<const float4*>(base + (int64_t)(s + 32) * n)[c4];
-      const float4 d = reinterpret_cast<const float4*>(base + (int64_t)(s + 48) * n)[c4];
+      const float4 a = reinterpret_cast<const float4*>(base + (int64_t)s * row_stride)[c4];
+      const float4 b = reinterpret_cast<const float4*>(base + (int64_t)(s + 16) * row_stride)[c4];
+      const float4 c = reinterpret_cast<const float4*>(base + (int64_t)(s + 32) * row_stride)[c4];
+      const float4 d = reinterpret_cast<const float4*>(base + (int64_t)(s + 48) * row_stride)[c4];
       acc.x += (a.x + b.x) + (c.x + d.x); acc.y += (a.y + b.y) + (c.y + d.y);
       acc.z += (a.z + b.z) + (c.z + d.z); acc.w += (a.w + b.w) + (c.w + d.w);
     }
     for (; s < splits; s += 16) {
-      const float4 a = reinterpret_cast<const float4*>(base + (int64_t)s * n)[c4];
+      const float4 a = reinterpret_cast<const float4*>(base + (int64_t)s * row_stride)[c4];
       acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
     }
   }
@@ -356,8 +358,17 @@ __global__ void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __re
 // up to three outputs reduced from partial[q][splits][n] in one launch (n % 4 == 0)
 int launch_reduce_cols(const float* partial, float* out0, float* out1, float* out2, int nq, int splits, int n, int accumulate,
                        hipStream_t st) {
-  hipLaunchKernelGGL(reduce_cols_kernel, dim3((n / 4 + 63) / 64, nq), dim3(1024), 0, st, partial, out0, out1, out2, splits, n, accumulate);
+  hipLaunchKernelGGL(reduce_cols_kernel, dim3((n / 4 + 63) / 64, nq), dim3(1024), 0, st, partial, out0, out1, out2, splits, n, accumulate,
+                     (int64_t)splits * n, n);
   return check_launch("reduce_cols");
+}
+
+// two column ranges [c0, c0 + n) and [c1, c1 + n) of partial[splits][N] reduced into out0 / out1 in one launch (n, c0, c1, N % 4 == 0)
+int launch_reduce_col_ranges(const float* partial, int N, int splits, int c0, float* out0, int c1, float* out1, int n, int accumulate,
+                             hipStream_t st) {
+  hipLaunchKernelGGL(reduce_cols_kernel, dim3((n / 4 + 63) / 64, 2), dim3(1024), 0, st, partial + c0, out0, out1, nullptr, splits, n, accumulate,
+                     (int64_t)(c1 - c0), N);
+  return check_launch("reduce_col_ranges");
 }
 
 int launch_reduce_partials(const float* partial, float* out, int splits, int64_t n, int accumulate, hipStream_t st) {

@@ -21,6 +21,8 @@
 namespace tad {
 
 int launch_reduce_partials(const float* partial, float* out, int splits, int64_t n, int accumulate, hipStream_t st);
+int launch_reduce_col_ranges(const float* partial, int N, int splits, int c0, float* out0, int c1, float* out1, int n, int accumulate,
+                             hipStream_t st);
 
 // EPI_RESMOD = EPI_RESIDUAL with the residual row taken modulo res_mod ("+ pos_embed" of the patch embedding): a variant of its
 // own so that the integer division stays out of the Linear kernels
@@ -31,6 +33,8 @@ struct GemmNT {
   const uint16_t* B;  // [N,K]
   void* C;            // [M,N] f32 or bf16
   const float* bias;  // [N] or null
+  const float* bias2; // with bias_seg > 0: columns [0, seg) take bias[n], [2 seg, 3 seg) take bias2[n - 2 seg], the rest 0 (qkv Linear)
+  int bias_seg;
   const float* residual;   // [M or res_mod, N] f32 or null
   const float* gamma;      // [N] or null
   const float* rowscale;   // [ceil(M/rows_per_scale)] or null
@@ -341,8 +345,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
     const int nc = n0 + wn * WTN + (OUT_BF16 ? (32 * (j >> 1) + 8 * kq + 4 * (j & 1)) : (16 * j + 4 * kq));
     f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
     if (EPI != EPI_DGELU && p.bias && nc < p.N) {
-      const float4 t = *reinterpret_cast<const float4*>(p.bias + nc);
-      b4 = f32x4{t.x, t.y, t.z, t.w};
+      if (EPI == EPI_PLAIN && p.bias_seg > 0) {
+        if (nc < p.bias_seg || nc >= 2 * p.bias_seg) {
+          const float4 t = *reinterpret_cast<const float4*>(nc < p.bias_seg ? p.bias + nc : p.bias2 + (nc - 2 * p.bias_seg));
+          b4 = f32x4{t.x, t.y, t.z, t.w};
+        }
+      } else {
+        const float4 t = *reinterpret_cast<const float4*>(p.bias + nc);
+        b4 = f32x4{t.x, t.y, t.z, t.w};
+      }
     }
 #pragma unroll
     for (int i = 0; i < MREP; ++i) acc[i][j] = b4;
@@ -964,8 +975,10 @@ size_t gemm_tn_workspace_bytes(int64_t Mr, int N, int K) {
   return (size_t)s * ((size_t)N * (size_t)K + (size_t)((K + bn - 1) / bn) * (size_t)N) * sizeof(float);
 }
 
-int launch_gemm_tn(const uint16_t* P, const uint16_t* Q, float* out, float* bias_out, int accumulate, void* ws, size_t ws_bytes,
-                   int64_t Mr, int N, int K, hipStream_t st) {
+// bias_out2 != null: the column sums of the first third of the columns go to bias_out, those of the last third to bias_out2 and the
+// middle third is dropped (the qkv Linear: q_bias / no k bias / v_bias, modeling_finetune.py:69-76, 89-92)
+int launch_gemm_tn(const uint16_t* P, const uint16_t* Q, float* out, float* bias_out, float* bias_out2, int accumulate, void* ws,
+                   size_t ws_bytes, int64_t Mr, int N, int K, hipStream_t st) {
   if (!(Mr > 0 && N > 0 && K > 0)) { set_error("gemm_tn: empty problem"); return TAD_EINVAL; }
   if (N % 8 || K % 8) { set_error("gemm_tn: N=%d and K=%d must be multiples of 8", N, K); return TAD_EINVAL; }
   if (Mr * (int64_t)N * 2 >= (1ll << 32) || Mr * (int64_t)K * 2 >= (1ll << 32)) { set_error("gemm_tn: operand exceeds 4 GiB"); return TAD_EINVAL; }
@@ -986,6 +999,7 @@ int launch_gemm_tn(const uint16_t* P, const uint16_t* Q, float* out, float* bias
   if (rc) return rc;
   rc = launch_reduce_partials(p.slab, out, splits, (int64_t)N * K, accumulate, st);
   if (rc || !bias_out) return rc;
+  if (bias_out2) return launch_reduce_col_ranges(p.bias_slab, N, splits * tiles_k, 0, bias_out, 2 * (N / 3), bias_out2, N / 3, accumulate, st);
   return launch_reduce_partials(p.bias_slab, bias_out, splits * tiles_k, N, accumulate, st);
 }
 
@@ -1011,6 +1025,29 @@ int tad_linear_fwd(const uint16_t* x, const uint16_t* w, const float* bias, void
   else if (epilogue == TAD_EPI_BIAS_RESIDUAL) { p.epi = EPI_RESIDUAL; p.residual = residual; p.gamma = gamma; p.rowscale = rowscale; }
   else p.epi = EPI_PLAIN;
   return launch_gemm_nt(p, (hipStream_t)stream);
+}
+
+int tad_linear_fwd_qkv(const uint16_t* x, const uint16_t* w, const float* q_bias, const float* v_bias, void* y, int y_dtype, int64_t M, int N,
+                       int K, tad_stream_t stream) {
+  TAD_REQUIRE(x && w && y, "linear_fwd_qkv: null pointer");
+  TAD_REQUIRE((q_bias == nullptr) == (v_bias == nullptr), "linear_fwd_qkv: q_bias and v_bias come together");
+  TAD_REQUIRE(y_dtype == TAD_F32 || y_dtype == TAD_BF16, "linear_fwd_qkv: bad y_dtype %d", y_dtype);
+  TAD_REQUIRE(N > 0 && N % 12 == 0, "linear_fwd_qkv: N=%d must be 3 x a multiple of 4", N);
+  TAD_REQUIRE(M > 0 && M < (1ll << 31), "linear_fwd_qkv: bad M");
+  GemmNT p{};
+  p.A = x; p.B = w; p.C = y; p.c_bf16 = (y_dtype == TAD_BF16);
+  p.bias = q_bias; p.bias2 = v_bias; p.bias_seg = q_bias ? N / 3 : 0;
+  p.M = (int)M; p.N = N; p.K = K;
+  p.rows_per_scale = 1;
+  p.epi = EPI_PLAIN;
+  return launch_gemm_nt(p, (hipStream_t)stream);
+}
+
+int tad_linear_bwd_weight_qkv(const uint16_t* dy, const uint16_t* x, float* dW, float* dq_bias, float* dv_bias, int accumulate, void* ws,
+                              size_t ws_bytes, int64_t M, int N, int K, tad_stream_t stream) {
+  TAD_REQUIRE(dy && x && dW && ws && dq_bias && dv_bias, "linear_bwd_weight_qkv: null pointer");
+  TAD_REQUIRE(N > 0 && N % 12 == 0, "linear_bwd_weight_qkv: N=%d must be 3 x a multiple of 4", N);
+  return launch_gemm_tn(dy, x, dW, dq_bias, dv_bias, accumulate, ws, ws_bytes, M, N, K, (hipStream_t)stream);
 }
 
 int tad_linear_tuning(const char* key, int value) {
@@ -1054,7 +1091,7 @@ size_t tad_linear_bwd_weight_workspace_bytes(int64_t M, int N, int K) {
 int tad_linear_bwd_weight(const uint16_t* dy, const uint16_t* x, float* dW, float* db, int accumulate, void* ws, size_t ws_bytes,
                           int64_t M, int N, int K, tad_stream_t stream) {
   TAD_REQUIRE(dy && x && dW && ws, "linear_bwd_weight: null pointer");
-  return launch_gemm_tn(dy, x, dW, db, accumulate, ws, ws_bytes, M, N, K, (hipStream_t)stream);
+  return launch_gemm_tn(dy, x, dW, db, nullptr, accumulate, ws, ws_bytes, M, N, K, (hipStream_t)stream);
 }
 
 // ---- PatchEmbed = im2col + NT GEMM with bias and broadcast pos_embed in the epilogue

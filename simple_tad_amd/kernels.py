@@ -368,6 +368,40 @@ def linear_bwd_weight(dy, x, want_bias=True, dW=None, db=None, accumulate=False)
     return dW, (db if want_bias else None)
 
 
+def linear_fwd_qkv(x, w, q_bias, v_bias, out_dtype=torch.bfloat16):
+    """qkv Linear with bias = cat(q_bias, 0, v_bias) (modeling_finetune.py:89-92) taken from the two parameters directly"""
+    _req(x, torch.bfloat16, "linear_qkv.x")
+    _req(w, torch.bfloat16, "linear_qkv.w")
+    M, K = x.shape
+    N, K2 = w.shape
+    if K != K2:
+        raise _lib.TadError(f"linear_qkv: x K={K} vs w K={K2}")
+    if q_bias is not None:
+        _req(q_bias, torch.float32, "linear_qkv.q_bias")
+        _req(v_bias, torch.float32, "linear_qkv.v_bias")
+        assert q_bias.numel() == v_bias.numel() == N // 3
+    y = torch.empty((M, N), dtype=out_dtype, device=x.device)
+    with _timed("gemm_nt", 2.0 * M * N * K, 2.0 * (M * K + N * K) + y.element_size() * M * N):
+        check(_lib.load().tad_linear_fwd_qkv(x.data_ptr(), w.data_ptr(), _p(q_bias), _p(v_bias), y.data_ptr(), _dt(y), M, N, K, _stream()),
+              "tad_linear_fwd_qkv")
+    return y
+
+
+def linear_bwd_weight_qkv(dy, x, dW, dq_bias, dv_bias, accumulate):
+    """weight gradient of the qkv Linear with the bias column sums split into dq_bias / dv_bias [N/3] (in place)"""
+    _req(dy, torch.bfloat16, "linear_bwd_weight_qkv.dy")
+    _req(x, torch.bfloat16, "linear_bwd_weight_qkv.x")
+    M, N = dy.shape
+    M2, K = x.shape
+    assert M == M2 and dq_bias.numel() == dv_bias.numel() == N // 3
+    lib = _lib.load()
+    ws = workspace(lib.tad_linear_bwd_weight_workspace_bytes(M, N, K), dy.device)
+    with _timed("gemm_tn", 2.0 * M * N * K, 2.0 * (M * N + M * K) + 4.0 * N * K):
+        check(lib.tad_linear_bwd_weight_qkv(dy.data_ptr(), x.data_ptr(), dW.data_ptr(), dq_bias.data_ptr(), dv_bias.data_ptr(), int(accumulate),
+                                            ws.data_ptr(), ws.numel(), M, N, K, _stream()), "tad_linear_bwd_weight_qkv")
+    return dW
+
+
 def colsum_bf16(a, out=None):
     _req(a, torch.bfloat16, "colsum.a")
     M, N = a.shape

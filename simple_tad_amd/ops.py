@@ -310,16 +310,27 @@ class PatchEmbedU8Fn(torch.autograd.Function):
 
 # --------------------------------------------------------------------------- attention / mlp cores (2-D tensors)
 def _attn_fwd_core(xn, qkv_w, q_bias, v_bias, B, N, H, scale, train):
-    qkv, _ = K.linear_fwd(xn, w_bf16(qkv_w, train), _qkv_bias(q_bias, v_bias), out_dtype=torch.bfloat16)
+    qkv = K.linear_fwd_qkv(xn, w_bf16(qkv_w, train), None if q_bias is None else _f32c(q_bias.detach()),
+                           None if v_bias is None else _f32c(v_bias.detach()), out_dtype=torch.bfloat16)
     ao, lse = K.attn_fwd(qkv, B, N, H, scale, out_dtype=torch.bfloat16, want_lse=train)
     return qkv, ao, lse
 
 
-def _attn_bwd_core(d_ao, xn, qkv, ao, lse, qkv_w, has_qkv_bias, B, N, H, scale, dx_dtype):
-    """returns dxn, dWqkv, dq_bias, dv_bias"""
+def _attn_bwd_core(d_ao, xn, qkv, ao, lse, qkv_w, has_qkv_bias, B, N, H, scale, dx_dtype, qv_params=None):
+    """returns dxn, dWqkv, dq_bias, dv_bias (None for what went into gradient sinks)"""
     D = xn.shape[1]
     dqkv = K.attn_bwd(qkv, ao, d_ao, lse, B, N, H, scale)
     dxn = K.linear_bwd_input(dqkv, wT_bf16(qkv_w, True), out_dtype=dx_dtype)
+    if has_qkv_bias and qv_params is not None:
+        ents = [_sink(qkv_w), _sink(qv_params[0]), _sink(qv_params[1])]
+        if all(e is not None for e in ents):
+            # dW, dq_bias and dv_bias accumulate straight into the flat gradient buffer: no [3D] temporary, no slicing copies, no
+            # autograd accumulation kernels
+            K.linear_bwd_weight_qkv(dqkv, xn, ents[0][1].view(qkv_w.shape[0], -1), ents[1][1], ents[2][1], accumulate=True)
+            for ent, prm in zip(ents, (qkv_w,) + tuple(qv_params)):
+                if ent[2] is not None:
+                    ent[2](prm)
+            return dxn, None, None, None
     dWqkv, dbqkv = linear_dw(dqkv, xn, qkv_w, None, loose_bias=has_qkv_bias)
     if has_qkv_bias:
         AH = dbqkv.numel() // 3
@@ -342,6 +353,7 @@ class AttentionFn(torch.autograd.Function):
             ctx.save_for_backward(xb, qkv, ao, lse, qkv_w, proj_w)
         ctx.meta = (B, N, H, scale, q_bias is not None, proj_b is not None)
         ctx.proj_b = proj_b
+        ctx.qv = (q_bias, v_bias)
         return y.reshape(B, N, -1)
 
     @staticmethod
@@ -351,7 +363,7 @@ class AttentionFn(torch.autograd.Function):
         dyb = K.cast_bf16(_f32c(dy).reshape(B * N, -1))
         d_ao = K.linear_bwd_input(dyb, wT_bf16(proj_w, True))
         dWp, dbp = linear_dw(dyb, ao, proj_w, ctx.proj_b)
-        dx, dWqkv, dqb, dvb = _attn_bwd_core(d_ao, xb, qkv, ao, lse, qkv_w, has_qb, B, N, H, scale, torch.float32)
+        dx, dWqkv, dqb, dvb = _attn_bwd_core(d_ao, xb, qkv, ao, lse, qkv_w, has_qb, B, N, H, scale, torch.float32, ctx.qv)
         return dx.reshape(B, N, -1), dWqkv, dqb, dvb, dWp, dbp, None, None
 
 
@@ -413,6 +425,7 @@ class BlockFn(torch.autograd.Function):
         ctx.meta = (B, N, D, H, scale, q_bias is not None)
         ctx.biases = (proj_b, fc1_b, fc2_b)
         ctx.norms = (n1w, n1b, n2w, n2b)
+        ctx.qv = (q_bias, v_bias)
         return x2.reshape(B, N, D)
 
     @staticmethod
@@ -437,7 +450,7 @@ class BlockFn(torch.autograd.Function):
         # ---- attention branch
         d_ao = K.linear_bwd_input(gpb, wT_bf16(proj_w, True))
         dWp, _ = linear_dw(gpb, ao, proj_w)
-        dxn1, dWqkv, dqb, dvb = _attn_bwd_core(d_ao, xn1, qkv, ao, lse, qkv_w, has_qb, B, N, H, scale, torch.bfloat16)
+        dxn1, dWqkv, dqb, dvb = _attn_bwd_core(d_ao, xn1, qkv, ao, lse, qkv_w, has_qb, B, N, H, scale, torch.bfloat16, ctx.qv)
         gin, _, dg1, dbeta1, _ = layernorm_bwd_sunk(dxn1, x0, g1, mean1, rstd1, n1w, n1b, dres=gmid)
         return (gin.reshape(B, N, D), dg1, dbeta1, dWqkv, dqb, dvb, dWp, dbp, dg2, dbeta2, dW1, db1, dW2, db2, None, None, None, None,
                 None)
