@@ -358,8 +358,10 @@ class VisionTransformer(nn.Module):
                 x = checkpoint.checkpoint(blk, x, use_reentrant=False)
         else:
             self._presample_drop_path(x.shape[0], x.device)
+            ops.reset_block_chain()
             for blk in self.blocks:
                 x = blk(x)
+            ops.reset_block_chain()  # (keeps the bf16 hand-off entries of a backward that has not run yet: only the forward side is reset)
         x = self._ln(self.norm, x)
         if self.final_reduction == "fc_norm":
             return self._ln(self.fc_norm, ops.MeanPoolFn.apply(x))

@@ -397,6 +397,39 @@ class MlpFn(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------- fused Block
+class _BlockChain:
+    """Hand-off between consecutive fused Blocks.  Block i's backward starts by casting the incoming residual-stream gradient to
+    bf16 scaled by ITS drop-path scale dp2 -- a pass over an f32 [M, D] tensor that block i+1's LayerNorm backward, which produces
+    that very gradient, can emit on the side.  Forward: block i leaves (output pointer, dp2) here; block i+1 picks it up if its
+    input is that output.  Backward: block i+1 leaves the bf16 copy keyed by the f32 gradient's data pointer; block i takes it if
+    the gradient autograd hands over is that tensor.  Anything unexpected (checkpointing, hooks that copy gradients, a consumer
+    in between) just misses and falls back to the cast pass."""
+
+    def __init__(self):
+        self.out_ptr = 0
+        self.dp2 = None
+        self.ready = {}
+        self.enabled = True
+        self.hits = 0  # hand-offs taken (tests)
+
+    def reset(self):
+        self.out_ptr, self.dp2 = 0, None
+        self.ready.clear()
+
+
+_chain = _BlockChain()
+
+
+def reset_block_chain():
+    _chain.reset()
+
+
+def set_block_chain(enabled: bool):
+    """switch the Block-to-Block bf16 gradient hand-off off / on (results are bit-identical either way; for tests and timing)"""
+    _chain.enabled = bool(enabled)
+    _chain.reset()
+
+
 class BlockFn(torch.autograd.Function):
     """Block.forward without layer-scale (modeling_finetune.py:159-163):
          x = x + dp1 * attn(norm1(x));  x = x + dp2 * mlp(norm2(x))
@@ -426,6 +459,9 @@ class BlockFn(torch.autograd.Function):
         ctx.biases = (proj_b, fc1_b, fc2_b)
         ctx.norms = (n1w, n1b, n2w, n2b)
         ctx.qv = (q_bias, v_bias)
+        # block chain: what my backward should emit for the block before me / what the block after me needs to know
+        ctx.prev = (True, _chain.dp2) if (train and _chain.enabled and _chain.out_ptr and _chain.out_ptr == x0.data_ptr()) else (False, None)
+        _chain.out_ptr, _chain.dp2 = x2.data_ptr(), (None if dp2 is None else _f32c(dp2))
         return x2.reshape(B, N, D)
 
     @staticmethod
@@ -437,7 +473,11 @@ class BlockFn(torch.autograd.Function):
         M = B * N
         g = _f32c(g).reshape(M, D)
         # ---- MLP branch
-        gb = K.cast_bf16(g) if dp2 is None else K.scale_cast_bf16(g, None, dp2, N)
+        gb = _chain.ready.pop(g.data_ptr(), None)
+        if gb is None or gb.shape != g.shape:
+            gb = K.cast_bf16(g) if dp2 is None else K.scale_cast_bf16(g, None, dp2, N)
+        else:
+            _chain.hits += 1
         dh = K.linear_bwd_input(gb, wT_bf16(fc2_w, True), gelu_preact=h)
         dW2, db2 = linear_dw(gb, a, fc2_w, fc2_b)
         dxn2 = K.linear_bwd_input(dh, wT_bf16(fc1_w, True))
@@ -451,7 +491,13 @@ class BlockFn(torch.autograd.Function):
         d_ao = K.linear_bwd_input(gpb, wT_bf16(proj_w, True))
         dWp, _ = linear_dw(gpb, ao, proj_w)
         dxn1, dWqkv, dqb, dvb = _attn_bwd_core(d_ao, xn1, qkv, ao, lse, qkv_w, has_qb, B, N, H, scale, torch.bfloat16, ctx.qv)
-        gin, _, dg1, dbeta1, _ = layernorm_bwd_sunk(dxn1, x0, g1, mean1, rstd1, n1w, n1b, dres=gmid)
+        emit, prev_dp2 = ctx.prev
+        if emit:
+            gin, ginb, dg1, dbeta1, _ = layernorm_bwd_sunk(dxn1, x0, g1, mean1, rstd1, n1w, n1b, dres=gmid, want_bf16=True, rowscale=prev_dp2,
+                                                           rows_per_scale=N)
+            _chain.ready[gin.data_ptr()] = ginb
+        else:
+            gin, _, dg1, dbeta1, _ = layernorm_bwd_sunk(dxn1, x0, g1, mean1, rstd1, n1w, n1b, dres=gmid)
         return (gin.reshape(B, N, D), dg1, dbeta1, dWqkv, dqb, dvb, dWp, dbp, dg2, dbeta2, dW1, db1, dW2, db2, None, None, None, None,
                 None)
 

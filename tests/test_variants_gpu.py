@@ -180,3 +180,27 @@ def test_gradient_sinks_write_the_same_gradients_in_place():
     F.cross_entropy(dp(x), y).backward()  # second micro-step accumulates
     for (k, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
         assert rell2(pb.grad, 2 * pa.grad) < 1e-6, k
+
+
+def test_block_chain_handoff_is_bit_identical_and_taken():
+    """Block i+1's LayerNorm backward emits the bf16, drop-path-scaled copy of the residual-stream gradient that block i's backward
+    starts from (ops._BlockChain): same gradients bit for bit as the separate cast pass, and the hand-off is actually used."""
+    from simple_tad_amd import ops
+    m = _model(128, 2, depth=3, drop_path_rate=0.3).cuda().train()
+    x = torch.randn(4, 3, 4, 32, 32).cuda()
+    y = torch.tensor([0, 1, 1, 0]).cuda()
+    grads = {}
+    try:
+        for on in (False, True):
+            ops.set_block_chain(on)
+            ops._chain.hits = 0
+            m.zero_grad(set_to_none=True)
+            torch.manual_seed(7)  # same stochastic-depth masks in both runs
+            F.cross_entropy(m(x), y).backward()
+            grads[on] = {k: p.grad.clone() for k, p in m.named_parameters()}
+            assert ops._chain.hits == (2 if on else 0)  # blocks 0 and 1 take the copy made by blocks 1 and 2
+            assert not ops._chain.ready
+    finally:
+        ops.set_block_chain(True)
+    for k in grads[True]:
+        assert torch.equal(grads[True][k], grads[False][k]), k
