@@ -794,7 +794,7 @@ static unsigned long long* g_nt_stamps = nullptr;
 
 // Tile configurations.  NT: 1 = 256x256 (2x4 waves) 2 stages; 2 = 128x128 (2x2) 2 stages, 2 workgroups/CU;
 // 3 = 256x128 (4x2) 3 stages.  0 = auto.  The epilogue kind and output type are compile-time (the epilogue is VALU-bound).
-// Variants 1 and 3 run as persistent kernels (one workgroup per CU, staggered starts) once there are at least two tiles per CU.
+// Variants 1 and 3 run as persistent kernels (one workgroup per CU walks a tile list) once there are more than 1.5 tiles per CU.
 template <int EPI, bool OUT_BF16>
 static void launch_nt_variant(int v, GemmNT& p, hipStream_t st) {
   auto tiles = [&](int bm, int bn) { return ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
@@ -802,7 +802,7 @@ static void launch_nt_variant(int v, GemmNT& p, hipStream_t st) {
   if (((EPI == EPI_RESIDUAL && OUT_BF16) || EPI == EPI_RESMOD) && v == 1) v = 3;  // (not instantiated: no registers / never needed)
   const int grid_p = cu_count() & ~7;
   const int bn = v == 1 ? 256 : 128;
-  const bool persist = !no_persist && (v == 1 || v == 3) && grid_p >= 8 && tiles(256, bn) >= 2 * grid_p;
+  const bool persist = !no_persist && (v == 1 || v == 3) && grid_p >= 8 && tiles(256, bn) > grid_p + grid_p / 2;
   if (persist) {
     // one K-tile (64 deep) of a 256 x bn tile at ~1.15 PFLOP/s chip-wide: 1.87 us for bn = 256
     const double ktile_us = 2.0 * 256.0 * bn * 64.0 / (1.15e15 / cu_count()) * 1e6;

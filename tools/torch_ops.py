@@ -40,9 +40,9 @@ agg = collections.Counter()
 for ev in prof.events():
     if ev.device_type.name != "CPU" or not ev.name.startswith("aten::"):
         continue
-    if not any(k for k in ev.kernels):
+    if not any(k for k in ev.kernels) and ev.name not in ("aten::copy_", "aten::clone", "aten::_to_copy", "aten::zero_", "aten::fill_"):
         continue
-    frame = next((f for f in ev.stack if "/simple_tad_amd/" in f or "bench" in f or "torch_ops" in f), ev.stack[0] if ev.stack else "?")
+    frame = next((f for f in ev.stack if "simple_tad_amd/" in f or "bench" in f or "torch_ops" in f), ev.stack[0] if ev.stack else "?")
     agg[(ev.name, str(ev.input_shapes)[:60], frame.split("/root/repo/")[-1][:90] if "/root/repo/" in frame else frame[-90:])] += 1
 for (name, shp, fr), n in sorted(agg.items(), key=lambda kv: -kv[1]):
     print(f"{n:4d} x {name:28s} {shp:60s} {fr}")
