@@ -726,7 +726,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(const Ge
     if (!(p.debug & 2)) {                                                                                   \
       _Pragma("unroll") for (int i = 0; i < MREP; ++i)                                                      \
           _Pragma("unroll") for (int j = 0; j < NREP; ++j)                                                  \
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[i], qf[j], acc[i][j], 0, 0, 0);        \
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], pf[i], acc[i][j], 0, 0, 0);        \
     } else {                                                                                                \
       _Pragma("unroll") for (int i = 0; i < MREP; ++i) asm volatile("" ::"v"(pf[i]));                       \
       _Pragma("unroll") for (int j = 0; j < NREP; ++j) asm volatile("" ::"v"(qf[j]));                       \
@@ -760,19 +760,20 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(const Ge
         if (n < p.N) bo[n] = bacc[ib][r];
       }
   }
-  // D[row = n][col = k]: lane col = lane&15, rows 4*(lane>>4) + r
+  // The Q (k) fragments feed the MFMA's row operand, so D[row = k][col = n]: lane (li, g) holds k = 4g .. 4g+3 of output row
+  // n = li -- one 16-byte store per fragment (16 rows x 64 contiguous bytes per instruction) instead of four 4-byte stores.
+  // K % 8 == 0, so a group of four k is either wholly inside or wholly outside.
   float* out = p.slab + (int64_t)split * p.N * p.K;
 #pragma unroll
-  for (int i = 0; i < MREP; ++i)
+  for (int i = 0; i < MREP; ++i) {
+    const int n = n0 + wm * WTM + 16 * i + li;
 #pragma unroll
     for (int j = 0; j < NREP; ++j) {
-      const int k = k0 + wn * WTN + 16 * j + li;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int n = n0 + wm * WTM + 16 * i + 4 * g + r;
-        if (n < p.N && k < p.K) out[(int64_t)n * p.K + k] = acc[i][j][r];
-      }
+      const int k = k0 + wn * WTN + 16 * j + 4 * g;
+      if (n < p.N && k < p.K)
+        *reinterpret_cast<float4*>(out + (int64_t)n * p.K + k) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
     }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------
