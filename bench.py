@@ -237,8 +237,12 @@ def main():
                 traffic = None
             out["roofline"] = {"kernel": "gemm_nt_kernel (bf16 MFMA GEMM, all Linear fwd / input-grad launches)", "bound": "mfma",
                                "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "launches": prof.seen.get("gemm_nt", g["launches"]),
-                               "sampled_launches": g["launches"], "avg_launch_us": round(1e3 * g["ms"] / g["launches"], 2),
+                               "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                               # a Linear call is one kernel launch, or two under the split-tail plan (whole rounds of 256x256
+                               # tiles + remaining rows): times and flops are per KERNEL launch, as rocprofv3 counts them
+                               "calls": prof.seen.get("gemm_nt", g["calls"]), "sampled_calls": g["calls"], "sampled_launches": g["launches"],
+                               "launches": round(prof.seen.get("gemm_nt", g["calls"]) * g["launches"] / max(g["calls"], 1)),
+                               "avg_launch_us": round(1e3 * g["ms"] / g["launches"], 2),
                                "gflop_per_launch": round(g["flops"] / g["launches"] / 1e9, 2)}
         tot = sum(v["ms"] for v in summ.values())
         if args.breakdown:

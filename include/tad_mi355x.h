@@ -136,6 +136,9 @@ int tad_linear_bwd_weight_qkv(const uint16_t* dy, const uint16_t* x, float* dW, 
  *   "split_tail"      1 = a Linear whose 256 x 256 tiles do not fill whole rounds of one workgroup per CU may run as two
  *                     launches (whole rounds + remaining rows) when the cost model says so (default); 0 = never; 2 = always */
 int tad_linear_tuning(const char* key, int value);
+/* Number of gemm_nt kernel launches issued so far by tad_linear_fwd* / tad_linear_bwd_input / tad_patch_embed_* (a call is one
+ * launch, or two when the split-tail plan is taken): lets a profiler attribute event time to kernel launches. */
+long long tad_linear_kernel_launches(void);
 /* Debug timeline of the Linear GEMM kernels: while buf (device memory, >= gridDim * 64 * 32 * 8 bytes, caller-owned) is set,
  * every workgroup records s_memrealtime (100 MHz) for each of its first 64 tiles: slot 0 tile start, 1 K-loop end, 2 epilogue
  * issued, 3 stores acknowledged, 4 + 2q / 5 + 2q epilogue chunk q transposed / stored.  NULL switches it off (default).  Costs a store drain per tile: never leave it on. */

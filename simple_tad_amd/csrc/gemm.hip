@@ -792,6 +792,7 @@ static int g_nt_direct = getenv("TAD_GEMM_DIRECT_EPI") ? env_int("TAD_GEMM_DIREC
 static int g_nt_split = getenv("TAD_GEMM_SPLIT_TAIL") ? env_int("TAD_GEMM_SPLIT_TAIL") : 1;
 
 static unsigned long long* g_nt_stamps = nullptr;
+static long long g_nt_launches = 0;  // gemm_nt kernel launches so far (tad_linear_kernel_launches)
 
 // Tile configurations.  NT: 1 = 256x256 (2x4 waves) 2 stages; 2 = 128x128 (2x2) 2 stages, 2 workgroups/CU;
 // 3 = 256x128 (4x2) 3 stages.  0 = auto.  The epilogue kind and output type are compile-time (the epilogue is VALU-bound).
@@ -834,6 +835,7 @@ static void launch_nt_variant(int v, GemmNT& p, hipStream_t st) {
 }
 
 static int launch_gemm_nt_one(GemmNT p, int v, hipStream_t st) {
+  ++g_nt_launches;
   if (p.epi == EPI_RESIDUAL && p.residual && p.res_mod > 0) p.epi = EPI_RESMOD;
 #define NT_CASE(E)                                                       \
   case E:                                                                \
@@ -1065,6 +1067,8 @@ int tad_linear_tuning(const char* key, int value) {
   else { set_error("linear_tuning: unknown key '%s'", key); return TAD_EINVAL; }
   return TAD_OK;
 }
+
+long long tad_linear_kernel_launches(void) { return g_nt_launches; }
 
 int tad_linear_debug_stamps(void* buf) {
   g_nt_stamps = (unsigned long long*)buf;

@@ -40,17 +40,18 @@ class LaunchProfiler:
         e.record(torch.cuda.current_stream())
         return e
 
-    def end(self, start, kernel, flops, nbytes):
+    def end(self, start, kernel, flops, nbytes, kernel_launches=1):
         e = torch.cuda.Event(enable_timing=True)
         e.record(torch.cuda.current_stream())
-        self.items.append((kernel, start, e, flops, nbytes))
+        self.items.append((kernel, start, e, flops, nbytes, kernel_launches))
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for kernel, s, e, flops, nbytes in self.items:
-            d = out.setdefault(kernel, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
-            d["launches"] += 1
+        for kernel, s, e, flops, nbytes, nk in self.items:
+            d = out.setdefault(kernel, {"launches": 0, "calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            d["launches"] += nk
+            d["calls"] += 1
             d["ms"] += s.elapsed_time(e)
             d["flops"] += flops
             d["bytes"] += nbytes
@@ -66,17 +67,21 @@ def set_profiler(p):
 
 
 class _timed:
-    __slots__ = ("k", "f", "b", "s")
+    __slots__ = ("k", "f", "b", "s", "n0")
 
     def __init__(self, kernel, flops=0.0, nbytes=0.0):
         self.k, self.f, self.b = kernel, flops, nbytes
 
     def __enter__(self):
         self.s = _prof.begin() if (_prof is not None and _prof.wants(self.k)) else None
+        if self.s is not None and self.k == "gemm_nt":
+            self.n0 = _lib.load().tad_linear_kernel_launches()
 
     def __exit__(self, *a):
         if self.s is not None:
-            _prof.end(self.s, self.k, self.f, self.b)
+            # a Linear call is one gemm_nt kernel launch, or two under the split-tail plan: count kernels, not calls
+            n = (_lib.load().tad_linear_kernel_launches() - self.n0) if self.k == "gemm_nt" else 1
+            _prof.end(self.s, self.k, self.f, self.b, n)
 
 
 def _stream() -> int:
