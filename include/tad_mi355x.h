@@ -133,6 +133,9 @@ int tad_linear_bwd_weight_qkv(const uint16_t* dy, const uint16_t* x, float* dW, 
  *   "stagger_group"   workgroups of an XCD start in groups of this many (power of two, default 1)
  *   "direct_epilogue" 2 = epilogue on the accumulator registers, stores straight from the MFMA layout; 0 = accumulators
  *                     transposed through the LDS first (whole rows per store instruction); 1 = per epilogue kind (default)
+ *   "dynamic_tiles"   1 = the workgroups of a persistent launch pull their tiles (after the first) from per-XCD counters (robust
+ *                     when another stream's kernel holds some CUs; the counters live in a 16 KiB ring the library allocates once
+ *                     per device on first use; measured 7 % slower per launch inside a training step), 0 = fixed lists (default)
  *   "split_tail"      1 = a Linear whose 256 x 256 tiles do not fill whole rounds of one workgroup per CU may run as two
  *                     launches (whole rounds + remaining rows) when the cost model says so (default); 0 = never; 2 = always */
 int tad_linear_tuning(const char* key, int value);

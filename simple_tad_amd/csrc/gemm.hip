@@ -49,6 +49,8 @@ struct GemmNT {
   int debug;  // ablation (TAD_GEMM_DEBUG, timing only, wrong results): 1 = no DMA inside the K loop, 2 = no MFMA, 4 = no epilogue
   int stagger_ticks;  // persistent kernel: span (10 ns ticks of s_memrealtime) over which the workgroups of an XCD spread their start
   int stagger_group;  // workgroups of an XCD start in groups of this many (power of two)
+  int* sched;        // persistent kernel: 8 tile counters (one per XCD) of this launch, or null = fixed tile lists
+  int* sched_clear;  // 8 counters of another slot of the ring to reset (see launch_nt_variant)
   unsigned long long* stamps;  // debug timeline (tad_linear_debug_stamps): per workgroup 64 slots of 4 x s_memrealtime, or null
 };
 
@@ -101,7 +103,7 @@ __device__ __forceinline__ int sw_rows(int row) { return BKT == 64 ? sw_nt(row) 
 // PERSIST: one workgroup per CU walks a strided list of tiles (see the comment at the tile loop).
 // DIRECT: the epilogue runs on the accumulator registers and stores straight from the MFMA layout (16 rows x 64 contiguous bytes
 // per store instruction); otherwise the accumulators are transposed through the LDS first (whole rows per instruction).
-template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int BKT, int MIN_WAVES, int EPI, bool OUT_BF16, bool PERSIST, bool DIRECT>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int BKT, int MIN_WAVES, int EPI, bool OUT_BF16, bool PERSIST, bool DIRECT, bool DYN = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kernel(const GemmNT p) {
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr bool IS_RES = (EPI == EPI_RESIDUAL || EPI == EPI_RESMOD);
@@ -145,12 +147,22 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
   const int per_group = GROUP_M * tiles_n;
-  int t_cur, t_end, t_step;
+  // Dynamic lists (p.sched): only the first tile of a workgroup is fixed (first + j); every further one is pulled from its XCD's
+  // counter (one returning atomic per tile, issued right after a K loop -- never inside it -- and consumed after the next one, so a
+  // workgroup always holds one tile in reserve).  A
+  // workgroup that starts late -- its CU was busy with another stream's kernel, e.g. an RCCL collective beside the backward pass --
+  // then simply finds fewer tiles left, instead of doubling the launch's time with a full list of its own.
+  __shared__ int next_idx_lds[1];
+  int t_cur, t_end, t_step, t_first = 0, fetched = 0;
+  const int xcd = blockIdx.x & 7;
   if (PERSIST) {
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    t_cur = xcd_remap(xcd, tiles_m * tiles_n) + j;  // first id of this XCD's range (+ j)
-    t_end = xcd_remap(xcd, tiles_m * tiles_n) + (tiles_m * tiles_n >> 3) + ((xcd < ((tiles_m * tiles_n) & 7)) ? 1 : 0);
+    const int j = blockIdx.x >> 3;
+    t_first = xcd_remap(xcd, tiles_m * tiles_n);  // first id of this XCD's range
+    t_cur = t_first + j;
+    t_end = t_first + (tiles_m * tiles_n >> 3) + ((xcd < ((tiles_m * tiles_n) & 7)) ? 1 : 0);
     t_step = gridDim.x >> 3;
+    if (DYN && p.sched_clear && blockIdx.x == 0 && tid < 8) p.sched_clear[tid] = 0;
+    if (DYN && tid == 0) fetched = __hip_atomic_fetch_add(p.sched + xcd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (p.stagger_ticks > 0) {
       const int ph = j & ~(p.stagger_group - 1);
       const uint64_t wait = (uint64_t)p.stagger_ticks * ph / t_step;
@@ -405,9 +417,18 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
   // a wave covers whole contiguous rows (512 B - 1 KiB runs).  The epilogue is VALU-bound (128 outputs per lane), so the
   // variant (EPI, OUT_BF16) is a template parameter, offsets are 32-bit, and loads are issued BATCH rows ahead because the CU
   // has only NW waves to cover HBM latency.
-  t_cur += t_step;
+  if (PERSIST && DYN) {
+    if (tid == 0) {
+      next_idx_lds[0] = fetched;  // (the compiler waits for the atomic issued one tile ago -- or at kernel start -- here)
+      fetched = __hip_atomic_fetch_add(p.sched + xcd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the tile after next
+    }
+    lds_barrier();  // every wave is done with the ring (its LDS reads were consumed by the MFMAs above); next_idx_lds is published
+    t_cur = t_first + t_step + __builtin_amdgcn_readfirstlane(next_idx_lds[0]);
+  } else {
+    t_cur += t_step;
+    block_barrier();  // every wave is done with the ring
+  }
   const bool has_next = PERSIST && t_cur < t_end;
-  block_barrier();  // every wave is done with the ring (its LDS reads were consumed by the MFMAs above)
   STAMP(1);
   if (has_next) {
     DECODE_TILE(t_cur);
@@ -790,8 +811,33 @@ static int g_nt_stagger_pct = getenv("TAD_GEMM_STAGGER") ? env_int("TAD_GEMM_STA
 static int g_nt_stagger_group = getenv("TAD_GEMM_STAGGER_GROUP") ? env_int("TAD_GEMM_STAGGER_GROUP") : 1;
 static int g_nt_direct = getenv("TAD_GEMM_DIRECT_EPI") ? env_int("TAD_GEMM_DIRECT_EPI") : 1;
 static int g_nt_split = getenv("TAD_GEMM_SPLIT_TAIL") ? env_int("TAD_GEMM_SPLIT_TAIL") : 1;
+static int g_nt_dynamic = getenv("TAD_GEMM_DYNAMIC") ? env_int("TAD_GEMM_DYNAMIC") : 0;  // measured: +7 % gemm_nt time in the full step
 
 static unsigned long long* g_nt_stamps = nullptr;
+
+// Tile counters of the persistent kernels with dynamic lists: a ring of SCHED_SLOTS slots of 8 ints (one counter per XCD), one slot
+// per launch in rotation.  A launch resets the slot half a ring ahead of its own (used long ago, needed again only half a ring
+// later), so no memset launch is needed and launches on different streams never share a slot.  The ring is the library's only
+// device allocation (16 KiB per device, made on the first persistent launch); a launch that is being captured into a HIP graph
+// takes fixed lists instead (a replayed node would find its slot used up).
+constexpr int SCHED_SLOTS = 512;
+static int* g_sched_ring[64] = {};
+static unsigned g_sched_seq = 0;
+static int* sched_ring(hipStream_t st) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!g_sched_ring[dev]) {
+    int* ptr = nullptr;
+    if (hipMalloc(&ptr, SCHED_SLOTS * 8 * sizeof(int)) != hipSuccess || hipMemset(ptr, 0, SCHED_SLOTS * 8 * sizeof(int)) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    g_sched_ring[dev] = ptr;
+  }
+  return g_sched_ring[dev];
+}
 static long long g_nt_launches = 0;  // gemm_nt kernel launches so far (tad_linear_kernel_launches)
 
 // Tile configurations.  NT: 1 = 256x256 (2x4 waves) 2 stages; 2 = 128x128 (2x2) 2 stages, 2 workgroups/CU;
@@ -805,14 +851,27 @@ static void launch_nt_variant(int v, GemmNT& p, hipStream_t st) {
   const int grid_p = cu_count() & ~7;
   const int bn = v == 1 ? 256 : 128;
   const bool persist = !no_persist && (v == 1 || v == 3) && grid_p >= 8 && tiles(256, bn) > grid_p + grid_p / 2;
+  p.sched = p.sched_clear = nullptr;
+  if (persist && g_nt_dynamic) {
+    if (int* ring = sched_ring(st)) {
+      const unsigned seq = g_sched_seq++;
+      p.sched = ring + (seq % SCHED_SLOTS) * 8;
+      p.sched_clear = ring + ((seq + SCHED_SLOTS / 2) % SCHED_SLOTS) * 8;
+    }
+  }
   if (persist) {
     // one K-tile (64 deep) of a 256 x bn tile at ~1.15 PFLOP/s chip-wide: 1.87 us for bn = 256
     const double ktile_us = 2.0 * 256.0 * bn * 64.0 / (1.15e15 / cu_count()) * 1e6;
     p.stagger_ticks = (int)(ktile_us * (p.K / 64) * 100.0 * stagger_pct / 100.0);
     p.stagger_group = stagger_group > 0 ? stagger_group : 1;
   }
-#define NT_LAUNCH(BM_, BN_, WM_, WN_, ST_, PER_, DIR_, GRID_, THREADS_) \
-  hipLaunchKernelGGL((gemm_nt_kernel<BM_, BN_, WM_, WN_, ST_, 64, 1, EPI, OUT_BF16, PER_, DIR_>), dim3(GRID_), dim3(THREADS_), 0, st, p)
+#define NT_LAUNCH(BM_, BN_, WM_, WN_, ST_, PER_, DIR_, GRID_, THREADS_)                                                              \
+  do {                                                                                                                             \
+    if (PER_ && p.sched)                                                                                                           \
+      hipLaunchKernelGGL((gemm_nt_kernel<BM_, BN_, WM_, WN_, ST_, 64, 1, EPI, OUT_BF16, PER_, DIR_, PER_>), dim3(GRID_), dim3(THREADS_), 0, st, p); \
+    else                                                                                                                           \
+      hipLaunchKernelGGL((gemm_nt_kernel<BM_, BN_, WM_, WN_, ST_, 64, 1, EPI, OUT_BF16, PER_, DIR_, false>), dim3(GRID_), dim3(THREADS_), 0, st, p); \
+  } while (0)
   // measured per shape (tools/exp_epilogue.py): storing straight from the MFMA layout wins only for the bias-only bf16 epilogue
   // (nothing to fetch, no arithmetic); the others keep the LDS transposition.  g_nt_direct: 0 = never, 1 = auto, 2 = always.
   const bool direct = g_nt_direct == 2 || (g_nt_direct == 1 && EPI == EPI_PLAIN && OUT_BF16);
@@ -1063,6 +1122,7 @@ int tad_linear_tuning(const char* key, int value) {
     g_nt_stagger_group = value;
   }
   else if (k == "direct_epilogue") { TAD_REQUIRE(value >= 0 && value <= 2, "linear_tuning: direct_epilogue=%d not in 0..2", value); g_nt_direct = value; }
+  else if (k == "dynamic_tiles") g_nt_dynamic = value != 0;
   else if (k == "split_tail") { TAD_REQUIRE(value >= 0 && value <= 2, "linear_tuning: split_tail=%d not in 0..2", value); g_nt_split = value; }
   else { set_error("linear_tuning: unknown key '%s'", key); return TAD_EINVAL; }
   return TAD_OK;

@@ -336,10 +336,11 @@ def test_linear_persistent_schedule_is_bit_identical(K, M, N, Kd, mode):
 
     outs = {}
     try:
-        base = dict(persistent=0, stagger_pct=0, stagger_group=1, direct_epilogue=0, split_tail=0)
+        base = dict(persistent=0, stagger_pct=0, stagger_group=1, direct_epilogue=0, split_tail=0, dynamic_tiles=0)
         for name, cfg in [("tile", {}), ("tile_direct", dict(direct_epilogue=2)), ("persist", dict(persistent=1, stagger_pct=100)),
                           ("persist_grouped", dict(persistent=1, stagger_pct=50, stagger_group=8, direct_epilogue=2)),
                           ("persist_direct", dict(persistent=1, direct_epilogue=2)), ("split", dict(persistent=1, split_tail=2)),
+                          ("persist_dynamic", dict(persistent=1, dynamic_tiles=1)), ("split_dynamic", dict(persistent=1, split_tail=2, dynamic_tiles=1)),
                           ("default", K.LINEAR_TUNING_DEFAULTS)]:
             K.linear_tuning(**{**base, **cfg})
             y, pre = run()
@@ -348,7 +349,7 @@ def test_linear_persistent_schedule_is_bit_identical(K, M, N, Kd, mode):
     finally:
         K.linear_tuning(**K.LINEAR_TUNING_DEFAULTS)
     y0, p0 = outs["tile"]
-    for name in ("tile_direct", "persist", "persist_grouped", "persist_direct", "split", "default"):
+    for name in ("tile_direct", "persist", "persist_grouped", "persist_direct", "split", "persist_dynamic", "split_dynamic", "default"):
         y1, p1 = outs[name]
         assert torch.equal(y0, y1), f"{name}: output differs from per-tile scheduling"
         if p0 is not None:
