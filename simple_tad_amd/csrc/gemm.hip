@@ -75,8 +75,9 @@ __device__ __forceinline__ void stage_tile(const void* gbase, int gbytes, char* 
 // instructions are still outstanding
 template <int LOADS, int EXTRA = 0>
 __device__ __forceinline__ void wait_stage(int stages_in_flight) {
-  static_assert(2 * LOADS + EXTRA <= 63, "vmcnt immediate is 6 bits");
-  if (stages_in_flight >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS + EXTRA) : "memory");
+  static_assert(3 * LOADS + EXTRA <= 63, "vmcnt immediate is 6 bits");
+  if (stages_in_flight >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LOADS + EXTRA) : "memory");
+  else if (stages_in_flight == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS + EXTRA) : "memory");
   else if (stages_in_flight == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS + EXTRA) : "memory");
   else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EXTRA) : "memory");
 }
