@@ -218,3 +218,41 @@ def test_precise_mode_training_step_vs_reference_golden(golden):
         sq = float(g[f"grad.{k}.sqsum"])
         assert abs((v.double() ** 2).sum().item() - sq) < 2e-3 * sq, k
     print("precise worst grad rel-l2", worst)
+
+
+# ------------------------------------------------------------------ full-size properties (BASELINE configs[1] / configs[2])
+def test_full_size_batch_properties():
+    """ViT-B/16 16x224^2 at the benchmark's batch of 32, where no oracle finishes in seconds: size-independent properties.
+    (1) Clips are independent: a clip's features in the batch of 32 (persistent 256x256-tile GEMMs, split-tail plan) equal its
+        features run alone (per-tile 256x128 / 128x128 grids) BIT FOR BIT -- every output row sees the same K order and the same
+        epilogue arithmetic whatever the tile plan.
+    (2) The loss gradient is additive over clips: grads of the 32-clip sum-loss equal the sum of the grads of its two halves (the dW
+        GEMMs split their reduction differently: f32 summation order only)."""
+    torch.manual_seed(0)
+    m = T.create_model("vit_base_patch16_224", pretrained=False, num_classes=2, all_frames=16, tubelet_size=2, final_reduction="fc_norm",
+                       use_flash_attn=True, init_scale=1.0, drop_path_rate=0.0).cuda()
+    gen = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if p.dim() == 1:
+                p.copy_((torch.randn(p.shape, generator=gen) * 0.02 + (1.0 if "norm" in k and k.endswith("weight") else 0.0)).cuda())
+    x = torch.randn(32, 3, 16, 224, 224, generator=torch.Generator().manual_seed(6)).cuda()
+    y = torch.randint(0, 2, (32,), generator=torch.Generator().manual_seed(7)).cuda()
+    m.eval()
+    with torch.no_grad():
+        f32 = m.forward_features(x)
+        for i in (0, 17, 31):
+            fi = m.forward_features(x[i:i + 1])
+            assert torch.equal(fi[0], f32[i]), f"clip {i}: features depend on the batch it is in"
+    m.train()  # drop_path_rate = 0: deterministic
+
+    def grads(xs, ys):
+        m.zero_grad(set_to_none=True)
+        F.cross_entropy(m(xs), ys, reduction="sum").backward()
+        return {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+
+    g_all = grads(x, y)
+    g_a, g_b = grads(x[:16], y[:16]), grads(x[16:], y[16:])
+    worst = max(rell2(g_a[k] + g_b[k], g_all[k]) for k in g_all)
+    print("full-size additivity: worst rel-l2 over parameters", worst)
+    assert worst < 1e-3
