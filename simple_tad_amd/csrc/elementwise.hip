@@ -371,6 +371,60 @@ int launch_reduce_col_ranges(const float* partial, int N, int splits, int c0, fl
   return check_launch("reduce_col_ranges");
 }
 
+// The two reductions that follow a dW GEMM in ONE launch: the split-K slabs (as reduce_partials_kernel) and, in extra blocks at the
+// end of the grid, the bias column sums partial2[rows2][n2] -> out2a (columns [0, n2a)) and, if out2b, columns [c2b, c2b + n2a) ->
+// out2b (the qkv Linear: q_bias / v_bias ranges), else all n2 columns -> out2a.
+__global__ void reduce_dw_kernel(const float* __restrict__ partial, float* __restrict__ out, int splits, int64_t n, int accumulate,
+                                 int slab_blocks, const float* __restrict__ partial2, int rows2, int n2, float* out2a, float* out2b, int n2a,
+                                 int c2b) {
+  if ((int)blockIdx.x < slab_blocks) {
+    const int64_t stride = (int64_t)slab_blocks * blockDim.x;
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+      float4 s = reinterpret_cast<const float4*>(partial)[i];
+      for (int k = 1; k < splits; ++k) {
+        const float4 v = reinterpret_cast<const float4*>(partial + (int64_t)k * n)[i];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      if (accumulate) {
+        const float4 o = reinterpret_cast<float4*>(out)[i];
+        s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+      }
+      reinterpret_cast<float4*>(out)[i] = s;
+    }
+    return;
+  }
+  // bias job: one float4 column group per thread
+  const int c4 = ((int)blockIdx.x - slab_blocks) * blockDim.x + threadIdx.x;
+  const int groups = n2a >> 2;
+  const int total = out2b ? 2 * groups : groups;
+  if (c4 >= total) return;
+  const bool second = c4 >= groups;
+  const int col = second ? c2b + 4 * (c4 - groups) : 4 * c4;
+  float* dst = (second ? out2b : out2a) + (second ? 4 * (c4 - groups) : 4 * c4);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int r = 0; r < rows2; ++r) {
+    const float4 v = *reinterpret_cast<const float4*>(partial2 + (int64_t)r * n2 + col);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  if (accumulate) {
+    const float4 o = *reinterpret_cast<float4*>(dst);
+    s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+  }
+  *reinterpret_cast<float4*>(dst) = s;
+}
+
+// n % 4 == 0, n2 % 4 == 0; out2b != null: two ranges of n2a columns each (the second starting at column c2b), else n2a = n2
+int launch_reduce_dw(const float* partial, float* out, int splits, int64_t n, int accumulate, const float* partial2, int rows2, int n2,
+                     float* out2a, float* out2b, int n2a, int c2b, hipStream_t st) {
+  const int slab_blocks = capped_grid((n + 3) / 4, 256);
+  const int groups = (out2b ? 2 : 1) * (n2a / 4);
+  const int bias_blocks = (groups + 255) / 256;
+  hipLaunchKernelGGL(reduce_dw_kernel, dim3(slab_blocks + bias_blocks), dim3(256), 0, st, partial, out, splits, n, accumulate, slab_blocks,
+                     partial2, rows2, n2, out2a, out2b, n2a, c2b);
+  return check_launch("reduce_dw");
+}
+
 int launch_reduce_partials(const float* partial, float* out, int splits, int64_t n, int accumulate, hipStream_t st) {
   if (n <= 16384 && splits >= 16 && (n & 3) == 0) return launch_reduce_cols(partial, out, nullptr, nullptr, 1, splits, (int)n, accumulate, st);
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(capped_grid((n + 3) / 4, 256)), dim3(256), 0, st, partial, out, splits, n,

@@ -23,6 +23,8 @@ namespace tad {
 int launch_reduce_partials(const float* partial, float* out, int splits, int64_t n, int accumulate, hipStream_t st);
 int launch_reduce_col_ranges(const float* partial, int N, int splits, int c0, float* out0, int c1, float* out1, int n, int accumulate,
                              hipStream_t st);
+int launch_reduce_dw(const float* partial, float* out, int splits, int64_t n, int accumulate, const float* partial2, int rows2, int n2,
+                     float* out2a, float* out2b, int n2a, int c2b, hipStream_t st);
 
 // EPI_RESMOD = EPI_RESIDUAL with the residual row taken modulo res_mod ("+ pos_embed" of the patch embedding): a variant of its
 // own so that the integer division stays out of the Linear kernels
@@ -1060,10 +1062,10 @@ int launch_gemm_tn(const uint16_t* P, const uint16_t* Q, float* out, float* bias
     hipLaunchKernelGGL((gemm_tn_kernel<256, 128, 4, 2, 3>), dim3(tiles * splits), dim3(512), 0, st, p);
   int rc = check_launch("gemm_tn");
   if (rc) return rc;
-  rc = launch_reduce_partials(p.slab, out, splits, (int64_t)N * K, accumulate, st);
-  if (rc || !bias_out) return rc;
-  if (bias_out2) return launch_reduce_col_ranges(p.bias_slab, N, splits * tiles_k, 0, bias_out, 2 * (N / 3), bias_out2, N / 3, accumulate, st);
-  return launch_reduce_partials(p.bias_slab, bias_out, splits * tiles_k, N, accumulate, st);
+  if (!bias_out) return launch_reduce_partials(p.slab, out, splits, (int64_t)N * K, accumulate, st);
+  // slab reduction and bias column sums in one launch (N * K % 4 == 0 and N % 4 == 0 hold: N, K are multiples of 8)
+  if (bias_out2) return launch_reduce_dw(p.slab, out, splits, (int64_t)N * K, accumulate, p.bias_slab, splits * tiles_k, N, bias_out, bias_out2, N / 3, 2 * (N / 3), st);
+  return launch_reduce_dw(p.slab, out, splits, (int64_t)N * K, accumulate, p.bias_slab, splits * tiles_k, N, bias_out, nullptr, N, 0, st);
 }
 
 }  // namespace tad
