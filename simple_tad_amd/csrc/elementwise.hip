@@ -372,15 +372,17 @@ int launch_reduce_col_ranges(const float* partial, int N, int splits, int c0, fl
 }
 
 // The two reductions that follow a dW GEMM in ONE launch: the split-K slabs (as reduce_partials_kernel) and, in extra blocks at the
-// end of the grid, the bias column sums partial2[rows2][n2] -> out2a (columns [0, n2a)) and, if out2b, columns [c2b, c2b + n2a) ->
+// start of the grid, the bias column sums partial2[rows2][n2] -> out2a (columns [0, n2a)) and, if out2b, columns [c2b, c2b + n2a) ->
 // out2b (the qkv Linear: q_bias / v_bias ranges), else all n2 columns -> out2a.
 __global__ void reduce_dw_kernel(const float* __restrict__ partial, float* __restrict__ out, int splits, int64_t n, int accumulate,
                                  int slab_blocks, const float* __restrict__ partial2, int rows2, int n2, float* out2a, float* out2b, int n2a,
                                  int c2b) {
-  if ((int)blockIdx.x < slab_blocks) {
+  // the (few, latency-bound) bias blocks come FIRST in the grid so that they run beside the slab blocks, not after them
+  const int bias_blocks = (int)gridDim.x - slab_blocks;
+  if ((int)blockIdx.x >= bias_blocks) {
     const int64_t stride = (int64_t)slab_blocks * blockDim.x;
     const int64_t n4 = n >> 2;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    for (int64_t i = (int64_t)((int)blockIdx.x - bias_blocks) * blockDim.x + threadIdx.x; i < n4; i += stride) {
       float4 s = reinterpret_cast<const float4*>(partial)[i];
       for (int k = 1; k < splits; ++k) {
         const float4 v = reinterpret_cast<const float4*>(partial + (int64_t)k * n)[i];
@@ -395,7 +397,7 @@ __global__ void reduce_dw_kernel(const float* __restrict__ partial, float* __res
     return;
   }
   // bias job: one float4 column group per thread
-  const int c4 = ((int)blockIdx.x - slab_blocks) * blockDim.x + threadIdx.x;
+  const int c4 = (int)blockIdx.x * blockDim.x + threadIdx.x;
   const int groups = n2a >> 2;
   const int total = out2b ? 2 * groups : groups;
   if (c4 >= total) return;
@@ -403,7 +405,15 @@ __global__ void reduce_dw_kernel(const float* __restrict__ partial, float* __res
   const int col = second ? c2b + 4 * (c4 - groups) : 4 * c4;
   float* dst = (second ? out2b : out2a) + (second ? 4 * (c4 - groups) : 4 * c4);
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int r = 0; r < rows2; ++r) {
+  int r = 0;
+  for (; r + 8 <= rows2; r += 8) {  // 8 loads in flight (the rows are read in a fixed order: deterministic sums)
+    float4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4*>(partial2 + (int64_t)(r + k) * n2 + col);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s.x += v[k].x; s.y += v[k].y; s.z += v[k].z; s.w += v[k].w; }
+  }
+  for (; r < rows2; ++r) {
     const float4 v = *reinterpret_cast<const float4*>(partial2 + (int64_t)r * n2 + col);
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
   }
