@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
 
   int qrow = q0 + ql;
   const bool qvalid = qrow < N;
+  const bool wave_live = q0 < N;  // wave-uniform
   if (!qvalid) qrow = N - 1;
   bf16x8 qf[4], dof[4];
   {
@@ -145,6 +146,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
     if (t + 1 < nt) DMA_KV((t + 1) & 1, kv0 + 64);
     const char* kl = lds + (t & 1) * 2 * TILE_BYTES;
     const char* vl = kl + TILE_BYTES;
+    // a wave whose 32 query rows all lie past the sequence (the last block of N = 1568 has one live wave of four) only helps
+    // staging the tiles: its matrix / VALU slots go to the other waves on its SIMD
+    if (wave_live)
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
       f32x16 s, dp;
@@ -220,6 +224,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const uint16_t* __
 
   int krow = key0 + kl_;
   const bool kvalid = krow < N;
+  const bool wave_live = key0 < N;  // wave-uniform
   if (!kvalid) krow = N - 1;
   bf16x8 kfr[4], vfr[4];
 #pragma unroll
@@ -280,6 +285,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const uint16_t* __
     const char* ql = lds + (t & 1) * STAGE;
     const char* dl = ql + TILE_BYTES;
     const float* rowc = reinterpret_cast<const float*>(ql + 2 * TILE_BYTES);  // [0..63] -lse2/c, [64..127] -delta
+    if (wave_live)  // (see the dQ kernel: waves whose 32 keys all lie past the sequence only stage tiles)
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
       // initial accumulators: per-row constants; accumulator register r <-> row (r&3) + 8*(r>>2) + 4*h5

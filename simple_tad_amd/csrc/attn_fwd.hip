@@ -50,6 +50,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
   const int qblk = lin % nblk, pair = lin / nblk;
   const int head = pair % H, b = pair / H;
   const int q0 = qblk * Q_BLOCK + wave * Q_WAVE;
+  const bool wave_live = q0 < N;  // wave-uniform
   const int ql = lane & 31, h5 = lane >> 5;
   const int64_t tok_stride = (int64_t)3 * H * HD;  // elements per token
   const uint16_t* base = qkv + (int64_t)b * N * tok_stride + head * HD;
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
     if ((T) + 1 < nt) DMA_TILE((BUF) ^ 1, kv0 + KV_TILE);                                                                   \
     const char* kl = lds + (BUF) * 2 * TILE_BYTES;                                                                        \
     const char* vl = kl + TILE_BYTES;                                                                                     \
+    if (wave_live) { /* waves whose 32 query rows all lie past the sequence only help staging the tiles */               \
     f32x16 s[2];                                                                                                          \
     _Pragma("unroll") for (int kt = 0; kt < 2; ++kt) {                                                                    \
       _Pragma("unroll") for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;                                                      \
@@ -173,6 +175,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
       }                                                                                                                   \
     }                                                                                                                     \
     l_run += rs[0]; /* every row of rs holds the full column sum over the 64 keys: no cross-lane step */                  \
+    }                                                                                                                     \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                      \
     __syncthreads();                                                                                                      \
   }
