@@ -151,6 +151,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
     if (wave_live)
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
+      if (kv0 + 32 * kt >= N) continue;  // a half tile past the sequence (N = 1568: the second half of the last tile) contributes nothing
       f32x16 s, dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = -dlt; }
@@ -288,6 +289,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const uint16_t* __
     if (wave_live)  // (see the dQ kernel: waves whose 32 keys all lie past the sequence only stage tiles)
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
+      if (t * 64 + 32 * qt >= N) continue;  // half tile of query rows past the sequence: P = dS = 0 there anyway
       // initial accumulators: per-row constants; accumulator register r <-> row (r&3) + 8*(r>>2) + 4*h5
       f32x16 s, dp;
 #pragma unroll
