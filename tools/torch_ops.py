@@ -44,5 +44,14 @@ for ev in prof.events():
         continue
     frame = next((f for f in ev.stack if "simple_tad_amd/" in f or "bench" in f or "torch_ops" in f), ev.stack[0] if ev.stack else "?")
     agg[(ev.name, str(ev.input_shapes)[:60], frame.split("/root/repo/")[-1][:90] if "/root/repo/" in frame else frame[-90:])] += 1
+mem = collections.Counter()
+for ev in prof.events():
+    if ev.device_type.name == "CPU" and any("emcpy" in k.name or "emset" in k.name for k in ev.kernels):
+        frame = next((f for f in ev.stack if "simple_tad_amd/" in f or "bench" in f or "torch_ops" in f), ev.stack[0] if ev.stack else "?")
+        mem[(ev.name, str(ev.input_shapes)[:60], [k.name for k in ev.kernels][0][:30], frame[-80:])] += 1
+print("--- ops that issued a memcpy / memset")
+for k, n in sorted(mem.items(), key=lambda kv: -kv[1]):
+    print(f"{n:4d} x {k}")
+print("--- aten ops")
 for (name, shp, fr), n in sorted(agg.items(), key=lambda kv: -kv[1]):
     print(f"{n:4d} x {name:28s} {shp:60s} {fr}")
