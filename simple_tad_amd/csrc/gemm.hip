@@ -48,7 +48,8 @@ struct GemmNT {
   int c_bf16;
   int epi;
   int M, N, K;
-  int debug;  // ablation (TAD_GEMM_DEBUG, timing only, wrong results): 1 = no DMA inside the K loop, 2 = no MFMA, 4 = no epilogue
+  int debug;  // ablation (TAD_GEMM_DEBUG, timing only, wrong results): 1 = no DMA inside the K loop, 2 = no MFMA, 4 = no epilogue,
+              // 8 = (gemm_tn) no fragment reads and no MFMA: staging and barriers only, 16 = (gemm_tn) unswizzled DMA source
   int stagger_ticks;  // persistent kernel: span (10 ns ticks of s_memrealtime) over which the workgroups of an XCD spread their start
   int stagger_group;  // workgroups of an XCD start in groups of this many (power of two)
   int* sched;        // persistent kernel: 8 tile counters (one per XCD) of this launch, or null = fixed tile lists
@@ -686,7 +687,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(const Ge
   for (int i = 0; i < P_PIECES; ++i) {
     const int piece = i * NW + wave;
     const int row = piece * (64 / P_LPR) + lane / P_LPR;
-    const int chunk = (lane % P_LPR) ^ sw_tn(row);
+    const int chunk = (lane % P_LPR) ^ ((p.debug & 16) ? 0 : sw_tn(row));  // (debug 16: unswizzled source, timing experiments only)
     // columns beyond N only feed outputs that are never stored; clamp keeps the address inside the row
     int col = n0 + chunk * 8;
     if (col > p.N - 8) col = p.N - 8;
@@ -696,7 +697,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(const Ge
   for (int i = 0; i < Q_PIECES; ++i) {
     const int piece = i * NW + wave;
     const int row = piece * (64 / Q_LPR) + lane / Q_LPR;
-    const int chunk = (lane % Q_LPR) ^ sw_tn(row);
+    const int chunk = (lane % Q_LPR) ^ ((p.debug & 16) ? 0 : sw_tn(row));
     int col = k0 + chunk * 8;
     if (col > p.K - 8) col = p.K - 8;
     q_off[i] = (uint32_t)(mr0 + row) * (uint32_t)(p.K * 2) + (uint32_t)(col * 2);
@@ -743,7 +744,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(const Ge
     rd = (rd + 1 == STAGES) ? 0 : rd + 1;
     wr = (wr + 1 == STAGES) ? 0 : wr + 1;
 #define KSTEP_TN(ks)                                                                                        \
-  {                                                                                                         \
+  if (!(p.debug & 8)) {                                                                                     \
     bf16x8 pf[MREP], qf[NREP];                                                                              \
     _Pragma("unroll") for (int j = 0; j < NREP; ++j) qf[j] = tr_frag_tn(sq, QROW, (ks), wn * WTN + 16 * j, lane);  \
     _Pragma("unroll") for (int i = 0; i < MREP; ++i) pf[i] = tr_frag_tn(sp, PROW, (ks), wm * WTM + 16 * i, lane);  \
