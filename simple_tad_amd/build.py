@@ -42,7 +42,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(srcp), os.path.getmtime(os.path.join(CSRC, "common.h")),
                                                                           os.path.getmtime(os.path.join(os.path.dirname(HERE), "include", "tad_mi355x.h")))):
             return obj
-        cmd = [hipcc, *FLAGS, "-c", srcp, "-o", obj]
+        cmd = [hipcc, *FLAGS, *(["-DTAD_GEMM_ABLATION"] if os.environ.get("TAD_BUILD_ABLATION") == "1" else []), "-c", srcp, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

@@ -28,6 +28,14 @@ int launch_reduce_dw(const float* partial, float* out, int splits, int64_t n, in
 
 // EPI_RESMOD = EPI_RESIDUAL with the residual row taken modulo res_mod ("+ pos_embed" of the patch embedding): a variant of its
 // own so that the integer division stays out of the Linear kernels
+// Ablation switches (TAD_GEMM_DEBUG, see GemmNT::debug) cost scalar branches inside the K loops: compiled in only with
+// -DTAD_GEMM_ABLATION (python -m simple_tad_amd.build reads TAD_BUILD_ABLATION=1); production builds see a constant 0.
+#ifdef TAD_GEMM_ABLATION
+#define DBG_BITS(p) ((p).debug)
+#else
+#define DBG_BITS(p) 0
+#endif
+
 enum { EPI_PLAIN = 0, EPI_GELU = 1, EPI_RESIDUAL = 2, EPI_DGELU = 3, EPI_RESMOD = 4 };
 
 struct GemmNT {
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
   _Pragma("unroll") for (int j = 0; j < NREP; ++j)  \
       dst[j] = *reinterpret_cast<const bf16x8*>((base) + b_rd[j] + ((((KSTEPS > 1 ? 4 * (ks) : 0) + kq) ^ b_sw[j]) << 4))
 #define MFMA_BLOCK(afr, bfr_)                                                                            \
-  if (!(p.debug & 2)) {                                                                                  \
+  if (!(DBG_BITS(p) & 2)) {                                                                                  \
     _Pragma("unroll") for (int i = 0; i < MREP; ++i)                                                     \
         _Pragma("unroll") for (int j = 0; j < NREP; ++j)                                                 \
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr_[j], afr[i], acc[i][j], 0, 0, 0);    \
@@ -401,7 +409,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
       // Issuing a tile's LDS-DMA pieces blocks the issuing wave for ~100 cycles per piece.  The two waves that share a SIMD
       // (wave w and w + NW/2) therefore issue them at different times: the older half before its first k-step, the younger
       // half between its two k-steps, so the SIMD's matrix pipe always has one wave feeding it.
-      const bool dma = more && !(p.debug & 1);
+      const bool dma = more && !(DBG_BITS(p) & 1);
       bf16x8 af[MREP], bfr[NREP];
       if (dma && (!late || KSTEPS == 1)) { STAGE_NT(wr_now, kt_next); }
       FRAG_B(bfr, sb, 0);
@@ -444,7 +452,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
         if (st < nk) { STAGE_NT(st, st); }
     }
   }
-  if (DIRECT && !((p.debug & 4) && p.M > 1)) {
+  if (DIRECT && !((DBG_BITS(p) & 4) && p.M > 1)) {
     float gam[CPL];
 #pragma unroll
     for (int i = 0; i < MREP; ++i) {
@@ -511,7 +519,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
       }
     }
   }
-  if (!DIRECT && !((p.debug & 4) && p.M > 1)) {
+  if (!DIRECT && !((DBG_BITS(p) & 4) && p.M > 1)) {
   float gam[CPL];
 #pragma unroll
   for (int e = 0; e < CPL; ++e) gam[e] = (IS_RES && p.gamma && nvalid && (e < 4 || full)) ? p.gamma[n + e] : 1.f;
@@ -687,7 +695,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(const Ge
   for (int i = 0; i < P_PIECES; ++i) {
     const int piece = i * NW + wave;
     const int row = piece * (64 / P_LPR) + lane / P_LPR;
-    const int chunk = (lane % P_LPR) ^ ((p.debug & 16) ? 0 : sw_tn(row));  // (debug 16: unswizzled source, timing experiments only)
+    const int chunk = (lane % P_LPR) ^ ((DBG_BITS(p) & 16) ? 0 : sw_tn(row));  // (debug 16: unswizzled source, timing experiments only)
     // columns beyond N only feed outputs that are never stored; clamp keeps the address inside the row
     int col = n0 + chunk * 8;
     if (col > p.N - 8) col = p.N - 8;
@@ -697,7 +705,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(const Ge
   for (int i = 0; i < Q_PIECES; ++i) {
     const int piece = i * NW + wave;
     const int row = piece * (64 / Q_LPR) + lane / Q_LPR;
-    const int chunk = (lane % Q_LPR) ^ ((p.debug & 16) ? 0 : sw_tn(row));
+    const int chunk = (lane % Q_LPR) ^ ((DBG_BITS(p) & 16) ? 0 : sw_tn(row));
     int col = k0 + chunk * 8;
     if (col > p.K - 8) col = p.K - 8;
     q_off[i] = (uint32_t)(mr0 + row) * (uint32_t)(p.K * 2) + (uint32_t)(col * 2);
@@ -744,11 +752,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(const Ge
     rd = (rd + 1 == STAGES) ? 0 : rd + 1;
     wr = (wr + 1 == STAGES) ? 0 : wr + 1;
 #define KSTEP_TN(ks)                                                                                        \
-  if (!(p.debug & 8)) {                                                                                     \
+  if (!(DBG_BITS(p) & 8)) {                                                                                     \
     bf16x8 pf[MREP], qf[NREP];                                                                              \
     _Pragma("unroll") for (int j = 0; j < NREP; ++j) qf[j] = tr_frag_tn(sq, QROW, (ks), wn * WTN + 16 * j, lane);  \
     _Pragma("unroll") for (int i = 0; i < MREP; ++i) pf[i] = tr_frag_tn(sp, PROW, (ks), wm * WTM + 16 * i, lane);  \
-    if (!(p.debug & 2)) {                                                                                   \
+    if (!(DBG_BITS(p) & 2)) {                                                                                   \
       _Pragma("unroll") for (int i = 0; i < MREP; ++i)                                                      \
           _Pragma("unroll") for (int j = 0; j < NREP; ++j)                                                  \
               acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], pf[i], acc[i][j], 0, 0, 0);        \
@@ -763,7 +771,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(const Ge
     }                                                                                                       \
   }
     const bool late = wave >= NW / 2;  // stagger the DMA issue of the two waves that share a SIMD (see gemm_nt_kernel)
-    const bool dma = more && !(p.debug & 1);
+    const bool dma = more && !(DBG_BITS(p) & 1);
     if (KSTEPS == 2) {
       if (dma && !late) { STAGE_TN(wr_now, t_next); }
       KSTEP_TN(0);
