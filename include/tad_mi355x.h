@@ -144,7 +144,8 @@ int tad_linear_tuning(const char* key, int value);
 long long tad_linear_kernel_launches(void);
 /* Debug timeline of the Linear GEMM kernels: while buf (device memory, >= gridDim * 64 * 32 * 8 bytes, caller-owned) is set,
  * every workgroup records s_memrealtime (100 MHz) for each of its first 64 tiles: slot 0 tile start, 1 K-loop end, 2 epilogue
- * issued, 3 stores acknowledged, 4 + 2q / 5 + 2q epilogue chunk q transposed / stored.  NULL switches it off (default).  Costs a store drain per tile: never leave it on. */
+ * issued, 3 stores acknowledged, 4 + 2q / 5 + 2q epilogue chunk q transposed / stored.  NULL switches it off (default).  Costs a store drain per tile: never leave it on.  Only libraries built with
+ * -DTAD_GEMM_ABLATION (TAD_BUILD_ABLATION=1) carry the stamps; others return TAD_EINVAL for a non-NULL buffer. */
 int tad_linear_debug_stamps(void* buf);
 /* Weight gradient: dW [N,K] f32 = dy^T [N,M] @ x [M,K]; db [N] f32 = column sums of dy (nullable).
  * Outputs are overwritten (accumulate==0) or added to (accumulate!=0). */

@@ -276,10 +276,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
   DECODE_TILE(t_cur);
   TILE_OFFSETS();
   if (0 < nk) { STAGE_NT(0, 0); }
+#ifdef TAD_GEMM_ABLATION
   int stamp_i = 0;
+#endif
   bool first_tile = true;
+#ifdef TAD_GEMM_ABLATION
 #define STAMP(k) \
   if (p.stamps && tid == 0 && stamp_i < 64) p.stamps[((size_t)blockIdx.x * 64 + stamp_i) * 32 + (k)] = __builtin_amdgcn_s_memrealtime()
+#else
+#define STAMP(k) (void)0  // timeline stamps (tad_linear_debug_stamps) exist in ablation builds only
+#endif
   for (;;) {
   STAMP(0);
   const int em0 = m0, en0 = n0;  // this tile; (m0, n0) move on to the next one when its first K-tile is prefetched
@@ -613,11 +619,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
   }
   }  // epilogue
   STAMP(2);
+#ifdef TAD_GEMM_ABLATION
   if (p.stamps) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(3);
   }
   ++stamp_i;
+#endif
   if (!has_next) break;
   if (!DIRECT) lds_barrier();  // epilogue reads of the LDS are done before the next tile's DMAs overwrite it
   }  // tile loop
@@ -1143,6 +1151,9 @@ int tad_linear_tuning(const char* key, int value) {
 long long tad_linear_kernel_launches(void) { return g_nt_launches; }
 
 int tad_linear_debug_stamps(void* buf) {
+#ifndef TAD_GEMM_ABLATION
+  if (buf) { set_error("linear_debug_stamps: timeline stamps need an ablation build (TAD_BUILD_ABLATION=1 python -m simple_tad_amd.build --force)"); return TAD_EINVAL; }
+#endif
   g_nt_stamps = (unsigned long long*)buf;
   return TAD_OK;
 }

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""In-kernel timeline of one gemm_nt launch (tad_linear_debug_stamps): per tile K-loop / epilogue / store-drain durations and
+"""In-kernel timeline of one gemm_nt launch (tad_linear_debug_stamps; needs an ablation build:
+TAD_BUILD_ABLATION=1 python -m simple_tad_amd.build --force): per tile K-loop / epilogue / store-drain durations and
 the spread of the workgroups' phases.   python tools/exp_timeline.py [--shape fc1] [--config 1,100,1]"""
 import argparse, os, sys, torch, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -30,7 +31,7 @@ for cfg in a.configs.split(";"):
         fn()
     nwg = 4096
     buf = torch.zeros(nwg * 64 * 32, dtype=torch.int64, device=dev)
-    lib.tad_linear_debug_stamps(buf.data_ptr())
+    assert lib.tad_linear_debug_stamps(buf.data_ptr()) == 0, lib.tad_last_error_string()
     fn()
     torch.cuda.synchronize()
     lib.tad_linear_debug_stamps(None)
