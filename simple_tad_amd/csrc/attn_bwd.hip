@@ -16,6 +16,7 @@
 //
 // Tiles that are read both by rows (ds_read_b128) and transposed (ds_read_b64_tr_b16) use one LDS image with a
 // swizzle that is conflict-free for both (found by tools/lds_bank_sim.py).
+#include <type_traits>
 #include "common.h"
 
 namespace tad {
@@ -141,10 +142,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
   DMA_KV(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  for (int t = 0; t < nt; ++t) {
+  // the tile loop runs in pairs so that the LDS buffer index is a literal in each copy of the body: every LDS address is then a
+  // lane constant + immediate instead of a handful of v_add / v_or per fragment read
+  auto dq_tile = [&](auto BUFC, int t) {
+    constexpr int BUF = decltype(BUFC)::value;
     const int kv0 = t * 64;
-    if (t + 1 < nt) DMA_KV((t + 1) & 1, kv0 + 64);
-    const char* kl = lds + (t & 1) * 2 * TILE_BYTES;
+    if (t + 1 < nt) DMA_KV(BUF ^ 1, kv0 + 64);
+    const char* kl = lds + BUF * 2 * TILE_BYTES;
     const char* vl = kl + TILE_BYTES;
     // a wave whose 32 query rows all lie past the sequence (the last block of N = 1568 has one live wave of four) only helps
     // staging the tiles: its matrix / VALU slots go to the other waves on its SIMD
@@ -182,6 +186,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+  };
+  for (int t = 0; t < nt; t += 2) {
+    dq_tile(std::integral_constant<int, 0>{}, t);
+    if (t + 1 < nt) dq_tile(std::integral_constant<int, 1>{}, t + 1);
   }
 
   if (qvalid) {
