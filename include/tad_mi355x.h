@@ -177,6 +177,10 @@ int tad_meanpool_bwd(const float* dy, float* dx, uint16_t* dx_bf16, int B, int N
 /* ---- small helpers used by the training step ------------------------------------------
  * column sums of a bf16 [M,N] matrix into f32 [N] (bias gradients: q_bias/v_bias/fc1.bias). */
 size_t tad_colsum_workspace_bytes(int64_t M, int N);
+/* Column sums over a row window of an f32 [B, R, N] tensor: out[n] (+)= sum_b sum_{r0 <= r < r0 + rc} a[b, r, n] (workspace:
+ * tad_colsum_workspace_bytes(B * rc, N)).  The mask-token gradient of the MAE decoder input. */
+int tad_colsum_window_f32(const float* a, float* out, int accumulate, void* ws, size_t ws_bytes, int B, int R, int N,
+                          int r0, int rc, tad_stream_t stream);
 int tad_colsum_bf16(const uint16_t* a, float* out, int accumulate, void* ws, size_t ws_bytes, int64_t M,
                     int N, tad_stream_t stream);
 /* y_bf16 = bf16(rowscale[m/rows_per_scale] * gamma[n] * x_f32)  (backward of the residual-branch scale) */

@@ -43,6 +43,7 @@ SIGNATURES = {
     "tad_meanpool_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "tad_colsum_workspace_bytes": (_sz, [_i64, _i]),
     "tad_colsum_bf16": (_i, [_vp, _vp, _i, _vp, _sz, _i64, _i, _vp]),
+    "tad_colsum_window_f32": (_i, [_vp, _vp, _i, _vp, _sz, _i, _i, _i, _i, _i, _vp]),
     "tad_scale_cast_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp]),
     "tad_sumsq_f32": (_i, [_vp, _i64, _vp, _vp]),
     "tad_transpose_bf16_batched": (_i, [_vp, _vp, _vp, _i, _vp]),

@@ -251,6 +251,33 @@ __global__ void colsum_partial_kernel(const uint16_t* __restrict__ a, float* __r
       partial[(int64_t)blockIdx.y * N + c0 + j] = red[0][lane][j] + red[1][lane][j] + red[2][lane][j] + red[3][lane][j];
   }
 }
+// f32 variant over a row window of a [B, R, N] tensor: sums rows r in [r0, r0 + rc) of every batch entry (the mask-token gradient of the
+// MAE decoder input: the masked positions of every clip, modeling_pretrain.py:283-287) -- no contiguous copy of the window needed.
+// 256 threads = 64 lanes (4 columns each = 256 columns) x 4 waves over rows; blockIdx.y = row split over the B * rc window rows.
+__global__ void colsum_window_f32_kernel(const float* __restrict__ a, float* __restrict__ partial, int B, int R, int N, int r0, int rc,
+                                         int rows_per) {
+  __shared__ float4 red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = (blockIdx.x * 64 + lane) * 4;
+  const int64_t total = (int64_t)B * rc;
+  const int64_t m0 = (int64_t)blockIdx.y * rows_per, m1 = min(total, m0 + rows_per);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c0 < N) {
+    for (int64_t m = m0 + wave; m < m1; m += 4) {
+      const int64_t b = m / rc, r = m - b * rc;
+      const float4 v = *reinterpret_cast<const float4*>(a + ((b * R + r0 + r) * (int64_t)N + c0));
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && c0 < N) {
+    float4 t = red[0][lane];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) { t.x += red[w][lane].x; t.y += red[w][lane].y; t.z += red[w][lane].z; t.w += red[w][lane].w; }
+    *reinterpret_cast<float4*>(partial + (int64_t)blockIdx.y * N + c0) = t;
+  }
+}
 // stage 2 (also used for LayerNorm dgamma/dbeta and split-K slabs): out[j] (+)= sum_s partial[s][j]
 __global__ void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, int splits,
                                        int64_t n, int accumulate) {
@@ -526,6 +553,21 @@ int tad_colsum_bf16(const uint16_t* a, float* out, int accumulate, void* ws, siz
   if (ws_bytes < (size_t)splits * N * sizeof(float)) { set_error("colsum: workspace too small"); return TAD_ENOSPACE; }
   const int rows_per = (int)((M + splits - 1) / splits);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 511) / 512, splits), dim3(256), 0, (hipStream_t)stream, a, (float*)ws, M, N, rows_per);
+  return launch_reduce_partials((const float*)ws, out, splits, N, accumulate, (hipStream_t)stream);
+}
+
+int tad_colsum_window_f32(const float* a, float* out, int accumulate, void* ws, size_t ws_bytes, int B, int R, int N, int r0, int rc,
+                          tad_stream_t stream) {
+  TAD_REQUIRE(a && out && ws && B > 0 && R > 0 && N > 0 && N % 4 == 0, "colsum_window: bad args (N must be a multiple of 4)");
+  TAD_REQUIRE(r0 >= 0 && rc > 0 && r0 + rc <= R, "colsum_window: rows [%d, %d) outside [0, %d)", r0, r0 + rc, R);
+  const int64_t total = (int64_t)B * rc;
+  const int splits = colsum_splits(total);
+  if (ws_bytes < (size_t)splits * N * sizeof(float)) { set_error("colsum_window: workspace too small"); return TAD_ENOSPACE; }
+  const int rows_per = (int)((total + splits - 1) / splits);
+  hipLaunchKernelGGL(colsum_window_f32_kernel, dim3((N + 255) / 256, splits), dim3(256), 0, (hipStream_t)stream, a, (float*)ws, B, R, N, r0,
+                     rc, rows_per);
+  int rc_ = check_launch("colsum_window");
+  if (rc_) return rc_;
   return launch_reduce_partials((const float*)ws, out, splits, N, accumulate, (hipStream_t)stream);
 }
 

@@ -646,6 +646,18 @@ def gelu_bwd_f32(dy, h):
     return dh
 
 
+def colsum_window_f32(a, r0, rc):
+    """a [B, R, N] f32 -> [N]: sum over the batch and rows r0 .. r0+rc-1 (no copy of the window)"""
+    _req(a, torch.float32, "colsum_window.a")
+    B, R, N = a.shape
+    out = torch.empty(N, dtype=torch.float32, device=a.device)
+    lib = _lib.load()
+    ws = workspace(lib.tad_colsum_workspace_bytes(B * rc, N), a.device)
+    check(lib.tad_colsum_window_f32(a.data_ptr(), out.data_ptr(), 0, ws.data_ptr(), ws.numel(), B, R, N, int(r0), int(rc), _stream()),
+          "tad_colsum_window_f32")
+    return out
+
+
 def colsum_f32(a):
     _req(a, torch.float32, "colsum_f32.a")
     M, N = a.shape

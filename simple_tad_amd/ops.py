@@ -563,7 +563,7 @@ class MaeAssembleFn(torch.autograd.Function):
         B, Nv, Nm, D = ctx.meta
         g = _f32c(g)
         d_xv = g[:, :Nv].contiguous()
-        d_tok = K.colsum_f32(g[:, Nv:].reshape(B * Nm, D).contiguous()).reshape(1, 1, D)
+        d_tok = K.colsum_window_f32(g, Nv, Nm).reshape(1, 1, D)  # (the f64 verification kernel on a contiguous copy took 2.3 ms here)
         return d_xv, d_tok, None, None, None
 
 
