@@ -10,9 +10,13 @@
 // ds_read_b64_tr_b16 below is bank-conflict free (tools/lds_bank_sim.py).
 //
 // gemm_nt computes C^T tiles (W rows feed the MFMA "A" operand) with a permuted assignment of W rows to fragment
-// lanes, so that each lane ends up holding 4*NREP *consecutive* output columns of one output row: the epilogue
-// (bias / GELU / residual / layer-scale / drop-path scale / GELU-backward) runs on registers and stores 16-byte
-// vectors straight to HBM without an LDS round trip.
+// lanes, so that each lane ends up holding 4 (f32) or 8 (bf16) *consecutive* output columns of one output row.  Above
+// 1.5 tiles per CU it runs persistently (one workgroup per CU walks a tile list and fetches the next tile's first
+// K-tile under the current epilogue); the launcher picks the tile shape -- or whole rounds of 256 x 256 tiles plus a
+// second launch for the remaining rows -- from a small cost model.  Epilogue (bias / GELU / residual / layer-scale /
+// drop-path scale / GELU-backward): accumulators transposed through the LDS so that global accesses cover whole rows,
+// raw buffer loads / stores without per-lane branches, what it reads fetched one chunk ahead; bias-only bf16 outputs are
+// stored straight from the MFMA layout instead.  DESIGN.md section 3.1 has the measurements behind each choice.
 #include <math.h>
 #include <stdlib.h>
 #include <string>
