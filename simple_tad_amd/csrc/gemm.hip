@@ -153,12 +153,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
   //
   // PERSIST: the grid is one workgroup per CU (a multiple of 8).  Workgroup (xcd = blockIdx & 7, j = blockIdx >> 3) walks the
   // ids first + j, first + j + step, ... of its XCD's range, so at any time the XCD works on ~step consecutive ids as above.
-  // Two things are gained over one launch-scheduled workgroup per tile:
-  //  (1) the epilogue is HBM-bound when every CU reaches it at the same time (all K loops have the same length, so a plain
-  //      grid stays in lock-step: 64 MB of stores per round of fc1 tiles at ~5 TB/s while the matrix pipes idle, then a K loop
-  //      during which HBM idles).  The workgroups therefore start `stagger` apart and keep that phase difference, which spreads
-  //      the store bursts over the K loops of the other CUs.  Later starters are the ones with fewer tiles in their list.
-  //  (2) the first K-tile of the next tile is fetched under the epilogue.
+  // What is gained over one launch-scheduled workgroup per tile: the first K-tile of the next tile (with the register-layout
+  // epilogue: its whole prologue) is fetched under the epilogue, and no workgroup launch sits between two tiles.
+  // Optional staggered starts (stagger_ticks > 0: workgroup j of an XCD waits j / step of a K-loop time before its first tile, so the
+  // store bursts of the epilogues spread over the K loops of the other CUs) were measured NOT to shorten the epilogues -- their own
+  // LDS / VALU time, not HBM contention, is what is left -- and default to off (profiles/README.md).
   constexpr int GROUP_M = 8;
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
