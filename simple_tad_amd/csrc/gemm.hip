@@ -433,11 +433,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
     }
   }
 
-  // ---- epilogue through LDS.  Straight from the MFMA layout a global access would touch 16 rows x 64 bytes per instruction;
-  // the accumulators are transposed through the (now idle) LDS in chunks of CROWS rows so that every global load / store of
-  // a wave covers whole contiguous rows (512 B - 1 KiB runs).  The epilogue is VALU-bound (128 outputs per lane), so the
-  // variant (EPI, OUT_BF16) is a template parameter, offsets are 32-bit, and loads are issued BATCH rows ahead because the CU
-  // has only NW waves to cover HBM latency.
+  // ---- epilogue.  Straight from the MFMA layout a global access touches 16 rows x 64 bytes per instruction (24.6 B/clk per CU
+  // against 70 for whole rows: tools/micro/store_rate.hip), so except for the bias-only bf16 case (DIRECT) the accumulators are
+  // transposed through the LDS in chunks of CROWS rows and every global load / store of a wave covers whole contiguous rows
+  // (512 B - 1 KiB runs).  The variant (EPI, OUT_BF16) is a template parameter, offsets are 32-bit buffer offsets, the rows read
+  // besides the accumulators come one chunk ahead (ISSUE_EXTRA), and the LDS reads of a chunk are batched BATCH rows at a time.
   if (PERSIST && DYN) {
     if (tid == 0) {
       next_idx_lds[0] = fetched;  // (the compiler waits for the atomic issued one tile ago -- or at kernel start -- here)
