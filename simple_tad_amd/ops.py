@@ -11,6 +11,7 @@ The residual stream stays f32 (as under torch autocast); GEMM / attention operan
 """
 from __future__ import annotations
 
+import threading
 import weakref
 from typing import Optional
 
@@ -240,8 +241,31 @@ def precise_patch_embed(x, weight, bias, pos, tubelet, patch):
 
 
 
+
+# --------------------------------------------------------------------------- grad mode seen by the CALLER of a Function
+# Inside Function.forward autograd has switched grad mode off and ctx.needs_input_grad is True for every Parameter even under
+# torch.no_grad(), so "will this forward be differentiated?" (decides whether cached bf16 weight copies may be reused, whether
+# pre-activations / statistics are kept) has to be sampled before apply().
+_outer = threading.local()
+
+
+class _Fn(torch.autograd.Function):
+    @classmethod
+    def apply(cls, *args, **kwargs):
+        prev = getattr(_outer, "grad", None)
+        _outer.grad = torch.is_grad_enabled()
+        try:
+            return super().apply(*args, **kwargs)
+        finally:
+            _outer.grad = prev
+
+
+def _differentiated(ctx) -> bool:
+    g = getattr(_outer, "grad", None)
+    return (True if g is None else g) and any(ctx.needs_input_grad)
+
 # --------------------------------------------------------------------------- LayerNorm
-class LayerNormFn(torch.autograd.Function):
+class LayerNormFn(_Fn):
     """nn.LayerNorm(D, eps) on f32 rows -> f32 (modeling_finetune.py:143,149,270)."""
 
     @staticmethod
@@ -262,14 +286,14 @@ class LayerNormFn(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------- PatchEmbed (+ pos_embed)
-class PatchEmbedFn(torch.autograd.Function):
+class PatchEmbedFn(_Fn):
     """Conv3d(k=s=(tub,p,p)) + flatten/transpose (+ sinusoid pos_embed) (modeling_finetune.py:181-190, 312-313)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, pos, tubelet, patch):
         _need_gpu(x, "PatchEmbed")
         xc = _f32c(x)
-        out, cols = K.patch_embed_fwd(xc, w_bf16(weight, any(ctx.needs_input_grad)), _f32c(bias), _f32c(pos), tubelet, patch)
+        out, cols = K.patch_embed_fwd(xc, w_bf16(weight, _differentiated(ctx)), _f32c(bias), _f32c(pos), tubelet, patch)
         ctx.save_for_backward(cols)
         ctx.params = (weight, bias)
         return out
@@ -284,7 +308,7 @@ class PatchEmbedFn(torch.autograd.Function):
         return None, (None if dW is None else dW.reshape(weight.shape)), db, None, None, None
 
 
-class PatchEmbedU8Fn(torch.autograd.Function):
+class PatchEmbedU8Fn(_Fn):
     """PatchEmbed on uint8 frames [B,T,H,W,3]: normalisation (run_inference.py:15-34; dota.py:443-460) fused into the im2col."""
 
     @staticmethod
@@ -294,7 +318,7 @@ class PatchEmbedU8Fn(torch.autograd.Function):
         B, T, H, W, _ = fr.shape
         cols = K.im2col_tubelets_u8(fr, tubelet, patch, mean, std, bgr, t_offset)
         ntok = (T // tubelet) * (H // patch) * (W // patch)
-        out = K.patch_embed_gemm(cols, w_bf16(weight, any(ctx.needs_input_grad)), _f32c(bias), _f32c(pos), ntok)
+        out = K.patch_embed_gemm(cols, w_bf16(weight, _differentiated(ctx)), _f32c(bias), _f32c(pos), ntok)
         ctx.save_for_backward(cols)
         ctx.params = (weight, bias)
         return out
@@ -338,14 +362,14 @@ def _attn_bwd_core(d_ao, xn, qkv, ao, lse, qkv_w, has_qkv_bias, B, N, H, scale, 
     return dxn, dWqkv, None, None
 
 
-class AttentionFn(torch.autograd.Function):
+class AttentionFn(_Fn):
     """Attention.forward (modeling_finetune.py:86-134): qkv Linear, scaled-dot-product space-time attention, proj."""
 
     @staticmethod
     def forward(ctx, x, qkv_w, q_bias, v_bias, proj_w, proj_b, H, scale):
         _need_gpu(x, "Attention")
         B, N, C = x.shape
-        train = any(ctx.needs_input_grad)
+        train = _differentiated(ctx)
         xb = K.cast_bf16(_f32c(x).reshape(B * N, C))
         qkv, ao, lse = _attn_fwd_core(xb, qkv_w, q_bias, v_bias, B, N, H, scale, train)
         y, _ = K.linear_fwd(ao, w_bf16(proj_w, train), _f32c(proj_b), out_dtype=torch.float32)
@@ -367,14 +391,14 @@ class AttentionFn(torch.autograd.Function):
         return dx.reshape(B, N, -1), dWqkv, dqb, dvb, dWp, dbp, None, None
 
 
-class MlpFn(torch.autograd.Function):
+class MlpFn(_Fn):
     """Mlp.forward (modeling_finetune.py:47-54): fc2(GELU_erf(fc1(x)))."""
 
     @staticmethod
     def forward(ctx, x, fc1_w, fc1_b, fc2_w, fc2_b):
         _need_gpu(x, "Mlp")
         shp = x.shape
-        train = any(ctx.needs_input_grad)
+        train = _differentiated(ctx)
         xb = K.cast_bf16(_f32c(x).reshape(-1, shp[-1]))
         a, h = K.linear_fwd(xb, w_bf16(fc1_w, train), _f32c(fc1_b), out_dtype=torch.bfloat16, epilogue=EPI_BIAS_GELU, want_preact=train)
         y, _ = K.linear_fwd(a, w_bf16(fc2_w, train), _f32c(fc2_b), out_dtype=torch.float32)
@@ -430,7 +454,7 @@ def set_block_chain(enabled: bool):
     _chain.reset()
 
 
-class BlockFn(torch.autograd.Function):
+class BlockFn(_Fn):
     """Block.forward without layer-scale (modeling_finetune.py:159-163):
          x = x + dp1 * attn(norm1(x));  x = x + dp2 * mlp(norm2(x))
     dp1/dp2 are optional per-sample drop-path scales [B] (mask / keep_prob) or None."""
@@ -441,7 +465,7 @@ class BlockFn(torch.autograd.Function):
         _need_gpu(x, "Block")
         B, N, D = x.shape
         M = B * N
-        train = any(ctx.needs_input_grad)
+        train = _differentiated(ctx)
         x0 = _f32c(x).reshape(M, D)
         g1, b1, g2, b2 = _f32c(n1w), _f32c(n1b), _f32c(n2w), _f32c(n2b)
         xn1, mean1, rstd1 = K.layernorm_fwd(x0, g1, b1, eps, save_stats=train)
@@ -503,14 +527,14 @@ class BlockFn(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------- plain Linear (f32 rows in / out)
-class LinearFn(torch.autograd.Function):
+class LinearFn(_Fn):
     """nn.Linear on f32 rows through the bf16 MFMA GEMM (encoder_to_decoder and the decoder head, modeling_pretrain.py:163,269)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
         _need_gpu(x, "Linear")
         shp = x.shape
-        train = any(ctx.needs_input_grad)
+        train = _differentiated(ctx)
         xb = K.cast_bf16(_f32c(x).reshape(-1, shp[-1]))
         y, _ = K.linear_fwd(xb, w_bf16(weight, train), _f32c(bias), out_dtype=torch.float32)
         if train:
@@ -530,7 +554,7 @@ class LinearFn(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------- MAE pre-training path
-class GatherRowsFn(torch.autograd.Function):
+class GatherRowsFn(_Fn):
     """x[~mask].reshape(B, -1, C) (modeling_pretrain.py:98) with precomputed row indices (b*N + visible token)."""
 
     @staticmethod
@@ -548,7 +572,7 @@ class GatherRowsFn(torch.autograd.Function):
         return K.scatter_rows(_f32c(g).reshape(-1, D), idx, Bx * N).reshape(Bx, N, D), None, None
 
 
-class MaeAssembleFn(torch.autograd.Function):
+class MaeAssembleFn(_Fn):
     """cat([x_vis + pos[vis], mask_token + pos[masked]], dim=1) (modeling_pretrain.py:283-287); the positional table is a constant"""
 
     @staticmethod
@@ -567,7 +591,7 @@ class MaeAssembleFn(torch.autograd.Function):
         return d_xv, d_tok, None, None, None
 
 
-class MseLossFn(torch.autograd.Function):
+class MseLossFn(_Fn):
     """nn.MSELoss()(outputs, labels) (engine_for_pretraining.py:27,70): loss and d(loss)/d(outputs) in one pass"""
 
     @staticmethod
@@ -585,7 +609,7 @@ class MseLossFn(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------- mean-pool
-class MeanPoolFn(torch.autograd.Function):
+class MeanPoolFn(_Fn):
     """x.mean(1) over tokens (modeling_finetune.py:325-326)."""
 
     @staticmethod
@@ -601,7 +625,7 @@ class MeanPoolFn(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------- precise mode: autograd
-class PreciseBlockFn(torch.autograd.Function):
+class PreciseBlockFn(_Fn):
     """Block forward/backward in the precise mode (f32 activations, split-bf16 Linears, f32 attention): the gradient side of the
     parity gate.  Same data flow as BlockFn; no drop-path (verification runs use drop_path_rate = 0)."""
 
@@ -610,7 +634,7 @@ class PreciseBlockFn(torch.autograd.Function):
         _need_gpu(x, "Block")
         B, N, D = x.shape
         M = B * N
-        fr = any(ctx.needs_input_grad)  # differentiated forward: never reuse cached weight copies (see _cached)
+        fr = _differentiated(ctx)  # differentiated forward: never reuse cached weight copies (see _cached)
         x0 = _f32c(x).reshape(M, D)
         g1, b1, g2, b2 = _f32c(n1w), _f32c(n1b), _f32c(n2w), _f32c(n2b)
         xn1, mean1, rstd1 = K.layernorm_fwd(x0, g1, b1, eps, out_dtype=torch.float32)
@@ -648,7 +672,7 @@ class PreciseBlockFn(torch.autograd.Function):
         return (gin.reshape(B, N, D), dg1, dbeta1, dWqkv, dqb, dvb, dWp, dbp, dg2, dbeta2, dW1, db1, dW2, db2, None, None, None)
 
 
-class PrecisePatchEmbedFn(torch.autograd.Function):
+class PrecisePatchEmbedFn(_Fn):
     @staticmethod
     def forward(ctx, x, weight, bias, pos, tubelet, patch):
         _need_gpu(x, "PatchEmbed")
@@ -656,7 +680,7 @@ class PrecisePatchEmbedFn(torch.autograd.Function):
         cols = K.im2col_tubelets_f32(_f32c(x), tubelet, patch)
         ntok = cols.shape[0] // B
         res = _f32c(pos).repeat(B, 1) if pos is not None else None
-        y, _ = K.linear_fwd(K.split_bf16x3(cols, role_b=False), _cached_split(weight, any(ctx.needs_input_grad)), _f32c(bias),
+        y, _ = K.linear_fwd(K.split_bf16x3(cols, role_b=False), _cached_split(weight, _differentiated(ctx)), _f32c(bias),
                             out_dtype=torch.float32, epilogue=EPI_BIAS_RESIDUAL if res is not None else EPI_BIAS, residual=res)
         ctx.save_for_backward(cols)
         ctx.wshape = weight.shape
