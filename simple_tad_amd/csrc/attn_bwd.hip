@@ -46,6 +46,19 @@ __device__ __forceinline__ bf16x8 tr_frag_dual(const char* tile, int rbase, int 
   const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8, v);
 }
+// The same fragment through the inline-asm reads of common.h (the builtin form above makes the compiler drain the LDS-DMA of the
+// next tile in front of it): tr_dual_addr gives the lane's two LDS addresses for rbase = 0 inside a tile at byte address `tile`
+// (the second read's swizzle differs from the first's, so it has its own base); rbase (a multiple of 16 rows: the swizzle only
+// looks at row bits 1..3) and the tile's position go into the instruction's immediate.
+__device__ __forceinline__ void tr_dual_addr(uint32_t tile, int col0, int lane, uint32_t (&a)[2]) {
+  const int G = lane >> 4, li = lane & 15;
+  const int col = col0 + 16 * (G & 1) + 4 * (li & 3);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row = 4 * (G >> 1) + (li >> 2) + 8 * h;
+    a[h] = tile + (uint32_t)(row * 128 + (((col >> 3) ^ sw_dual(row)) << 4) + (col & 7) * 2);
+  }
+}
 // row fragment: lane (row = lane&31, h = lane>>5) gets tile[row0 + row][16ks + 8h .. +7]
 __device__ __forceinline__ bf16x8 row_frag_dual(const char* tile, int row, int ks, int h5) {
   return *reinterpret_cast<const bf16x8*>(tile + row * 128 + (((2 * ks + h5) ^ sw_dual(row)) << 4));
@@ -108,7 +121,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
     }
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(part), __float_as_uint(part), false, false);
     dlt = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    if (qvalid && h5 == 0) delta[((int64_t)b * H + head) * N + qrow] = dlt;
+    // published for the dK/dV kernel as the initial values of its accumulators: -delta, and -lse/scale (so that
+    // exp2((q.k - lse/scale) * scale*log2e) = exp(q.k*scale - lse))
+    if (qvalid && h5 == 0) {
+      const int64_t idx = ((int64_t)b * H + head) * N + qrow;
+      delta[idx] = -dlt;
+      delta[(int64_t)B * H * N + idx] = -lse[idx] / scale;
+    }
   }
 
   // K/V tiles go global -> LDS by LDS-DMA (see attn_fwd.hip): 1-KiB piece = 8 keys x 128 B, wave w moves pieces w and w+4 of K and
@@ -144,6 +163,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
   __syncthreads();
   // the tile loop runs in pairs so that the LDS buffer index is a literal in each copy of the body: every LDS address is then a
   // lane constant + immediate instead of a handful of v_add / v_or per fragment read
+  uint32_t ktr[2][2];  // K^T fragment addresses (tile 0 of buffer 0), [d tile][first / second read]
+  tr_dual_addr(lds_addr(lds), 0, lane, ktr[0]);
+  tr_dual_addr(lds_addr(lds), 32, lane, ktr[1]);
   auto dq_tile = [&](auto BUFC, int t) {
     constexpr int BUF = decltype(BUFC)::value;
     const int kv0 = t * 64;
@@ -153,9 +175,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
     // a wave whose 32 query rows all lie past the sequence (the last block of N = 1568 has one live wave of four) only helps
     // staging the tiles: its matrix / VALU slots go to the other waves on its SIMD
     if (wave_live)
+    static_for<0, 2>([&](auto ktc) {
+      constexpr int kt = decltype(ktc)::value;
+      if (kv0 + 32 * kt >= N) return;  // a half tile past the sequence (N = 1568: the second half of the last tile) contributes nothing
+      // K^T fragments for the dQ product, issued now and waited for after the exponentials (asm reads: see common.h)
+      s16x4 tl[2][2], th[2][2];  // [s2][dt]
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      if (kv0 + 32 * kt >= N) continue;  // a half tile past the sequence (N = 1568: the second half of the last tile) contributes nothing
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          tl[s2][dt] = s2 == 0 ? lds_tr16_b64<BUF * 2 * TILE_BYTES + (kt * 32) * 128>(ktr[dt][0])
+                               : lds_tr16_b64<BUF * 2 * TILE_BYTES + (kt * 32 + 16) * 128>(ktr[dt][0]);
+          th[s2][dt] = s2 == 0 ? lds_tr16_b64<BUF * 2 * TILE_BYTES + (kt * 32) * 128>(ktr[dt][1])
+                               : lds_tr16_b64<BUF * 2 * TILE_BYTES + (kt * 32 + 16) * 128>(ktr[dt][1]);
+        }
       f32x16 s, dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = -dlt; }
@@ -176,14 +209,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
       f32x16 ds;
 #pragma unroll
       for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(s[r] * c - lse2) * dp[r];
+      lds_wait<4>(tl[0][0], th[0][0], tl[0][1], th[0][1]);
+      {
+        const bf16x8 dsf = pack8(ds, 0);
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const bf16x8 dsf = pack8(ds, s2);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_dual(kl, kt * 32 + 16 * s2, dt * 32, lane), dsf, dq[dt], 0, 0, 0);
+        for (int dt = 0; dt < 2; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_tr(tl[0][dt], th[0][dt]), dsf, dq[dt], 0, 0, 0);
       }
-    }
+      lds_wait<0>(tl[1][0], th[1][0], tl[1][1], th[1][1]);
+      {
+        const bf16x8 dsf = pack8(ds, 1);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_tr(tl[1][dt], th[1][dt]), dsf, dq[dt], 0, 0, 0);
+      }
+    });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   };
@@ -208,11 +246,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
-__global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
-                                                           const float* __restrict__ lse, const float* __restrict__ delta,
-                                                           uint16_t* __restrict__ dqkv, int N, int H, int B, float scale) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
+                                                           const float* __restrict__ rowc_g, uint16_t* __restrict__ dqkv, int N, int H, int B,
+                                                           float scale) {
   constexpr int TILE_BYTES = 64 * 128;
-  constexpr int STAGE = 2 * TILE_BYTES + 512;  // Q tile, dO tile, 64 x (-lse/c), 64 x (-delta)
+  constexpr int STAGE = 2 * TILE_BYTES + 512;  // Q tile, dO tile, 64 x (-lse/scale), 64 x (-delta)
   __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -226,10 +264,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const uint16_t* __
   const uint16_t* kbase = base + (int64_t)H * BHD;
   const uint16_t* vbase = base + (int64_t)2 * H * BHD;
   const uint16_t* dobase = dout + ((int64_t)b * N * H + head) * BHD;  // row q at + q*H*64
-  const float* lsebase = lse + ((int64_t)b * H + head) * N;
-  const float* dltbase = delta + ((int64_t)b * H + head) * N;
   const float c = scale * LOG2E;
-  const float inv_c = 1.f / c;
 
   int krow = key0 + kl_;
   const bool kvalid = krow < N;
@@ -257,7 +292,13 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const uint16_t* __
     dma_do[i] = (uint32_t)((((int64_t)b * N + row) * H + head) * BHD * 2) + ch;
   }
   const uint32_t q_step = (uint32_t)(tok * 2), do_step = (uint32_t)(H * BHD * 2);
-  float sreg = 0.f;  // tid < 64: -lse*log2e/c of row tid ; 64 <= tid < 128: -delta of row tid-64
+  // Row constants (initial accumulator values, written by the dQ kernel): rows [0, BHN) of `rowc` hold -delta, rows [BHN, 2 BHN)
+  // hold -lse/scale.  They are staged by LDS-DMA as well (4 bytes per lane: wave 0 moves the 64 -lse/scale values of the tile,
+  // wave 1 the 64 -delta values), so the tile loop holds no ordinary global load and no LDS store -- with either of them in the loop
+  // the compiler drained the DMA of the next tile (s_waitcnt vmcnt(0)) right after issuing it.
+  const int64_t bhn = (int64_t)B * H * N;
+  const auto rs_rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rowc_g), 0, (int)(2 * bhn * 4), 0x00020000);
+  const uint32_t rc_off = (uint32_t)(((wave == 0 ? bhn : 0) + ((int64_t)b * H + head) * N + lane) * 4);
 #define LOAD_QDO(buf, q0)                                                                                  \
   {                                                                                                        \
     char* ql_ = lds + (buf) * STAGE;                                                                       \
@@ -265,18 +306,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const uint16_t* __
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_qkv, LDS_PTR(ql_ + (wave + 4 * i) * 1024), 16, dma_q[i] + (uint32_t)(q0) * q_step, 0, 0, 0); \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_do, LDS_PTR(ql_ + TILE_BYTES + (wave + 4 * i) * 1024), 16, dma_do[i] + (uint32_t)(q0) * do_step, 0, 0, 0); \
     }                                                                                                      \
-    if (tid < 128) {                                                                                       \
-      const int qq_ = (q0) + (tid & 63);                                                                   \
-      const int qc_ = qq_ > N - 1 ? N - 1 : qq_;                                                           \
-      const float lv_ = lsebase[qc_], dv_ = dltbase[qc_];                                                  \
-      /* rows >= N: exp2(c*(s-3e30)) = 0 and delta = 0 */                                                  \
-      sreg = (tid < 64) ? (qq_ < N ? -lv_ * LOG2E * inv_c : -3.0e30f) : (qq_ < N ? -dv_ : 0.f);            \
-    }                                                                                                      \
-  }
-#define WRITE_QDO(buf)                                                                             \
-  {                                                                                                \
-    if (tid < 128) reinterpret_cast<float*>(lds + (buf) * STAGE + 2 * TILE_BYTES)[tid] = sreg;     \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                               \
+    if (wave < 2) /* wave-uniform */                                                                       \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_rc, LDS_PTR(ql_ + 2 * TILE_BYTES + wave * 256), 4, rc_off + (uint32_t)(q0) * 4u, 0, 0, 0); \
   }
 
   f32x16 dk[2], dv[2];
@@ -285,51 +316,94 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const uint16_t* __
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
 
+  // Every LDS read of the tile loop is inline asm (common.h): the compiler can then neither drain the DMA of the next tile in front
+  // of a read nor serialise read -> wait -> MFMA one fragment at a time; the reads of a half tile are issued in three batches and
+  // waited for where their consumers start.  Lane-constant addresses (stage 0); the stage offset is added per tile, the half
+  // tile / fragment position is an instruction immediate.
+  const uint32_t lds0 = lds_addr(lds);
+  uint32_t qtr[2][2];  // transposed fragments of the Q tile, [d tile][first / second read]; dO tile: + TILE_BYTES
+  tr_dual_addr(lds0, 0, lane, qtr[0]);
+  tr_dual_addr(lds0, 32, lane, qtr[1]);
+  uint32_t rfa[4];     // row fragments (row lane&31 of a half tile, chunk 2ks + h5) of the Q tile; dO tile: + TILE_BYTES
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) rfa[ks] = lds0 + (uint32_t)(kl_ * 128 + (((2 * ks + h5) ^ sw_dual(kl_)) << 4));
+  const uint32_t rca = lds0 + 2 * TILE_BYTES + 16 * h5;  // row constants: 4 floats at [8 r4 + 4 h5]
+
   const int nt = (N + 63) / 64;
   LOAD_QDO(0, 0);
-  WRITE_QDO(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
     if (t + 1 < nt) LOAD_QDO((t + 1) & 1, (t + 1) * 64);
-    const char* ql = lds + (t & 1) * STAGE;
-    const char* dl = ql + TILE_BYTES;
-    const float* rowc = reinterpret_cast<const float*>(ql + 2 * TILE_BYTES);  // [0..63] -lse2/c, [64..127] -delta
+    const uint32_t so = (uint32_t)((t & 1) * STAGE);
     if (wave_live)  // (see the dQ kernel: waves whose 32 keys all lie past the sequence only stage tiles)
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-      if (t * 64 + 32 * qt >= N) continue;  // half tile of query rows past the sequence: P = dS = 0 there anyway
-      // initial accumulators: per-row constants; accumulator register r <-> row (r&3) + 8*(r>>2) + 4*h5
-      f32x16 s, dp;
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const float4 a = *reinterpret_cast<const float4*>(rowc + qt * 32 + 8 * r4 + 4 * h5);
-        const float4 d = *reinterpret_cast<const float4*>(rowc + 64 + qt * 32 + 8 * r4 + 4 * h5);
-        s[4 * r4 + 0] = a.x; s[4 * r4 + 1] = a.y; s[4 * r4 + 2] = a.z; s[4 * r4 + 3] = a.w;
-        dp[4 * r4 + 0] = d.x; dp[4 * r4 + 1] = d.y; dp[4 * r4 + 2] = d.z; dp[4 * r4 + 3] = d.w;
-      }
-      const int qrow = qt * 32 + kl_;  // A-operand row for the row reads (lane&31)
+    static_for<0, 2>([&](auto qtc) {
+      constexpr int qt = decltype(qtc)::value;
+      constexpr int HT = qt * 32 * 128;  // byte offset of the half tile inside a tile
+      if (t * 64 + 32 * qt >= N) return;  // half tile of query rows past the sequence: P = dS = 0 there anyway
+      // batch 1: initial accumulators (per-row constants; accumulator register r <-> row (r&3) + 8*(r>>2) + 4*h5) and row fragments
+      f32x4 si[4], di[4];
+      bf16x8 qa[4], da[4];
+      static_for<0, 4>([&](auto r4c) {
+        constexpr int r4 = decltype(r4c)::value;
+        si[r4] = lds_read_b128<f32x4, (qt * 32 + 8 * r4) * 4>(rca + so);
+        di[r4] = lds_read_b128<f32x4, 256 + (qt * 32 + 8 * r4) * 4>(rca + so);
+      });
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_dual(ql, qrow, ks, h5), kfr[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_dual(dl, qrow, ks, h5), vfr[ks], dp, 0, 0, 0);
+        qa[ks] = lds_read_b128<bf16x8, HT>(rfa[ks] + so);
+        da[ks] = lds_read_b128<bf16x8, TILE_BYTES + HT>(rfa[ks] + so);
       }
+      // batch 2 / 3: transposed fragments for the dV / dK products of rows 0..15 / 16..31 of the half tile
+      s16x4 dol[2][2], doh[2][2], qtl[2][2], qth[2][2];  // [s2][dt]
+#define TR_ISSUE(s2_)                                                                         \
+  _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) {                                          \
+    dol[s2_][dt] = lds_tr16_b64<TILE_BYTES + HT + 16 * (s2_) * 128>(qtr[dt][0] + so);         \
+    doh[s2_][dt] = lds_tr16_b64<TILE_BYTES + HT + 16 * (s2_) * 128>(qtr[dt][1] + so);         \
+    qtl[s2_][dt] = lds_tr16_b64<HT + 16 * (s2_) * 128>(qtr[dt][0] + so);                      \
+    qth[s2_][dt] = lds_tr16_b64<HT + 16 * (s2_) * 128>(qtr[dt][1] + so);                      \
+  }
+#define TR_MFMA(s2_, YOUNGER, pf_, dsf_)                                                                                       \
+  lds_wait<YOUNGER>(dol[s2_][0], doh[s2_][0], qtl[s2_][0], qth[s2_][0], dol[s2_][1], doh[s2_][1], qtl[s2_][1], qth[s2_][1]);   \
+  _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) {                                                                           \
+    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_tr(dol[s2_][dt], doh[s2_][dt]), pf_, dv[dt], 0, 0, 0);               \
+    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_tr(qtl[s2_][dt], qth[s2_][dt]), dsf_, dk[dt], 0, 0, 0);              \
+  }
+      TR_ISSUE(0);
+      lds_wait<16>(si[0], si[1], si[2], si[3], di[0], di[1], di[2], di[3]);  // (the counter saturates at 15: this also covers the row fragments)
+      lds_wait<8>(qa[0], qa[1], qa[2], qa[3], da[0], da[1], da[2], da[3]);
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = si[r >> 2][r & 3]; dp[r] = di[r >> 2][r & 3]; }
+      if (t * 64 + 32 * qt + 32 > N) {  // ragged half tile (N % 32 != 0): rows >= N get exp2(c*(s - 3e30)) = 0 and delta = 0
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (t * 64 + 32 * qt + (r & 3) + 8 * (r >> 2) + 4 * h5 >= N) { s[r] = -3.0e30f; dp[r] = 0.f; }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks], kfr[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[ks], vfr[ks], dp, 0, 0, 0);
+      }
+      TR_ISSUE(1);
       f32x16 pm, ds;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         pm[r] = fast_exp2(s[r] * c);
         ds[r] = pm[r] * dp[r];
       }
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const bf16x8 pf = pack8(pm, s2), dsf = pack8(ds, s2);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_dual(dl, qt * 32 + 16 * s2, dt * 32, lane), pf, dv[dt], 0, 0, 0);
-          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_dual(ql, qt * 32 + 16 * s2, dt * 32, lane), dsf, dk[dt], 0, 0, 0);
-        }
+      {
+        const bf16x8 pf = pack8(pm, 0), dsf = pack8(ds, 0);
+        TR_MFMA(0, 8, pf, dsf);
       }
-    }
-    WRITE_QDO((t + 1) & 1);
+      {
+        const bf16x8 pf = pack8(pm, 1), dsf = pack8(ds, 1);
+        TR_MFMA(1, 0, pf, dsf);
+      }
+#undef TR_ISSUE
+#undef TR_MFMA
+    });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
 
@@ -362,11 +436,12 @@ extern "C" int tad_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint
   TAD_REQUIRE(d == BHD, "attn_bwd: head_dim must be 64 (got %d)", d);
   TAD_REQUIRE(B > 0 && N > 0 && H > 0 && H <= 65535 && B <= 65535, "attn_bwd: bad shape");
   TAD_REQUIRE(scale > 0.f, "attn_bwd: scale must be positive");
+  TAD_REQUIRE((int64_t)B * H * N * 8 < (1ll << 31), "attn_bwd: B*H*N too large for the row-constant descriptor");
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)(((N + 127) / 128) * H * B)), block(256);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, block, 0, st, qkv, out, dout, lse, delta, dqkv, N, H, B, scale);
   int rc = check_launch("attn_bwd_dq");
   if (rc) return rc;
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, block, 0, st, qkv, dout, lse, delta, dqkv, N, H, B, scale);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, block, 0, st, qkv, dout, delta, dqkv, N, H, B, scale);
   return check_launch("attn_bwd_dkv");
 }

@@ -105,6 +105,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
   const int v_q = li >> 2, v_p = li & 3;
   const int v_h = G >> 1, v_dc = 16 * (G & 1) + 4 * v_p;  // d offset inside a 32-wide d tile
 
+  // lane-constant LDS addresses of the transposed V reads (keys 4*v_h + v_q (+8) of a 16-key group, d tile dt) in buffer 0;
+  // swv only looks at key bit 1, i.e. at v_q
+  uint32_t v_rd[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt) {
+    const int col = dt * 32 + v_dc, key = 4 * v_h + v_q;
+    v_rd[dt] = lds_addr(lds) + (uint32_t)(key * 128 + (((col >> 3) ^ swv(key)) << 4) + (col & 7) * 2);
+  }
+
   // all-ones A operand: row sums of P^T come out of the matrix pipe (4 extra MFMAs per tile) instead of 32 v_add per lane --
   // the kernel is VALU-issue bound (MFMA pipe ~30 % busy), and the sum then uses the same bf16-rounded P as the PV product
   bf16x8 ones;
@@ -158,22 +167,26 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
                 pf[kt][s2][j] = (__bf16)fast_exp2(s[kt][8 * s2 + j] * c - mc);                                            \
     f32x16 rs;                                                                                                            \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) rs[r] = 0.f;                                                           \
-    _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                                      \
-        _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                                \
-      rs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[kt][s2], rs, 0, 0, 0);                                        \
-      const int k0 = kt * 32 + 16 * s2 + 4 * v_h + v_q; /* first transposed read: 4 keys from k0 - v_q; second: +8 */      \
-      const int k1 = k0 + 8;                                                                                              \
-      _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) {                                                                  \
-        const int col = dt * 32 + v_dc;                                                                                   \
-        const int ch = col >> 3, sub = (col & 7) * 2;                                                                     \
-        const char* a0 = vl + k0 * 128 + ((ch ^ swv(k0)) << 4) + sub;                                                     \
-        const char* a1 = vl + k1 * 128 + ((ch ^ swv(k1)) << 4) + sub;                                                     \
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(a0)); \
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(a1)); \
-        const s16x8_t vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};                                      \
-        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[kt][s2], o[dt], 0, 0, 0);      \
-      }                                                                                                                   \
+    /* V^T fragments through the asm reads of common.h (the builtin made the compiler drain the DMA of the next tile here):  \
+       group g = 2 kt + s2 covers keys 16g .. 16g+15; the reads of group g+1 are issued before the MFMAs of group g */     \
+    s16x4 vlo[2][2], vhi[2][2]; /* [group parity][dt] */                                                                  \
+    _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) {                                                                    \
+      vlo[0][dt] = lds_tr16_b64<(BUF) * 2 * TILE_BYTES + TILE_BYTES>(v_rd[dt]);                                           \
+      vhi[0][dt] = lds_tr16_b64<(BUF) * 2 * TILE_BYTES + TILE_BYTES + 8 * 128>(v_rd[dt]);                                 \
     }                                                                                                                     \
+    static_for<0, 4>([&](auto gc) {                                                                                       \
+      constexpr int g_ = decltype(gc)::value, par = g_ & 1;                                                               \
+      if constexpr (g_ < 3) {                                                                                             \
+        _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) {                                                                \
+          vlo[par ^ 1][dt] = lds_tr16_b64<(BUF) * 2 * TILE_BYTES + TILE_BYTES + (g_ + 1) * 16 * 128>(v_rd[dt]);           \
+          vhi[par ^ 1][dt] = lds_tr16_b64<(BUF) * 2 * TILE_BYTES + TILE_BYTES + (g_ + 1) * 16 * 128 + 8 * 128>(v_rd[dt]); \
+        }                                                                                                                 \
+      }                                                                                                                   \
+      rs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[g_ >> 1][g_ & 1], rs, 0, 0, 0);                               \
+      lds_wait<(g_ < 3 ? 4 : 0)>(vlo[par][0], vhi[par][0], vlo[par][1], vhi[par][1]);                                     \
+      _Pragma("unroll") for (int dt = 0; dt < 2; ++dt)                                                                    \
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_tr(vlo[par][dt], vhi[par][dt]), pf[g_ >> 1][g_ & 1], o[dt], 0, 0, 0); \
+    });                                                                                                                   \
     l_run += rs[0]; /* every row of rs holds the full column sum over the 64 keys: no cross-lane step */                  \
     }                                                                                                                     \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                      \

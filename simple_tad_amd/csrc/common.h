@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <type_traits>
 #include "../../include/tad_mi355x.h"
 
 namespace tad {
@@ -54,6 +55,62 @@ __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
+}
+
+// ---- transposed LDS reads (ds_read_b64_tr_b16) as inline asm
+// hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of the BUILTIN form of this read whenever an LDS-DMA (buffer_load ... lds) is
+// in flight -- it cannot tell that the read does not touch the DMA's destination -- so the prefetch of the next tile was drained
+// right after it had been issued and never overlapped the matrix work (plain ds_read_b128 reads do not get that wait).  The asm form
+// is invisible to the compiler's waitcnt pass: the DMA stays in flight, but the result registers must be waited for BY HAND with
+// lds_wait<N>(regs...), which emits s_waitcnt lgkmcnt(N) and names the registers as in/out operands so that no consumer (and no
+// register copy) can be scheduled ahead of it.  N = number of LDS instructions issued after the ones being waited for (LDS operations
+// complete in order; reads the compiler issues by itself in between only make the wait more conservative, never wrong; the counter
+// has 4 bits, so N saturates at 15).
+// EXEC must be all ones (the gather crosses lanes).
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)LDS_PTR(p); }
+template <int OFF>
+__device__ __forceinline__ s16x4 lds_tr16_b64(uint32_t addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+  s16x4 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+template <typename T, int OFF>
+__device__ __forceinline__ T lds_read_b128(uint32_t addr) {  // plain 16-byte read (T = bf16x8, f32x4 ...), same contract as lds_tr16_b64
+  static_assert(OFF >= 0 && OFF < 65536 && sizeof(T) == 16, "ds offset field is 16 bits; 16-byte result");
+  T r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+#define TAD_LGKM(N) "n"((N) > 15 ? 15 : (N))
+template <int N, typename A>
+__device__ __forceinline__ void lds_wait(A& a) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : TAD_LGKM(N));
+}
+template <int N, typename A, typename B>
+__device__ __forceinline__ void lds_wait(A& a, B& b) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : TAD_LGKM(N));
+}
+template <int N, typename A, typename B, typename C, typename D>
+__device__ __forceinline__ void lds_wait(A& a, B& b, C& c, D& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : TAD_LGKM(N));
+}
+template <int N, typename A, typename B, typename C, typename D, typename E, typename F, typename G, typename H>
+__device__ __forceinline__ void lds_wait(A& a, B& b, C& c, D& d, E& e, F& f, G& g, H& h) {
+  asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : TAD_LGKM(N));
+}
+__device__ __forceinline__ bf16x8 join_tr(const s16x4& lo, const s16x4& hi) {
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+// compile-time loop: f(std::integral_constant<int, I>) for I in [BEGIN, END)
+template <int BEGIN, int END, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (BEGIN < END) {
+    f(std::integral_constant<int, BEGIN>{});
+    static_for<BEGIN + 1, END>(f);
+  }
 }
 
 // raw v_exp_f32 (2^x); denormal results flush to zero, which is what the softmax wants

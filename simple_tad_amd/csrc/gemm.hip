@@ -649,21 +649,8 @@ struct GemmTN {
 // swizzle of the 16-byte chunk index within a tile row (rows are >= 256 bytes); changes bits 1..3 only
 __device__ __forceinline__ int sw_tn(int row) { return ((row & 3) | ((row >> 1) & 4)) << 1; }
 
-// transposed 16x16x32 fragment from a [64 red rows][rowbytes] tile: lane (g = lane>>4, li = lane&15) supplies rows
-// 32ks + 8g + (li>>2) (+4), columns col0 + 4*(li&3); receives column col0 + li, reduction rows 32ks + 8g + 0..7
-__device__ __forceinline__ bf16x8 tr_frag_tn(const char* base, int rowbytes, int ks, int col0, int lane) {
-  const int g = lane >> 4, li = lane & 15, lq = li >> 2, lp = li & 3;
-  const int r0 = 32 * ks + 8 * g + lq, r1 = r0 + 4;
-  const int col = col0 + 4 * lp;
-  const int ch = col >> 3, sub = (col & 7) * 2;
-  const char* a0 = base + r0 * rowbytes + ((ch ^ sw_tn(r0)) << 4) + sub;
-  const char* a1 = base + r1 * rowbytes + ((ch ^ sw_tn(r1)) << 4) + sub;
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(a0));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(a1));
-  typedef __attribute__((ext_vector_type(8))) short s16x8;
-  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return __builtin_bit_cast(bf16x8, v);
-}
+// Transposed 16x16x32 fragments from a [64 reduction rows][row bytes] tile: lane (g = lane>>4, li = lane&15) supplies rows
+// 32ks + 8g + (li>>2) (+4 for the second read), columns col0 + 4*(li&3); it receives column col0 + li, reduction rows 32ks + 8g + 0..7.
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int BKT = 64>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(const GemmTN p) {
@@ -747,6 +734,26 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(const Ge
 #pragma unroll
     for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // Fragment reads are inline asm (lds_tr16_b64, common.h): with the builtin the compiler drained the LDS-DMA of the next stage
+  // (s_waitcnt vmcnt(0)) in front of the first read after it had been issued, i.e. staging and matrix work ran one after the other.
+  // Byte offset of a fragment's first read inside its tile for k-step 0; the second read is 4 rows further, k-step 1 32 rows
+  // further (neither changes the swizzle: sw_tn looks at row bits 0, 1 and 3), both as instruction immediates.
+  static_assert(NREP == 4, "the waits below are written for four column fragments per wave");
+  uint32_t p_rd[MREP], q_rd[NREP];
+  {
+    const int r0 = 8 * g + (li >> 2);
+#pragma unroll
+    for (int i = 0; i < MREP; ++i) {
+      const int col = wm * WTM + 16 * i + 4 * (li & 3);
+      p_rd[i] = (uint32_t)(r0 * PROW + (((col >> 3) ^ sw_tn(r0)) << 4) + (col & 7) * 2);
+    }
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) {
+      const int col = wn * WTN + 16 * j + 4 * (li & 3);
+      q_rd[j] = (uint32_t)(r0 * QROW + (((col >> 3) ^ sw_tn(r0)) << 4) + (col & 7) * 2);
+    }
+  }
+  const uint32_t lds0 = lds_addr(lds);
 
 #pragma unroll
   for (int st = 0; st < STAGES - 1; ++st)
@@ -755,31 +762,41 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(const Ge
   for (int t = 0; t < nt; ++t) {
     wait_stage<LOADS>(min(STAGES - 2, nt - 1 - t));
     block_barrier();
-    const char* sp = lds + rd * STAGE_BYTES;
-    const char* sq = sp + P_BYTES;
+    const uint32_t st_addr = lds0 + (uint32_t)(rd * STAGE_BYTES);
     const bool more = t + STAGES - 1 < nt;
     const bool bias_now = bias_on && (t % tiles_k == tk_);
     const int wr_now = wr, t_next = t + STAGES - 1;
     rd = (rd + 1 == STAGES) ? 0 : rd + 1;
     wr = (wr + 1 == STAGES) ? 0 : wr + 1;
-#define KSTEP_TN(ks)                                                                                        \
-  if (!(DBG_BITS(p) & 8)) {                                                                                     \
-    bf16x8 pf[MREP], qf[NREP];                                                                              \
-    _Pragma("unroll") for (int j = 0; j < NREP; ++j) qf[j] = tr_frag_tn(sq, QROW, (ks), wn * WTN + 16 * j, lane);  \
-    _Pragma("unroll") for (int i = 0; i < MREP; ++i) pf[i] = tr_frag_tn(sp, PROW, (ks), wm * WTM + 16 * i, lane);  \
-    if (!(DBG_BITS(p) & 2)) {                                                                                   \
-      _Pragma("unroll") for (int i = 0; i < MREP; ++i)                                                      \
-          _Pragma("unroll") for (int j = 0; j < NREP; ++j)                                                  \
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], pf[i], acc[i][j], 0, 0, 0);        \
-    } else {                                                                                                \
-      _Pragma("unroll") for (int i = 0; i < MREP; ++i) asm volatile("" ::"v"(pf[i]));                       \
-      _Pragma("unroll") for (int j = 0; j < NREP; ++j) asm volatile("" ::"v"(qf[j]));                       \
-    }                                                                                                       \
-    if (bias_now) {                                                                                         \
-      _Pragma("unroll") for (int ib = 0; ib < BREP; ++ib)                                                   \
-          _Pragma("unroll") for (int w2 = 0; w2 < WAVES_N; ++w2)                                            \
-              if (w2 == wn) bacc[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[ib * WAVES_N + w2], ones, bacc[ib], 0, 0, 0); \
-    }                                                                                                       \
+#define KSTEP_TN(ks)                                                                                          \
+  if (!(DBG_BITS(p) & 8)) {                                                                                   \
+    s16x4 ql_[NREP], qh_[NREP], pl_[MREP], ph_[MREP];                                                         \
+    _Pragma("unroll") for (int j = 0; j < NREP; ++j) {                                                        \
+      ql_[j] = lds_tr16_b64<P_BYTES + (ks) * 32 * QROW>(st_addr + q_rd[j]);                                   \
+      qh_[j] = lds_tr16_b64<P_BYTES + (ks) * 32 * QROW + 4 * QROW>(st_addr + q_rd[j]);                        \
+    }                                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < MREP; ++i) {                                                        \
+      pl_[i] = lds_tr16_b64<(ks) * 32 * PROW>(st_addr + p_rd[i]);                                             \
+      ph_[i] = lds_tr16_b64<(ks) * 32 * PROW + 4 * PROW>(st_addr + p_rd[i]);                                  \
+    }                                                                                                         \
+    /* the four column fragments (8 reads), then one row fragment (2 reads) at a time as its MFMAs come up */ \
+    lds_wait<2 * MREP>(ql_[0], qh_[0], ql_[1], qh_[1], ql_[2], qh_[2], ql_[3], qh_[3]);                       \
+    bf16x8 qf[NREP];                                                                                          \
+    _Pragma("unroll") for (int j = 0; j < NREP; ++j) qf[j] = join_tr(ql_[j], qh_[j]);                         \
+    static_for<0, MREP>([&](auto ic) {                                                                        \
+      constexpr int i = decltype(ic)::value;                                                                  \
+      lds_wait<2 * (MREP - 1 - i)>(pl_[i], ph_[i]);                                                           \
+      const bf16x8 pf = join_tr(pl_[i], ph_[i]);                                                              \
+      if (!(DBG_BITS(p) & 2)) {                                                                               \
+        _Pragma("unroll") for (int j = 0; j < NREP; ++j)                                                      \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], pf, acc[i][j], 0, 0, 0);               \
+      } else {                                                                                                \
+        asm volatile("" ::"v"(pf));                                                                           \
+        _Pragma("unroll") for (int j = 0; j < NREP; ++j) asm volatile("" ::"v"(qf[j]));                       \
+      }                                                                                                       \
+      if (bias_now && (i % WAVES_N) == wn)                                                                    \
+        bacc[i / WAVES_N] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, ones, bacc[i / WAVES_N], 0, 0, 0);    \
+    });                                                                                                       \
   }
     const bool late = wave >= NW / 2;  // stagger the DMA issue of the two waves that share a SIMD (see gemm_nt_kernel)
     const bool dma = more && !(DBG_BITS(p) & 1);
