@@ -461,6 +461,22 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
         if (st < nk) { STAGE_NT(st, st); }
     }
   }
+  // Per-row scale (drop-path keep / scale of the row's clip): a 256-row tile lies in at most two groups of rows_per_scale rows
+  // (1568 tokens per clip), so the tile takes its one or two scales through scalar loads here.  A per-row global load inside the row
+  // pass costs a `s_waitcnt vmcnt(0)` per row -- which on CDNA4 also drains every store and the residual rows fetched ahead.
+  // The 256-row tiles are only launched with groups of at least 256 rows (launch_nt_variant) and carry no other path; the 128-row tile
+  // keeps the per-row load for shorter groups (tiny problems).
+  constexpr bool RS_ALWAYS_TILE = BM >= 256;
+  float rs_lo = 1.f, rs_hi = 1.f;
+  int rs_split = 0x7fffffff;
+  const bool rs_tile = IS_RES && p.rowscale && (RS_ALWAYS_TILE || p.rows_per_scale >= BM);
+  if (rs_tile) {
+    const int g0 = (em0 + p.row_base) / p.rows_per_scale;
+    const int last = (em0 + BM - 1 < p.M ? em0 + BM - 1 : p.M - 1) + p.row_base;
+    rs_lo = p.rowscale[g0];
+    rs_hi = p.rowscale[last / p.rows_per_scale];
+    rs_split = (g0 + 1) * p.rows_per_scale - p.row_base;  // first row (of this launch) in the second group
+  }
   if (DIRECT && !((DBG_BITS(p) & 4) && p.M > 1)) {
     float gam[CPL];
 #pragma unroll
@@ -468,7 +484,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
       if (i + 1 < MREP) { ISSUE_EXTRA_D(i + 1, (i + 1) & 1); }
       const int m = em0 + wm * WTM + 16 * i + c;
       float rsc = 1.f;
-      if (IS_RES && p.rowscale && m < p.M) rsc = p.rowscale[(m + p.row_base) / p.rows_per_scale];
+      if (RS_ALWAYS_TILE || rs_tile) rsc = m < rs_split ? rs_lo : rs_hi;
+      else if (IS_RES && p.rowscale && m < p.M) rsc = p.rowscale[(m + p.row_base) / p.rows_per_scale];
 #pragma unroll
       for (int jj = 0; jj < NJ; ++jj) {
         const int nn = DIRECT_COL(jj);
@@ -590,7 +607,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
           if (p.gamma || p.rowscale) {
             const int lr = ((r0 + b) * NW + wave) * RPI + lane / LPR;
             const int m = em0 + (lr / (16 * MREP_C)) * WTM + 16 * MREP_C * q + lr % (16 * MREP_C);
-            const float rsc = (p.rowscale && m < p.M) ? p.rowscale[(m + p.row_base) / p.rows_per_scale] : 1.f;
+            float rsc;
+            if (RS_ALWAYS_TILE || rs_tile) rsc = m < rs_split ? rs_lo : rs_hi;
+            else rsc = (p.rowscale && m < p.M) ? p.rowscale[(m + p.row_base) / p.rows_per_scale] : 1.f;
 #pragma unroll
             for (int e = 0; e < CPL; ++e) v[b][e] *= gam[e] * rsc;
           }
@@ -888,6 +907,7 @@ static void launch_nt_variant(int v, GemmNT& p, hipStream_t st) {
   auto tiles = [&](int bm, int bn) { return ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
   const int no_persist = !g_nt_persist, stagger_pct = g_nt_stagger_pct, stagger_group = g_nt_stagger_group;
   if (((EPI == EPI_RESIDUAL && OUT_BF16) || EPI == EPI_RESMOD) && v == 1) v = 3;  // (not instantiated: no registers / never needed)
+  if (v != 2 && p.rowscale && p.rows_per_scale < 256) v = 2;  // the 256-row tiles take at most two row-scale groups per tile
   const int grid_p = cu_count() & ~7;
   const int bn = v == 1 ? 256 : 128;
   const bool persist = !no_persist && (v == 1 || v == 3) && grid_p >= 8 && tiles(256, bn) > grid_p + grid_p / 2;
