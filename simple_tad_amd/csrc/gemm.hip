@@ -77,13 +77,20 @@ __device__ __forceinline__ int sw_nt(int row) { return ((row >> 1) & 7) ^ (((row
 
 // one wave issues PIECES 1-KiB LDS-DMA pieces: piece i of wave w lands at tile + (i*NW + w)*1024; off[i] is the lane's byte
 // offset into the buffer resource (already swizzled), `add` the per-tile advance
-template <int PIECES, int NW>
+// SCALAR_ADD: `add` goes into the instruction's scalar offset instead of a v_add per piece (8 short-lived VGPRs at the point of the
+// loop where the fragments are live too: the DGELU / residual 256 x 256 kernels spilled there, and the reload's vmcnt(0) drained the
+// DMA).  Only legal when off[i] alone decides whether the access is inside the operand -- true for gemm_nt, whose `add` moves along
+// a row (rows >= M have off[i] >= gbytes already), not for gemm_tn, whose `add` moves down the rows -- so the bounds check gives the
+// same answer whether or not the hardware includes the scalar offset in it.
+template <int PIECES, int NW, bool SCALAR_ADD = false>
 __device__ __forceinline__ void stage_tile(const void* gbase, int gbytes, char* tile, const uint32_t* off, uint32_t add, int wave) {
   // descriptor over the whole operand: reads past the end return 0 (rows beyond M / N)
   const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(gbase), 0, gbytes, 0x00020000);
 #pragma unroll
-  for (int i = 0; i < PIECES; ++i)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(tile + (i * NW + wave) * 1024), 16, off[i] + add, 0, 0, 0);
+  for (int i = 0; i < PIECES; ++i) {
+    if (SCALAR_ADD) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(tile + (i * NW + wave) * 1024), 16, off[i], add, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(tile + (i * NW + wave) * 1024), 16, off[i] + add, 0, 0, 0);
+  }
 }
 
 // wait until at most `stages_in_flight` later stages (LOADS DMA instructions each, per wave) plus EXTRA younger vector-memory
@@ -217,8 +224,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
     }                                                                                                                  \
   }
 #define STAGE_NT(buf, kt) \
-  stage_tile<BM / (RPP * NW), NW>(p.A, a_bytes, lds + (buf) * STAGE_BYTES, a_off, (uint32_t)(kt) * ROWB, wave); \
-  stage_tile<BN / (RPP * NW), NW>(p.B, b_bytes, lds + (buf) * STAGE_BYTES + A_BYTES, b_off, (uint32_t)(kt) * ROWB, wave)
+  stage_tile<BM / (RPP * NW), NW, true>(p.A, a_bytes, lds + (buf) * STAGE_BYTES, a_off, (uint32_t)(kt) * ROWB, wave); \
+  stage_tile<BN / (RPP * NW), NW, true>(p.B, b_bytes, lds + (buf) * STAGE_BYTES + A_BYTES, b_off, (uint32_t)(kt) * ROWB, wave)
 
   // ---- fragment addressing
   const int c = lane & 15, kq = lane >> 4;
