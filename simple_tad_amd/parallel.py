@@ -55,6 +55,51 @@ def init_distributed_mode(backend: Optional[str] = None):
     return True, rank, world, local
 
 
+class ShardSampler:
+    """Index sharding of the clip set across ranks: the role `torch.utils.data.DistributedSampler(dataset, num_replicas,
+    rank, shuffle=True, seed)` plays in the reference (run_class_finetuning.py:239-241, `set_epoch` at :502; shuffle=False
+    for validation, :248-254).  Same published algorithm, hence the same indices: permutation of range(n) from a
+    torch.Generator seeded `seed + epoch`, padded by wrap-around to a multiple of the world size (or truncated with
+    drop_last), rank r takes positions r, r + world, r + 2 world, ...  Usable as the `sampler=` of a DataLoader."""
+
+    def __init__(self, n: int, num_replicas: Optional[int] = None, rank: Optional[int] = None, shuffle: bool = True, seed: int = 0,
+                 drop_last: bool = False):
+        if num_replicas is None:
+            num_replicas = dist.get_world_size() if dist.is_initialized() else 1
+        if rank is None:
+            rank = dist.get_rank() if dist.is_initialized() else 0
+        if not 0 <= rank < num_replicas:
+            raise ValueError(f"rank {rank} outside [0, {num_replicas})")
+        self.n, self.num_replicas, self.rank, self.shuffle, self.seed, self.drop_last = int(n), num_replicas, rank, shuffle, seed, drop_last
+        self.epoch = 0
+        if drop_last and self.n % num_replicas:
+            self.num_samples = (self.n - num_replicas + num_replicas - 1) // num_replicas  # = n // world
+        else:
+            self.num_samples = (self.n + num_replicas - 1) // num_replicas
+        self.total_size = self.num_samples * num_replicas
+
+    def set_epoch(self, epoch: int):
+        self.epoch = int(epoch)
+
+    def __len__(self):
+        return self.num_samples
+
+    def __iter__(self):
+        if self.shuffle:
+            g = torch.Generator()
+            g.manual_seed(self.seed + self.epoch)
+            idx = torch.randperm(self.n, generator=g).tolist()
+        else:
+            idx = list(range(self.n))
+        if not self.drop_last:
+            pad = self.total_size - len(idx)
+            if pad > 0:
+                idx += (idx * ((pad + len(idx) - 1) // max(len(idx), 1) + 1))[:pad] if pad > len(idx) else idx[:pad]
+        else:
+            idx = idx[:self.total_size]
+        return iter(idx[self.rank:self.total_size:self.num_replicas])
+
+
 class DataParallel(nn.Module):
     """Replicated-model data parallelism with bucketed, overlapped gradient all-reduce."""
 

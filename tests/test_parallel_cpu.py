@@ -124,3 +124,25 @@ def test_flat_space_layout_and_views():
     assert lin[0].weight.grad.data_ptr() == sp.grad_view(lin[0].weight).data_ptr() and float(fg.sum()) == 0.0
     lin[0].weight.data = lin[0].weight.data.clone()
     assert not sp.params_are_flat()
+
+
+@pytest.mark.parametrize("n,world", [(10, 2), (11, 4), (7, 8), (1000, 8), (3, 2)])
+@pytest.mark.parametrize("shuffle,drop_last", [(True, False), (False, False), (True, True)])
+def test_shard_sampler_matches_torch_distributed_sampler(n, world, shuffle, drop_last):
+    """row 15 (index sharding): identical indices to torch.utils.data.DistributedSampler, which the reference uses
+    (run_class_finetuning.py:239-241), for every rank and epoch; together the ranks cover the clip set"""
+    from torch.utils.data import DistributedSampler
+    from simple_tad_amd.parallel import ShardSampler
+    data = list(range(n))
+    for epoch in (0, 1, 5):
+        seen = []
+        for rank in range(world):
+            ref = DistributedSampler(data, num_replicas=world, rank=rank, shuffle=shuffle, seed=3, drop_last=drop_last)
+            ref.set_epoch(epoch)
+            ours = ShardSampler(n, num_replicas=world, rank=rank, shuffle=shuffle, seed=3, drop_last=drop_last)
+            ours.set_epoch(epoch)
+            a, b = list(ref), list(ours)
+            assert a == b and len(ours) == len(ref) == len(b)
+            seen += b
+        if not drop_last:
+            assert set(seen) == set(data)
