@@ -114,11 +114,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
     v_rd[dt] = lds_addr(lds) + (uint32_t)(key * 128 + (((col >> 3) ^ swv(key)) << 4) + (col & 7) * 2);
   }
 
-  // all-ones A operand: row sums of P^T come out of the matrix pipe (4 extra MFMAs per tile) instead of 32 v_add per lane --
-  // the kernel is VALU-issue bound (MFMA pipe ~30 % busy), and the sum then uses the same bf16-rounded P as the PV product
-  bf16x8 ones;
+  // Row sums of P^T out of the matrix pipe instead of 32 v_add per lane and tile (the kernel is VALU-issue bound, and the sum then uses
+  // the same bf16-rounded P as the PV product) -- as ONE v_mfma_f32_16x16x32_bf16 per P fragment (half the matrix time and a quarter
+  // of the accumulator registers of a 32x32x16 against all-ones).  Fed to the 16x16x32 instruction, a P fragment register reads as
+  // B[k-group kg = lane>>4][column lane&15]: kg 0 / 2 = keys 0..7 / 8..15 of query lane&15, kg 1 / 3 = the same of query 16 + (lane&15).
+  // The selector A has ones in rows 0 and 8 over kg {0, 2} and in rows 4 and 12 over kg {1, 3}; output register 0 of lane l is
+  // D[4 (l>>4)][l & 15]: lanes 0-15 and 32-47 get the sum of query l & 15, lanes 16-31 and 48-63 that of query 16 + (l & 15) -- each
+  // lane its own query (lane & 31), no cross-lane step.
+  bf16x8 sel;
+  {
+    const int m = lane & 15, kg = lane >> 4;
+    const bool on = ((m & 7) == 0 && (kg & 1) == 0) || ((m & 7) == 4 && (kg & 1) == 1);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+    for (int e = 0; e < 8; ++e) sel[e] = (__bf16)(on ? 1.0f : 0.0f);
+  }
 
   // One K/V tile of 64 keys out of LDS buffer BUF (a literal: every LDS address below is then lane-constant + immediate).
 #define FWD_TILE(BUF, T)                                                                                                  \
@@ -165,8 +174,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
         _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2)                                                                  \
             _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                                 \
                 pf[kt][s2][j] = (__bf16)fast_exp2(s[kt][8 * s2 + j] * c - mc);                                            \
-    f32x16 rs;                                                                                                            \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) rs[r] = 0.f;                                                           \
+    f32x4 rs = {0.f, 0.f, 0.f, 0.f};                                                                                      \
     /* V^T fragments through the asm reads of common.h (the builtin made the compiler drain the DMA of the next tile here):  \
        group g = 2 kt + s2 covers keys 16g .. 16g+15; the reads of group g+1 are issued before the MFMAs of group g */     \
     s16x4 vlo[2][2], vhi[2][2]; /* [group parity][dt] */                                                                  \
@@ -182,12 +190,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
           vhi[par ^ 1][dt] = lds_tr16_b64<(BUF) * 2 * TILE_BYTES + TILE_BYTES + (g_ + 1) * 16 * 128 + 8 * 128>(v_rd[dt]); \
         }                                                                                                                 \
       }                                                                                                                   \
-      rs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[g_ >> 1][g_ & 1], rs, 0, 0, 0);                               \
+      rs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sel, pf[g_ >> 1][g_ & 1], rs, 0, 0, 0);                                \
       lds_wait<(g_ < 3 ? 4 : 0)>(vlo[par][0], vhi[par][0], vlo[par][1], vhi[par][1]);                                     \
       _Pragma("unroll") for (int dt = 0; dt < 2; ++dt)                                                                    \
         o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_tr(vlo[par][dt], vhi[par][dt]), pf[g_ >> 1][g_ & 1], o[dt], 0, 0, 0); \
     });                                                                                                                   \
-    l_run += rs[0]; /* every row of rs holds the full column sum over the 64 keys: no cross-lane step */                  \
+    l_run += rs[0]; /* the lane's own query: see `sel` */                                                                 \
     }                                                                                                                     \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                      \
     __syncthreads();                                                                                                      \
