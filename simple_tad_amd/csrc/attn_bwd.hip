@@ -3,13 +3,13 @@
 // Two kernels, both deterministic (no atomics):
 //   1. attn_bwd_dq_kernel: one workgroup = 128 query rows, loops over 64-key tiles (structure of the forward kernel).  Its
 //        prologue computes delta[b,h,q] = sum_d dO[q,d] * O[q,d] for its own rows (the dO fragments are in registers anyway) and
-//        publishes it for kernel 2 -- a separate delta pass was one more launch and one more read of dO per layer.
+//        publishes -delta and -lse/scale for kernel 2 -- a separate delta pass was one more launch and one more read of dO per layer.
 //        S^T = K Q^T, dP^T = V dO^T (query on the lane -> lse/delta are per-lane scalars),
 //        dS^T = P^T o (dP^T - delta), dQ^T += K^T dS^T (dS^T accumulator registers are the MFMA B operand).
 //   2. attn_bwd_dkv_kernel: one workgroup = 128 keys (32 per wave, K/V fragments pinned in registers), loops over
-//        64-row query tiles: S = Q K^T and dP = dO V^T with the key on the lane and (-lse, -delta) preloaded as the
-//        initial accumulators, then dV^T += dO^T P and dK^T += Q^T dS with P / dS taken straight from the
-//        accumulator registers.
+//        64-row query tiles: S = Q K^T and dP = dO V^T with the key on the lane and (-lse/scale, -delta) -- staged by LDS-DMA next
+//        to the Q / dO tiles -- preloaded as the initial accumulators, then dV^T += dO^T P and dK^T += Q^T dS with P / dS taken
+//        straight from the accumulator registers.
 // Summing dQ across key blocks would need ~1 GB of f32 atomics per layer at N=1568 (0.8 ms at the chip's 1.3 TB/s
 // atomic rate, more than the whole MFMA work), so dQ gets its own pass that recomputes S and dP (7 instead of 5
 // MFMA products, but no cross-workgroup reduction and bitwise-reproducible results).

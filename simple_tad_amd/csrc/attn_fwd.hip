@@ -1,15 +1,15 @@
 // Fused space-time attention forward (flash-style, non-causal, head_dim 64) for gfx950.
 //
 // qkv is the packed output of the qkv Linear: [B, N, 3, H, 64] bf16.  One workgroup = 4 waves = 128 query rows of one
-// (batch, head); each wave owns 32 query rows.  K/V tiles of 64 keys are staged global -> registers -> LDS
-// (double-buffered, loads for tile t+1 issued before the MFMA work on tile t, written after it), one barrier per tile.
+// (batch, head); each wave owns 32 query rows.  K/V tiles of 64 keys are staged global -> LDS by LDS-DMA (double-buffered,
+// the DMA of tile t+1 issued before the MFMA work on tile t), one barrier per tile.
 //
 // The score tile is computed *transposed*: S^T = K * Q^T with v_mfma_f32_32x32x16_bf16, so the query index sits on the
 // lane (lane & 31) and the keys on the accumulator registers.  The softmax row reductions are then in-lane max/add over
 // registers plus ONE exchange between the two 32-lane halves (v_permlane32_swap), and the P^T accumulator registers are,
 // after a pairwise bf16 pack, directly the B operand of the O^T += V^T * P^T MFMA (no LDS round trip for P).  V^T
-// fragments come from the row-major V tile with ds_read_b64_tr_b16.  Both LDS images are XOR-swizzled so all reads are
-// bank-conflict free (tools/lds_bank_sim.py).
+// fragments come from the row-major V tile with ds_read_b64_tr_b16 (inline asm with hand-counted waits: common.h).  Both LDS
+// images are XOR-swizzled so all reads are bank-conflict free (tools/lds_bank_sim.py).
 #include "common.h"
 
 namespace tad {
