@@ -126,7 +126,7 @@ def test_layernorm_fwd_bwd(K, rows, D):
 
 
 # ------------------------------------------------------------------ linear
-LIN_SHAPES = [(300, 384, 128), (2500, 768, 256), (16, 128, 1536), (2304, 100, 64), (3000, 1152, 384), (4100, 2304, 768)]
+LIN_SHAPES = [(300, 384, 128), (2500, 768, 256), (16, 128, 1536), (2304, 100, 64), (3000, 1152, 384), (4100, 2304, 768), (1568, 768, 3072)]
 
 
 @pytest.mark.parametrize("M,N,Kd", LIN_SHAPES)
