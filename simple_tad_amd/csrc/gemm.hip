@@ -907,14 +907,14 @@ static int* sched_ring(hipStream_t st) {
 static long long g_nt_launches = 0;  // gemm_nt kernel launches so far (tad_linear_kernel_launches)
 
 // Tile configurations.  NT: 1 = 256x256 (2x4 waves) 2 stages; 2 = 128x128 (2x2) 2 stages, 2 workgroups/CU;
-// 3 = 256x128 (4x2) 3 stages; 4 = 128x64 (2x2) 2 stages (small problems).  0 = auto.  The epilogue kind and output type are compile-time (the epilogue is VALU-bound).
+// 3 = 256x128 (4x2) 3 stages; 4 = 128x64, 5 = 64x64 (2x2 waves, 2 stages: small problems).  0 = auto.  The epilogue kind and output type are compile-time (the epilogue is VALU-bound).
 // Variants 1 and 3 run as persistent kernels (one workgroup per CU walks a tile list) once there are more than 1.5 tiles per CU.
 template <int EPI, bool OUT_BF16>
 static void launch_nt_variant(int v, GemmNT& p, hipStream_t st) {
   auto tiles = [&](int bm, int bn) { return ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
   const int no_persist = !g_nt_persist, stagger_pct = g_nt_stagger_pct, stagger_group = g_nt_stagger_group;
   if (((EPI == EPI_RESIDUAL && OUT_BF16) || EPI == EPI_RESMOD) && v == 1) v = 3;  // (not instantiated: no registers / never needed)
-  if (v != 2 && v != 4 && p.rowscale && p.rows_per_scale < 256) v = 2;  // the 256-row tiles take at most two row-scale groups per tile
+  if (v != 2 && v != 4 && v != 5 && p.rowscale && p.rows_per_scale < 256) v = 2;  // the 256-row tiles take at most two row-scale groups per tile
   const int grid_p = cu_count() & ~7;
   const int bn = v == 1 ? 256 : 128;
   const bool persist = !no_persist && (v == 1 || v == 3) && grid_p >= 8 && tiles(256, bn) > grid_p + grid_p / 2;
@@ -955,6 +955,9 @@ static void launch_nt_variant(int v, GemmNT& p, hipStream_t st) {
       break;
     case 4:
       if (direct) NT_LAUNCH(128, 64, 2, 2, 2, false, true, tiles(128, 64), 256); else NT_LAUNCH(128, 64, 2, 2, 2, false, false, tiles(128, 64), 256);
+      break;
+    case 5:
+      if (direct) NT_LAUNCH(64, 64, 2, 2, 2, false, true, tiles(64, 64), 256); else NT_LAUNCH(64, 64, 2, 2, 2, false, false, tiles(64, 64), 256);
       break;
     default:
       if (direct) NT_LAUNCH(128, 128, 2, 2, 2, false, true, tiles(128, 128), 256); else NT_LAUNCH(128, 128, 2, 2, 2, false, false, tiles(128, 128), 256);
@@ -1032,7 +1035,9 @@ int launch_gemm_nt(const GemmNT& p_in, hipStream_t st) {
     // small problems (batch-1 inference: 1568 or 784 rows): 128 x 128 tiles, or 128 x 64 when those would leave more than half of the
     // CUs without a workgroup (ViT-B proj / fc2 at 1568 rows: 78 tiles of 128 x 128)
     const int64_t t128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
-    return launch_gemm_nt_one(p, (t128 * 2 <= cu_count() && p.N >= 64) ? 4 : 2, st);
+    const int64_t t64 = (int64_t)((p.M + 127) / 128) * ((p.N + 63) / 64);
+    if (t128 * 2 > cu_count() || p.N < 64) return launch_gemm_nt_one(p, 2, st);
+    return launch_gemm_nt_one(p, (t64 * 4 <= 3 * cu_count() && p.M >= 64) ? 5 : 4, st);  // 64 x 64 while even 128 x 64 fills < 3/4 of the CUs
   }
   const bool v1_ok = !(p.epi == EPI_RESIDUAL && (p.c_bf16 || p.res_mod > 0));  // (those instantiations do not exist)
   // Plans: (a) 256 x 128 tiles, (b) 256 x 256 tiles, (c) 256 x 256 tiles for as many row panels as fill whole rounds of one
