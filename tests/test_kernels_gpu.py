@@ -185,7 +185,7 @@ def test_linear_bwd(K, M, N, Kd):
 
 
 # ------------------------------------------------------------------ attention
-ATT_SHAPES = [(2, 100, 2), (1, 1568, 2), (3, 64, 1), (2, 8, 3), (1, 784, 6), (1, 129, 1)]
+ATT_SHAPES = [(2, 100, 2), (1, 1568, 2), (3, 64, 1), (2, 8, 3), (1, 784, 6), (1, 129, 1), (4, 600, 12)]
 
 
 def _attn_ref(qkv, B, N, H, scale, dout=None):
