@@ -157,6 +157,18 @@ def test_linear_fwd_epilogues(K, M, N, Kd):
     check(yr, ref_r, what="linear residual")
     yr2, _ = K.linear_fwd(xd, wd, dev(b), out_dtype=torch.float32, epilogue=2, residual=dev(res))
     check(yr2, res.double() + ref, what="linear residual plain")
+    # groups at least as long as a tile (clips of 1568 tokens in the model): the epilogue takes one or two scales per tile instead of
+    # one load per row; group boundaries fall inside tiles, a zero scale (dropped sample) must give exactly the residual
+    for rows_per in (130, 300, 1568):
+        ng = (M + rows_per - 1) // rows_per
+        rs = torch.tensor([0.0 if i % 3 == 1 else 1.0 + 0.25 * i for i in range(ng)])
+        yr3, _ = K.linear_fwd(xd, wd, dev(b), out_dtype=torch.float32, epilogue=2, residual=dev(res), gamma=dev(gam), rowscale=dev(rs),
+                              rows_per_scale=rows_per)
+        ref3 = res.double() + rs.double().repeat_interleave(rows_per)[:M, None] * gam.double() * ref
+        check(yr3, ref3, what=f"linear residual, groups of {rows_per}")
+        dropped = (rs.repeat_interleave(rows_per)[:M] == 0)
+        if dropped.any():
+            assert torch.equal(yr3.cpu()[dropped], res[dropped]), "a dropped sample must pass the residual through unchanged"
 
 
 @pytest.mark.parametrize("M,N,Kd", [(300, 384, 128), (2500, 768, 3072), (1570, 3072, 768), (100, 64, 128)])
