@@ -79,14 +79,16 @@ def main():
             continue
         name = m.group(1)
         j = i
-        while j < len(text) and "s_endpgm" not in text[j]:
+        while j < len(text) and not text[j].startswith(".Lfunc_end"):  # (a body can hold several s_endpgm)
             j += 1
         res = {}
         k = j
-        while k < len(text) and k < j + 80:
+        while k < len(text) and not re.match(r"^_Z\w+:", text[k]):
             mm = re.match(r"^; (NumVgprs|NumAgprs|ScratchSize|Occupancy|LDSByteSize): (\d+)", text[k])
             if mm:
-                res[mm.group(1)] = int(mm.group(2))
+                res.setdefault(mm.group(1), int(mm.group(2)))
+            if "Occupancy" in res:
+                break
             k += 1
         if not a.kernel or a.kernel in name:
             flag = "  <-- SPILLS" if res.get("ScratchSize", 0) else ""
