@@ -161,8 +161,10 @@ int tad_linear_bwd_weight(const uint16_t* dy, const uint16_t* x, float* dW, floa
  * out [B,N,H,d] in out_dtype; lse [B,H,N] f32 = log(sum_j exp(scale * q.k_j)) (natural log). */
 int tad_attn_fwd(const uint16_t* qkv, void* out, int out_dtype, float* lse, int B, int N, int H, int d,
                  float scale, tad_stream_t stream);
-/* dqkv [B,N,3,H,d] bf16 (fully overwritten).  delta: f32 scratch of 2*B*H*N elements (the first kernel leaves -rowsum(dout*out)
- * in [0, BHN) and -lse/scale in [BHN, 2 BHN) for the second one, which takes them as the initial values of its accumulators). */
+/* dqkv [B,N,3,H,d] bf16 (fully overwritten).  delta: scratch of tad_attn_bwd_scratch_bytes(B, N, H) bytes = 2*B*H*N floats (the
+ * first kernel leaves -rowsum(dout*out) in [0, BHN) and -lse/scale in [BHN, 2 BHN) for the second one, which takes them as the
+ * initial values of its accumulators). */
+size_t tad_attn_bwd_scratch_bytes(int B, int N, int H);
 int tad_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* lse,
                  uint16_t* dqkv, float* delta, int B, int N, int H, int d, float scale,
                  tad_stream_t stream);

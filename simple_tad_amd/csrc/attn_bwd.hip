@@ -430,6 +430,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
 
 using namespace tad;
 
+extern "C" size_t tad_attn_bwd_scratch_bytes(int B, int N, int H) {
+  if (B <= 0 || N <= 0 || H <= 0) return 0;
+  return (size_t)2 * B * H * N * sizeof(float);
+}
+
 extern "C" int tad_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* lse, uint16_t* dqkv, float* delta,
                             int B, int N, int H, int d, float scale, tad_stream_t stream) {
   TAD_REQUIRE(qkv && out && dout && lse && dqkv && delta, "attn_bwd: null pointer");

@@ -438,7 +438,7 @@ def attn_bwd(qkv, out, dout, lse, B: int, N: int, H: int, scale: float):
         _req(t, torch.bfloat16, "attn_bwd." + n)
     _req(lse, torch.float32, "attn_bwd.lse")
     dqkv = torch.empty_like(qkv)
-    delta = torch.empty((2, B, H, N), dtype=torch.float32, device=qkv.device)  # scratch: -rowsum(dout*out), -lse/scale
+    delta = torch.empty((_lib.load().tad_attn_bwd_scratch_bytes(B, N, H) // 4,), dtype=torch.float32, device=qkv.device)  # -rowsum(dout*out), -lse/scale
     with _timed("attn_bwd", 8.0 * B * H * N * N * 64, 2.0 * 8 * B * N * H * 64):
         check(_lib.load().tad_attn_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), delta.data_ptr(),
                                        B, N, H, 64, float(scale), _stream()), "tad_attn_bwd")
