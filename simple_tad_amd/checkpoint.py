@@ -9,30 +9,34 @@ from collections import OrderedDict
 import torch
 
 
+# Key rewrites between a pre-training checkpoint and the fine-tuning model, first match wins: (prefix in the checkpoint, prefix in the
+# model).  ``encoder.norm`` must come before ``encoder.``: the MAE encoder's final LayerNorm becomes the classifier's ``fc_norm``.
+KEY_PREFIX_MAP = (("backbone.", ""), ("encoder.norm", "fc_norm"), ("encoder.", ""))
+HEAD_KEYS = ("head.weight", "head.bias")
+
+
+def _rename(key: str) -> str:
+    for src, dst in KEY_PREFIX_MAP:
+        if key.startswith(src):
+            return dst + key[len(src):]
+    return key
+
+
+def _select(checkpoint, model_key: str):
+    """the state dict inside a checkpoint: the first of ``model_key``'s '|'-separated names present, else the checkpoint itself"""
+    if isinstance(checkpoint, dict):
+        for name in model_key.split('|'):
+            if name in checkpoint:
+                return checkpoint[name]
+    return checkpoint
+
+
 def remap_pretrained_state_dict(checkpoint, model: torch.nn.Module, model_key: str = "model|module", num_frames: int = 16):
-    checkpoint_model = None
-    for key in model_key.split('|'):
-        if isinstance(checkpoint, dict) and key in checkpoint:
-            checkpoint_model = checkpoint[key]
-            break
-    if checkpoint_model is None:
-        checkpoint_model = checkpoint
-    checkpoint_model = OrderedDict(checkpoint_model)
-    state_dict = model.state_dict()
-    for k in ['head.weight', 'head.bias']:
-        if k in checkpoint_model and checkpoint_model[k].shape != state_dict[k].shape:
-            del checkpoint_model[k]
-    new_dict = OrderedDict()
-    for key in list(checkpoint_model.keys()):
-        if key.startswith('backbone.'):
-            new_dict[key[9:]] = checkpoint_model[key]
-        elif key.startswith('encoder.norm'):
-            new_dict[key.replace("encoder.norm", "fc_norm")] = checkpoint_model[key]
-        elif key.startswith('encoder.'):
-            new_dict[key[8:]] = checkpoint_model[key]
-        else:
-            new_dict[key] = checkpoint_model[key]
-    checkpoint_model = new_dict
+    own = model.state_dict()
+    source = _select(checkpoint, model_key)
+    # a classifier head of another shape (other number of classes) is dropped before the renaming, as the reference does
+    stale_head = {k for k in HEAD_KEYS if k in source and k in own and source[k].shape != own[k].shape}
+    checkpoint_model = OrderedDict((_rename(k), v) for k, v in source.items() if k not in stale_head)
     if 'pos_embed' in checkpoint_model:  # learnable table only (the sinusoid table is not in the state dict)
         pos = checkpoint_model['pos_embed']
         emb = pos.shape[-1]

@@ -118,3 +118,30 @@ def check_summary(t: torch.Tensor, npz, key: str, rtol: float, atol_scale: float
 # the tiny full-model configuration used by G3 (real head geometry d=64, K_patch % 64 == 0)
 TINY = dict(img_size=16, patch_size=8, embed_dim=128, depth=2, num_heads=2, all_frames=4, tubelet_size=2,
             num_classes=2)
+
+
+# ---- real-size fixtures (G10 ViT-L/16 MAE, G11 ViT-B/16 gradients): weights come from the model's own seeded init, inputs from here
+G10_ROWS = [0, 1, 587, 1175]   # masked-token rows of each clip whose whole 1536-wide prediction / label is stored
+
+
+def rerandomize_1d(model, seed: int = 1234):
+    """Every 1-D parameter ~ N(0, 0.02) (+1 for norm weights), in registration order, so that biases and LayerNorm affine terms
+    are exercised (the seeded init leaves them at 0 / 1).  Same recipe as G4's inline loop."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if p.dim() == 1:
+                p.copy_((torch.randn(p.shape, generator=g) * 0.02 + (1.0 if "norm" in k and k.endswith("weight") else 0.0)).to(p.device))
+
+
+def clip_for(tag: str, shape: Iterable[int], seed: int = 0) -> torch.Tensor:
+    """a normalised clip batch [B,3,T,H,W] ~ N(0,1) (the reference's own convention for synthetic input, test_efficiency.py:17)"""
+    return tensor_for(tag, shape, seed)
+
+
+def tube_masks(tag: str, batch: int, input_size, mask_ratio: float, generator_cls, seed: int = 0) -> torch.Tensor:
+    """bool [B, T'*H'*W'] tube masks from ``generator_cls(input_size, mask_ratio)`` (the reference's TubeMaskingGenerator or this
+    repo's), numpy's global RNG seeded from the tag -- one generator call per clip, as the reference's data loader does."""
+    np.random.seed(_seed_for(tag, seed))
+    gen = generator_cls(input_size, mask_ratio)
+    return torch.from_numpy(np.stack([gen() for _ in range(batch)])).bool()

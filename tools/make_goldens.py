@@ -373,11 +373,11 @@ def g7(ris):
     save("g7_input_stage", **arrs)
 
 
-def g8(mf):
-    """MAE pre-training path (SURVEY 8f-2): the real modeling_pretrain.PretrainVisionTransformer (tiny, fp64) driven by the real
-    engine_for_pretraining.train_one_epoch for ONE step on CPU.  The engine's module-level imports that this image lacks (utils ->
-    tensorboardX..., timm.data.constants) are satisfied by MagicMock / the published ImageNet constants; ``nn.MSELoss`` is wrapped to
-    record the (outputs, labels) pair the engine builds, ``torch.cuda.*`` calls are no-ops on CPU."""
+def _pretrain_engine(mf):
+    """The reference's pre-training engine importable on CPU: module-level imports that this image lacks (utils -> tensorboardX...,
+    timm.data.constants) are satisfied by MagicMock / the published ImageNet constants.  Returns (modeling_pretrain,
+    engine_for_pretraining, run) where run(model, x, mask, normlize_target) drives the REAL train_one_epoch for one step with
+    ``nn.MSELoss`` wrapped to record the (outputs, labels) pair the engine builds; ``torch.cuda.*`` calls are no-ops on CPU."""
     import contextlib
     import unittest.mock as mock
     tdc = types.ModuleType("timm.data.constants")
@@ -411,6 +411,35 @@ def g8(mf):
     sys.modules["utils"] = um
     import modeling_pretrain as mp
     import engine_for_pretraining as efp
+
+    def run(model, x, mask, normlize_target=True):
+        captured = {}
+
+        class _MSE(nn.MSELoss):
+            def forward(self, input, target):
+                captured["outputs"], captured["labels"] = input.detach().clone(), target.detach().clone()
+                return super().forward(input, target)
+
+        def scaler(loss, optimizer, clip_grad=None, parameters=None, create_graph=False):
+            loss.backward()
+            captured["loss"] = loss.detach().clone()
+            return 0.0
+
+        scaler.state_dict = lambda: {"scale": 1.0}
+        opt = torch.optim.SGD(model.parameters(), lr=0.0)
+        with mock.patch.object(efp.nn, "MSELoss", _MSE), mock.patch("torch.cuda.empty_cache"), mock.patch("torch.cuda.synchronize"), \
+                mock.patch("torch.cuda.amp.autocast", lambda *a, **k: contextlib.nullcontext()):
+            efp.train_one_epoch(model, [(x, mask)], opt, torch.device("cpu"), 0, scaler, max_norm=0, patch_size=16,
+                                normlize_target=normlize_target, start_steps=0)
+        return captured
+
+    return mp, efp, run
+
+
+def g8(mf):
+    """MAE pre-training path (SURVEY 8f-2): the real modeling_pretrain.PretrainVisionTransformer (tiny, fp64) driven by the real
+    engine_for_pretraining.train_one_epoch for ONE step on CPU (see _pretrain_engine)."""
+    mp, efp, run = _pretrain_engine(mf)
     torch.manual_seed(0)
     model = mp.PretrainVisionTransformer(img_size=32, patch_size=16, encoder_embed_dim=128, encoder_depth=2, encoder_num_heads=2,
                                          decoder_num_classes=1536, decoder_embed_dim=64, decoder_depth=1, decoder_num_heads=1,
@@ -426,37 +455,76 @@ def g8(mf):
         rng.shuffle(per)
         masks.append(np.tile(per, (8, 1)).flatten())
     mask = torch.from_numpy(np.stack(masks)).bool()
-    captured = {}
-
-    class _MSE(nn.MSELoss):
-        def forward(self, input, target):
-            captured["outputs"], captured["labels"] = input.detach().clone(), target.detach().clone()
-            return super().forward(input, target)
-
-    def scaler(loss, optimizer, clip_grad=None, parameters=None, create_graph=False):
-        loss.backward()
-        captured["loss"] = loss.detach().clone()
-        return 0.0
-
-    scaler.state_dict = lambda: {"scale": 1.0}
-    opt = torch.optim.SGD(model.parameters(), lr=0.0)
-    with mock.patch.object(efp.nn, "MSELoss", _MSE), mock.patch("torch.cuda.empty_cache"), mock.patch("torch.cuda.synchronize"), \
-            mock.patch("torch.cuda.amp.autocast", lambda *a, **k: contextlib.nullcontext()):
-        efp.train_one_epoch(model, [(x, mask)], opt, torch.device("cpu"), 0, scaler, max_norm=0, patch_size=16, normlize_target=True,
-                            start_steps=0)
+    captured = run(model, x, mask, True)
     arrs = {"mask": mask.numpy(), "outputs": captured["outputs"].numpy(), "labels": captured["labels"].numpy(),
             "loss": np.array(captured["loss"].item()), "keys": np.array(list(P.keys()))}
     for k, p in model.named_parameters():
         for kk, v in R.summarize(p.grad.float()).items():
             arrs[f"grad.{k}.{kk}"] = v
     # un-normalised (normlize_target=False) labels as well
-    captured.clear()
-    with mock.patch.object(efp.nn, "MSELoss", _MSE), mock.patch("torch.cuda.empty_cache"), mock.patch("torch.cuda.synchronize"), \
-            mock.patch("torch.cuda.amp.autocast", lambda *a, **k: contextlib.nullcontext()):
-        efp.train_one_epoch(model, [(x, mask)], opt, torch.device("cpu"), 0, scaler, max_norm=0, patch_size=16, normlize_target=False,
-                            start_steps=0)
-    arrs["labels_raw"] = captured["labels"].numpy()
+    arrs["labels_raw"] = run(model, x, mask, False)["labels"].numpy()
     save("g8_pretrain", **arrs)
+
+
+def g10(mf, mg):
+    """BASELINE configs[4] at its real size: pretrain_videomae_large_patch16_224 (ViT-L/16 encoder, 12-block decoder as in
+    jobs/dapt/pretrain_capdata_large.sh:34-36), 16x224x224, B = 2, tube mask 0.75 (392 visible / 1176 masked tokens per clip),
+    driven by the REAL engine_for_pretraining.train_one_epoch for one step in fp64.  The weights (340 M parameters) are not stored:
+    they are the reference's own seeded init (torch.manual_seed(0)) with every 1-D parameter re-randomised; per-tensor checksums let
+    the tests prove that the regenerated model is identical before outputs are compared."""
+    mp, efp, run = _pretrain_engine(mf)
+    torch.manual_seed(0)
+    model = mp.pretrain_videomae_large_patch16_224(pretrained=False, drop_path_rate=0.0, decoder_depth=12, use_checkpoint=False,
+                                                   use_flash_attn=False)
+    R.rerandomize_1d(model)
+    x = R.clip_for("g10.x", (2, 3, 16, 224, 224))
+    mask = R.tube_masks("g10", 2, (8, 14, 14), 0.75, generator_cls=mg.TubeMaskingGenerator)
+    keys = list(model.state_dict().keys())
+    arrs = {"mask": np.packbits(mask.numpy(), axis=1), "keys": np.array(keys),
+            "wsum": np.array([model.state_dict()[k].double().sum().item() for k in keys]),
+            "wabs": np.array([model.state_dict()[k].double().abs().sum().item() for k in keys]),
+            "nparams": np.array(sum(p.numel() for p in model.parameters()))}
+    model = model.double()
+    cap = run(model, x.double(), mask, True)
+    out, lab = cap["outputs"], cap["labels"]
+    assert out.shape == (2, 1176, 1536) and lab.shape == out.shape
+    arrs["loss"] = np.array(cap["loss"].item())
+    for nm, t in (("outputs", out), ("labels", lab)):
+        for kk, v in R.summarize(t.float(), head=4096).items():
+            arrs[f"{nm}.{kk}"] = v
+        arrs[f"{nm}.rows"] = t[:, R.G10_ROWS].float().numpy()       # a few whole prediction rows per clip
+    for k, p in model.named_parameters():
+        for kk, v in R.summarize(p.grad.float()).items():
+            arrs[f"grad.{k}.{kk}"] = v
+    arrs["grad_norm"] = np.array(torch.norm(torch.stack([torch.norm(p.grad.detach(), 2.0) for p in model.parameters()]), 2.0).item())
+    save("g10_vitl_mae", **arrs)
+
+
+def g11(mf):
+    """Gradient side of BASELINE configs[2] at its real shape: ViT-B/16 16x224x224, B = 2, forward + CE loss + backward through the
+    real reference model (fp64 run of the fp32-valued weights / inputs of G4's b16 case, so the stored numbers are correctly
+    rounded): logits, loss, utils.get_grad_norm_ norm and a summary (head + sum + sum of squares) of every gradient."""
+    torch.manual_seed(0)
+    model = mf.vit_base_patch16_224(num_classes=2, all_frames=16, tubelet_size=2, final_reduction="fc_norm", use_flash_attn=False,
+                                    init_scale=1.0, drop_path_rate=0.0)
+    R.rerandomize_1d(model)
+    torch.manual_seed(1)
+    x = torch.randn(2, 3, 16, 224, 224)
+    labels = torch.tensor([0, 1])
+    keys = list(model.state_dict().keys())
+    arrs = {"keys": np.array(keys), "wsum": np.array([model.state_dict()[k].double().sum().item() for k in keys])}
+    model = model.double().train()
+    feats = model.forward_features(x.double())
+    logits = model.head(feats)
+    loss = nn.CrossEntropyLoss()(logits, labels)
+    loss.backward()
+    arrs.update({"features": feats.detach().float().numpy(), "logits": logits.detach().numpy(), "loss": np.array(loss.item()),
+                 "grad_keys": np.array([k for k, _ in model.named_parameters()])})
+    arrs["grad_norm"] = np.array(torch.norm(torch.stack([torch.norm(p.grad.detach(), 2.0) for p in model.parameters()]), 2.0).item())
+    for k, p in model.named_parameters():
+        for kk, v in R.summarize(p.grad.float()).items():
+            arrs[f"grad.{k}.{kk}"] = v
+    save("g11_vitb_grads", **arrs)
 
 
 def g9():
@@ -483,7 +551,8 @@ def main():
     torch.set_num_threads(8)
     ris, mf, mg = import_reference()
     jobs = {"g1": lambda: g1(mf), "g2": lambda: g2(mf), "g3": lambda: g3(mf), "g4": lambda: g4(mf, ris),
-            "g5": g5, "g6": lambda: g6(mg), "g7": lambda: g7(ris), "g8": lambda: g8(mf), "g9": g9}
+            "g5": g5, "g6": lambda: g6(mg), "g7": lambda: g7(ris), "g8": lambda: g8(mf), "g9": g9,
+            "g10": lambda: g10(mf, mg), "g11": lambda: g11(mf)}
     for k, fn in jobs.items():
         if a.only and a.only != k:
             continue
