@@ -174,6 +174,26 @@ class NativeScalerWithGradNormCount:
         pass
 
 
+def synchronize_meters(stats: dict, device=None) -> dict:
+    """C4 of SURVEY 2.3 -- ``MetricLogger.synchronize_between_processes`` (utils.py:71-82, called at engine_for_finetuning.py:138):
+    every meter's (count, total) summed over the ranks, returned as ``{name: global_avg}`` (engine_for_finetuning.py:140), so every
+    rank logs the same epoch averages.  The reference issues one barrier + one fp64 all-reduce PER meter; here all meters travel in
+    ONE fp64 all-reduce of a [n_meters, 2] tensor.  Single process: the local averages.  ``None`` entries are skipped as
+    MetricLogger.update does (utils.py:121-122)."""
+    import torch.distributed as dist
+    names = sorted(k for k, v in stats.items() if isinstance(v, list))
+    packed = torch.zeros((len(names), 2), dtype=torch.float64)
+    for i, k in enumerate(names):
+        vals = [float(v) for v in stats[k] if v is not None]
+        packed[i, 0], packed[i, 1] = len(vals), sum(vals)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.get_backend() == "nccl":
+            packed = packed.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(packed)
+        packed = packed.cpu()
+    return {k: (packed[i, 1] / packed[i, 0]).item() for i, k in enumerate(names) if packed[i, 0] > 0}
+
+
 def train_class_batch(model, samples, target, criterion):
     """engine_for_finetuning.py:13-16"""
     outputs = model(samples)
@@ -185,7 +205,8 @@ def train_one_epoch(model: torch.nn.Module, criterion, data_loader: Iterable, op
                     max_norm: float = 0, start_steps=0, lr_schedule_values=None, wd_schedule_values=None,
                     num_training_steps_per_epoch=None, update_freq=1, log=None):
     """engine_for_finetuning.train_one_epoch (engine_for_finetuning.py:24-140) without mixup / EMA / DeepSpeed branches.
-    The loader yields (samples [B,3,T,H,W], targets [B], *rest)."""
+    The loader yields (samples [B,3,T,H,W], targets [B], *rest).  Returns the per-step meter lists of THIS rank plus
+    ``stats["averaged"]`` = the cross-rank epoch averages the reference returns (``{k: meter.global_avg}``)."""
     model.train(True)
     dp = model if isinstance(model, DataParallel) else None
     zero = (dp.zero_grad if dp is not None else lambda: optimizer.zero_grad(set_to_none=False))
@@ -226,6 +247,8 @@ def train_one_epoch(model: torch.nn.Module, criterion, data_loader: Iterable, op
         stats["min_lr"].append(min(g["lr"] for g in optimizer.param_groups))
         if log is not None:
             log(epoch, data_iter_step, stats)
+    # gather the stats from all processes (engine_for_finetuning.py:137-140): per-step lists stay per rank, "averaged" is global
+    stats["averaged"] = synchronize_meters(stats, device)
     return stats
 
 

@@ -69,4 +69,7 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, optimizer, de
         stats["weight_decay"].append(next((g["weight_decay"] for g in optimizer.param_groups if g["weight_decay"] > 0), None))
         if log is not None:
             log(epoch, step, stats)
+    # engine_for_pretraining.py:149-152: metric_logger.synchronize_between_processes() -> {k: meter.global_avg}
+    from .engine import synchronize_meters
+    stats["averaged"] = synchronize_meters(stats, device)
     return stats

@@ -40,6 +40,8 @@ class SlidingWindow:
         self.use_graph = bool(use_graph)
         self._graphs = {}
         self._pool = None
+        self._params = list(model.parameters())
+        self._sig = None
 
     @property
     def full(self) -> bool:
@@ -68,6 +70,14 @@ class SlidingWindow:
         try:
             if not self.use_graph:
                 return self.model(self.ring)
+            # A captured graph reads the bf16 weight copies (ops._wcache) and scratch buffers by raw pointer: the graphs are dropped
+            # whenever the weights may have changed (a new weight epoch, a parameter re-assigned or modified in place), and each
+            # graph entry keeps the copies it was captured with alive (kernels.workspace never frees a buffer either).
+            from . import ops
+            sig = (ops.weight_epoch(), tuple(p._version for p in self._params), tuple(p.data_ptr() for p in self._params[:4]))
+            if sig != self._sig:
+                self._graphs.clear()
+                self._sig = sig
             ent = self._graphs.get(self.start)
             if ent is None:
                 side = torch.cuda.Stream()
@@ -80,7 +90,7 @@ class SlidingWindow:
                     self._pool = torch.cuda.graph_pool_handle()
                 with torch.cuda.graph(g, pool=self._pool):
                     out = self.model(self.ring)
-                ent = self._graphs[self.start] = (g, out)
+                ent = self._graphs[self.start] = (g, out, ops.cached_weight_tensors())
             ent[0].replay()
             return ent[1].clone()
         finally:

@@ -109,13 +109,20 @@ def _dt(t: torch.Tensor) -> int:
     raise _lib.TadError(f"unsupported dtype {t.dtype}")
 
 
+_retired = []  # outgrown scratch buffers: kept alive because a captured HIP graph may have baked their addresses in
+
+
 def workspace(nbytes: int, device) -> torch.Tensor:
-    """Grow-only scratch buffer per device.  All kernels run on the current stream in issue
-    order, so one buffer is shared by consecutive ops."""
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+    """Grow-only scratch buffer per (device, stream): kernels on one stream run in issue order, so consecutive ops share it; another
+    stream (a side-stream warm-up, a capture stream) gets its own and never aliases it.  A buffer that is outgrown is retired, not
+    freed -- HIP graphs captured earlier (inference.SlidingWindow, bench --graph) hold raw pointers into it.  Growth is geometric, so
+    the retired buffers together stay below the size of the live one."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        if ws is not None:
+            _retired.append(ws)
+        ws = torch.empty(max(int(nbytes), 2 * (ws.numel() if ws is not None else 0), 1 << 20), dtype=torch.uint8, device=device)
         _workspaces[key] = ws
     return ws
 

@@ -186,9 +186,9 @@ class Block(nn.Module):
             s1 = dp.sample(x.shape[0], x.device) if dp is not None else None
             s2 = dp.sample(x.shape[0], x.device) if dp is not None else None
             a, m = self.attn, self.mlp
-            return ops.BlockFn.apply(x, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.q_bias, a.v_bias, a.proj.weight,
-                                     a.proj.bias, self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight,
-                                     m.fc2.bias, s1, s2, a.num_heads, a.scale, self.norm1.eps)
+            return ops.block_apply(x, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.q_bias, a.v_bias, a.proj.weight,
+                                   a.proj.bias, self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight,
+                                   m.fc2.bias, s1, s2, a.num_heads, a.scale, self.norm1.eps)
         # layer-scale / dropout variants: composed from the per-operator kernels
         n1 = ops.LayerNormFn.apply(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         n1 = self.attn(n1)
@@ -349,7 +349,9 @@ class VisionTransformer(nn.Module):
     def forward_features(self, x):
         pos = self._pos_on(x.device)
         if isinstance(self.pos_embed, nn.Parameter):
-            x = self.patch_embed(x) + pos  # learnable table: keep it in the autograd graph
+            # learnable table: the reference adds ``pos_embed.expand(...).clone().detach()`` (modeling_finetune.py:312-313), so the
+            # table never receives a gradient -- reproduced (pinned by tests/test_module_cpu.py)
+            x = self.patch_embed(x, pos_embed=pos.detach().to(dtype=torch.float32).contiguous())
         else:
             x = self.patch_embed(x, pos_embed=pos)  # fused "+ pos_embed" epilogue
         x = self.pos_drop(x)
@@ -358,10 +360,8 @@ class VisionTransformer(nn.Module):
                 x = checkpoint.checkpoint(blk, x, use_reentrant=False)
         else:
             self._presample_drop_path(x.shape[0], x.device)
-            ops.reset_block_chain()
             for blk in self.blocks:
                 x = blk(x)
-            ops.reset_block_chain()  # (keeps the bf16 hand-off entries of a backward that has not run yet: only the forward side is reset)
         x = self._ln(self.norm, x)
         if self.final_reduction == "fc_norm":
             return self._ln(self.fc_norm, ops.MeanPoolFn.apply(x))

@@ -34,8 +34,27 @@ _MAKERS = {}
 
 
 def invalidate_weight_cache():
-    """Drop every cached bf16 weight copy (call after modifying parameters by any means that may not bump ``_version``)."""
+    """Drop every cached bf16 weight copy AND every optimizer-written operand mirror (call after modifying parameters by any means
+    that may not bump ``_version``: ``p.data.copy_``, a torch fused optimizer step, EMA swaps).  optim.FusedAdamW calls this and then
+    re-registers the mirrors it has just rewritten."""
+    global _weight_epoch
+    _weight_epoch += 1
     _wcache.clear()
+    _mirrors.clear()
+    _mirrors_t.clear()
+
+
+_weight_epoch = 0
+
+
+def weight_epoch() -> int:
+    """bumped by every invalidate_weight_cache(): holders of captured HIP graphs compare it to know when to re-capture"""
+    return _weight_epoch
+
+
+def cached_weight_tensors():
+    """every bf16 weight copy currently cached (a captured graph keeps this list so that the addresses it baked in stay allocated)"""
+    return [v for ent in _wcache.values() for k, v in ent.items() if k not in ("ref", "key")]
 
 
 def _w2d(p):
@@ -421,37 +440,54 @@ class MlpFn(_Fn):
 
 
 # --------------------------------------------------------------------------- fused Block
-class _BlockChain:
-    """Hand-off between consecutive fused Blocks.  Block i's backward starts by casting the incoming residual-stream gradient to
-    bf16 scaled by ITS drop-path scale dp2 -- a pass over an f32 [M, D] tensor that block i+1's LayerNorm backward, which produces
-    that very gradient, can emit on the side.  Forward: block i leaves (output pointer, dp2) here; block i+1 picks it up if its
-    input is that output.  Backward: block i+1 leaves the bf16 copy keyed by the f32 gradient's data pointer; block i takes it if
-    the gradient autograd hands over is that tensor.  Anything unexpected (checkpointing, hooks that copy gradients, a consumer
-    in between) just misses and falls back to the cast pass."""
+class _ChainLink:
+    """Hand-off between two consecutive fused Blocks, one object per Block forward.  Block i's backward starts by casting the incoming
+    residual-stream gradient to bf16 scaled by ITS drop-path scale dp2 -- a pass over an f32 [M, D] tensor that block i+1's LayerNorm
+    backward, which produces that very gradient, can emit on the side.
 
+    Forward: ``block_apply`` creates the link of block i, stores it in block i's ctx and hangs it on block i's OUTPUT TENSOR OBJECT;
+    block i+1 finds it on its input (``_tad_link``) and keeps it as ``ctx.prev_link``.  Anything in between that produces a new tensor
+    (checkpointing, a hook, ``x + 0``) drops the attribute, so the next block simply has no predecessor.
+    Backward: block i+1 deposits (bf16 copy, the f32 gradient tensor it returns, that tensor's version) in ITS prev_link -- the
+    object only block i's ctx of the SAME forward holds; block i takes the copy only if the gradient autograd hands it is still that
+    storage, shape and version.  A second consumer of block i's output makes autograd either allocate a new sum (pointer differs)
+    or accumulate in place (version differs): both miss and fall back to the cast pass.  Nothing is keyed by raw pointers in a
+    process-wide table, so a stale entry of an earlier iteration can never be picked up by a later one."""
+    __slots__ = ("dp2", "deposit", "__weakref__")
+
+    def __init__(self, dp2):
+        self.dp2 = dp2
+        self.deposit = None
+
+
+class _ChainState:
     def __init__(self):
-        self.out_ptr = 0
-        self.dp2 = None
-        self.ready = {}
         self.enabled = True
-        self.hits = 0  # hand-offs taken (tests)
-
-    def reset(self):
-        self.out_ptr, self.dp2 = 0, None
-        self.ready.clear()
+        self.hits = 0      # hand-offs taken (tests)
+        self.pending = 0   # deposits made and not yet consumed or dropped (tests: must be 0 after a backward pass)
 
 
-_chain = _BlockChain()
+_chain = _ChainState()
 
 
 def reset_block_chain():
-    _chain.reset()
+    """kept for API compatibility: the hand-off state lives in per-forward link objects and needs no reset"""
 
 
 def set_block_chain(enabled: bool):
     """switch the Block-to-Block bf16 gradient hand-off off / on (results are bit-identical either way; for tests and timing)"""
     _chain.enabled = bool(enabled)
-    _chain.reset()
+
+
+def block_apply(x, *args):
+    """BlockFn.apply plus the chain bookkeeping on the input / output tensor objects"""
+    prev = getattr(x, "_tad_link", None) if _chain.enabled else None
+    dp2 = args[14]
+    link = _ChainLink(None if dp2 is None else _f32c(dp2)) if (_chain.enabled and torch.is_grad_enabled()) else None
+    out = BlockFn.apply(x, *args, prev, link)
+    if link is not None and out.requires_grad:
+        out._tad_link = link
+    return out
 
 
 class BlockFn(_Fn):
@@ -461,7 +497,7 @@ class BlockFn(_Fn):
 
     @staticmethod
     def forward(ctx, x, n1w, n1b, qkv_w, q_bias, v_bias, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, dp1, dp2, H, scale,
-                eps):
+                eps, prev_link=None, link=None):
         _need_gpu(x, "Block")
         B, N, D = x.shape
         M = B * N
@@ -483,9 +519,9 @@ class BlockFn(_Fn):
         ctx.biases = (proj_b, fc1_b, fc2_b)
         ctx.norms = (n1w, n1b, n2w, n2b)
         ctx.qv = (q_bias, v_bias)
-        # block chain: what my backward should emit for the block before me / what the block after me needs to know
-        ctx.prev = (True, _chain.dp2) if (train and _chain.enabled and _chain.out_ptr and _chain.out_ptr == x0.data_ptr()) else (False, None)
-        _chain.out_ptr, _chain.dp2 = x2.data_ptr(), (None if dp2 is None else _f32c(dp2))
+        # block chain (_ChainLink): where my backward deposits the bf16 gradient for the block before me / takes the one made for me
+        ctx.prev_link = prev_link if train else None
+        ctx.link = link if train else None
         return x2.reshape(B, N, D)
 
     @staticmethod
@@ -497,11 +533,17 @@ class BlockFn(_Fn):
         M = B * N
         g = _f32c(g).reshape(M, D)
         # ---- MLP branch
-        gb = _chain.ready.pop(g.data_ptr(), None)
-        if gb is None or gb.shape != g.shape:
+        gb = None
+        dep = ctx.link.deposit if ctx.link is not None else None
+        if dep is not None:
+            ctx.link.deposit = None
+            _chain.pending -= 1
+            cand, ref, ver = dep
+            if ref.data_ptr() == g.data_ptr() and ref._version == ver and g._version == ver and cand.shape == g.shape:
+                gb = cand
+                _chain.hits += 1
+        if gb is None:
             gb = K.cast_bf16(g) if dp2 is None else K.scale_cast_bf16(g, None, dp2, N)
-        else:
-            _chain.hits += 1
         dh = K.linear_bwd_input(gb, wT_bf16(fc2_w, True), gelu_preact=h)
         dW2, db2 = linear_dw(gb, a, fc2_w, fc2_b)
         dxn2 = K.linear_bwd_input(dh, wT_bf16(fc1_w, True))
@@ -515,15 +557,17 @@ class BlockFn(_Fn):
         d_ao = K.linear_bwd_input(gpb, wT_bf16(proj_w, True))
         dWp, _ = linear_dw(gpb, ao, proj_w)
         dxn1, dWqkv, dqb, dvb = _attn_bwd_core(d_ao, xn1, qkv, ao, lse, qkv_w, has_qb, B, N, H, scale, torch.bfloat16, ctx.qv)
-        emit, prev_dp2 = ctx.prev
-        if emit:
-            gin, ginb, dg1, dbeta1, _ = layernorm_bwd_sunk(dxn1, x0, g1, mean1, rstd1, n1w, n1b, dres=gmid, want_bf16=True, rowscale=prev_dp2,
+        prev = ctx.prev_link
+        if prev is not None:
+            gin, ginb, dg1, dbeta1, _ = layernorm_bwd_sunk(dxn1, x0, g1, mean1, rstd1, n1w, n1b, dres=gmid, want_bf16=True, rowscale=prev.dp2,
                                                            rows_per_scale=N)
-            _chain.ready[gin.data_ptr()] = ginb
+            if prev.deposit is None:
+                _chain.pending += 1
+            prev.deposit = (ginb, gin, gin._version)
         else:
             gin, _, dg1, dbeta1, _ = layernorm_bwd_sunk(dxn1, x0, g1, mean1, rstd1, n1w, n1b, dres=gmid)
         return (gin.reshape(B, N, D), dg1, dbeta1, dWqkv, dqb, dvb, dWp, dbp, dg2, dbeta2, dW1, db1, dW2, db2, None, None, None, None,
-                None)
+                None, None, None)
 
 
 # --------------------------------------------------------------------------- plain Linear (f32 rows in / out)

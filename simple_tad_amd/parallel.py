@@ -103,10 +103,14 @@ class ShardSampler:
 class DataParallel(nn.Module):
     """Replicated-model data parallelism with bucketed, overlapped gradient all-reduce."""
 
-    def __init__(self, module: nn.Module, bucket_mb: float = 64.0, process_group=None, broadcast: bool = True):
+    def __init__(self, module: nn.Module, bucket_mb: float = 64.0, process_group=None, broadcast: bool = True, overlap: bool = True):
+        """``overlap=False``: exchange every bucket in ``finish()`` after backward instead of as soon as its last gradient lands --
+        required for models that use a parameter more than once per backward (weight tying, a module called twice per forward):
+        the overlapped exchange announces a parameter after its FIRST gradient write and raises if it sees a second one."""
         super().__init__()
         self.module = module
         self.pg = process_group
+        self.overlap = bool(overlap)
         self.world = dist.get_world_size(self.pg) if dist.is_initialized() else 1
         params = [p for p in module.parameters() if p.requires_grad]
         assert params, "no trainable parameters"
@@ -153,15 +157,26 @@ class DataParallel(nn.Module):
         # orders its kernels after the current stream itself.
         self._drain_first = bool(dist.is_initialized() and dist.get_backend(self.pg) == "gloo" and self.flat_grad.is_cuda)
         self._announced = set()
+        self._sunk = set()
         self._works = []
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in order]
-        self.space.install_sinks(self._on_grad)  # GPU: dW GEMMs accumulate in place and call _on_grad themselves
+        self.space.install_sinks(self._on_sink)  # GPU: dW GEMMs accumulate in place and announce the parameter themselves
         self.require_sync = True
+
+    def _on_sink(self, p):
+        """called by the kernel-side gradient sinks (ops.linear_dw / layernorm_bwd_sunk) right after an in-place write into p.grad"""
+        if self.world > 1 and self.require_sync and self.overlap:
+            if id(p) in self._sunk:
+                raise RuntimeError("DataParallel: a parameter received a second gradient write in one backward pass after its bucket "
+                                   "had been announced (weight tying / a module used twice per forward); build DataParallel with "
+                                   "overlap=False for such models")
+            self._sunk.add(id(p))
+        self._on_grad(p)
 
     # -- hook: runs on the autograd thread right after p.grad has been accumulated
     def _on_grad(self, p):
         self.space.rehome_grad(p)  # someone called optimizer.zero_grad(set_to_none=True): autograd allocated a fresh tensor
-        if self.world == 1 or not self.require_sync:
+        if self.world == 1 or not self.require_sync or not self.overlap:
             return
         # A parameter can be announced twice in one backward pass: by the kernel-side gradient sink (ops.linear_dw /
         # layernorm_bwd_sunk, right after the in-place write) and again by autograd's post-accumulate hook, which torch also runs
@@ -189,8 +204,11 @@ class DataParallel(nn.Module):
             w.wait()
         self._works.clear()
         self._announced.clear()
+        self._sunk.clear()
+        if self.world == 1 or not self.require_sync:
+            return
         for b in self.buckets:  # a parameter that received no gradient this step leaves its bucket incomplete
-            if b["ready"]:
+            if b["ready"] or not self.overlap:
                 b["ready"] = 0
                 view = self.flat_grad[b["lo"]:b["hi"]]
                 view.div_(self.world)
@@ -199,9 +217,13 @@ class DataParallel(nn.Module):
                 dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg)
 
     def zero_grad(self, set_to_none: bool = False):
-        """Gradients are views into the flat buffer and must stay allocated: zero in place."""
+        """Gradients are views into the flat buffer and must stay allocated: zero in place.  Difference from the reference's
+        ``optimizer.zero_grad()`` (set_to_none): a parameter that receives no gradient in a step keeps a ZERO gradient here, so AdamW
+        still decays it and advances its moments, where torch skips a ``None`` gradient.  Every parameter of the hot-path models
+        receives a gradient in every step, so the trajectories agree (tests/test_optim_gpu.py covers the None case of FusedAdamW)."""
         self.flat_grad.zero_()
         self._announced.clear()
+        self._sunk.clear()
 
     def grad_sumsq_buffer(self):
         return self.flat_grad

@@ -95,6 +95,11 @@ def test_model_on_uint8_frames_and_sliding_window():
             if swe.full:
                 want.append(swe.predict())
     assert len(got) == 13 and len(swg._graphs) == 4 and all(torch.equal(a, b) for a, b in zip(got, want))
+    # the graphs follow the weights: an in-place update drops them (the old bf16 weight copies were baked in by address)
+    with torch.no_grad():
+        m.head.weight.mul_(2.0)
+        m.blocks[0].mlp.fc1.weight.mul_(1.5)
+    assert torch.equal(swg.predict(), swe.predict()) and len(swg._graphs) == 1 and not torch.equal(swg.predict(), got[-1])
     with pytest.raises(TypeError):
         sw.push(np.zeros((16, 16, 3), np.uint8))
     # training from uint8 clips (the loaders' [T,H,W,C] RGB buffers, dota.py:312): gradients equal the float path's

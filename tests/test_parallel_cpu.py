@@ -79,7 +79,21 @@ def _worker(rank, world, port, q):
     (crit(dp(xs[0]), ys[0])).backward()
     dp.finish()
     rehomed = all(p.grad.data_ptr() == dp.space.grad_view(p).data_ptr() for p in model.parameters())
-    q.put((rank, err, same_views, rehomed, float(local_after_first.abs().sum()) > 0))
+    # C4: epoch meters averaged over the ranks in one fp64 all-reduce (utils.py:71-82); None entries are skipped
+    avg = E.synchronize_meters({"loss": [1.0 + rank, 3.0 + rank], "grad_norm": [None, 2.0 * (rank + 1)], "lr": [0.5, 0.5]})
+    meters_ok = avg == {"loss": 2.5, "grad_norm": 3.0, "lr": 0.5}
+    # overlap=False: every bucket is exchanged in finish() (the mode for models that use a parameter twice per backward)
+    m2 = _make_model(seed=100)
+    dp2 = DataParallel(m2, bucket_mb=0.004, overlap=False)
+    dp2.zero_grad()
+    crit(dp2(xs[0]), ys[0]).backward()
+    assert not dp2._works
+    pre = dp2.flat_grad.clone()
+    dp2.finish()
+    allp = [torch.zeros_like(pre) for _ in range(world)]
+    dist.all_gather(allp, pre)
+    late_ok = (dp2.flat_grad - torch.stack(allp).mean(0)).abs().max().item() < 1e-6
+    q.put((rank, err, same_views, rehomed, float(local_after_first.abs().sum()) > 0 and meters_ok and late_ok))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -32,14 +32,21 @@ def _data():
     return torch.randn(8, 3, 4, 32, 32, generator=g), torch.randint(0, 2, (8,), generator=g)
 
 
-def _worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
-                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _worker(rank, world, port, q, backend="gloo"):
+    """backend "gloo": both ranks on cuda:0 (one-GPU box); "nccl": one GPU per rank, RCCL over xGMI -- the production transport,
+    through parallel.init_distributed_mode exactly as bench.py / a training script enters it"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank if backend == "nccl" else 0), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
     import torch.nn.functional as F
     from simple_tad_amd import engine as E
-    from simple_tad_amd.parallel import DataParallel
-    dist.init_process_group(backend="gloo", init_method="env://", world_size=world, rank=rank)
+    from simple_tad_amd.parallel import DataParallel, init_distributed_mode
+    if backend == "nccl":
+        ok, r, w, local = init_distributed_mode()
+        assert ok and r == rank and w == world and local == rank and dist.get_backend() == "nccl"
+        torch.cuda.set_device(local)
+    else:
+        dist.init_process_group(backend="gloo", init_method="env://", world_size=world, rank=rank)
     try:
         m = _model(seed=100 + rank).cuda()           # different init per rank: the broadcast must make them identical
         dp = DataParallel(m, bucket_mb=0.25)          # several buckets
@@ -63,13 +70,41 @@ def _worker(rank, world, port, q):
 
 
 def test_two_ranks_on_one_gpu_match_single_process_step():
+    _two_rank_step("gloo")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank (this box has one); runs on multi-GPU nodes")
+def test_two_ranks_over_rccl_match_single_process_step():
+    """the `backend == "nccl"` branch of init_distributed_mode and DataParallel's stream-ordering assumption (RCCL orders its kernels
+    after the current stream), on the real transport"""
+    _two_rank_step("nccl")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs")
+def test_bench_self_launch_two_gpus_over_rccl():
+    """`python bench.py --gpus 2` with no launcher: one rank-0 JSON line, n_gpus = the RCCL-reported world size"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "8"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stderr[-3000:])
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["collective"]["backend"] == "nccl" and out["collective"]["world_size"] == 2
+    assert out["config"]["global_batch"] == 16 and out["value"] > 0 and out["scaling"] == "weak"
+
+
+def _two_rank_step(backend):
     import torch.nn.functional as F
     from simple_tad_amd import engine as E
     from simple_tad_amd.parallel import DataParallel
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, backend)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])

@@ -184,7 +184,7 @@ def test_gradient_sinks_write_the_same_gradients_in_place():
 
 def test_block_chain_handoff_is_bit_identical_and_taken():
     """Block i+1's LayerNorm backward emits the bf16, drop-path-scaled copy of the residual-stream gradient that block i's backward
-    starts from (ops._BlockChain): same gradients bit for bit as the separate cast pass, and the hand-off is actually used."""
+    starts from (ops._ChainLink): same gradients bit for bit as the separate cast pass, and the hand-off is actually used."""
     from simple_tad_amd import ops
     m = _model(128, 2, depth=3, drop_path_rate=0.3).cuda().train()
     x = torch.randn(4, 3, 4, 32, 32).cuda()
@@ -199,11 +199,65 @@ def test_block_chain_handoff_is_bit_identical_and_taken():
             F.cross_entropy(m(x), y).backward()
             grads[on] = {k: p.grad.clone() for k, p in m.named_parameters()}
             assert ops._chain.hits == (2 if on else 0)  # blocks 0 and 1 take the copy made by blocks 1 and 2
-            assert not ops._chain.ready
+            assert ops._chain.pending == 0
     finally:
         ops.set_block_chain(True)
     for k in grads[True]:
         assert torch.equal(grads[True][k], grads[False][k]), k
+
+
+def test_block_chain_with_second_consumer_and_across_iterations():
+    """(1) a block output with a second consumer (auxiliary loss on an intermediate feature map): autograd sums the two
+    gradients, so the bf16 copy made by the next block's LayerNorm backward must NOT be taken -- gradients equal the chain-off run bit
+    for bit; (2) several iterations through the MAE model (which never called the old reset) leave no deposit behind and take
+    the hand-off in every encoder / decoder block pair."""
+    from simple_tad_amd import ops
+    import simple_tad_amd.modeling_pretrain as mp
+    m = _model(128, 2, depth=3, drop_path_rate=0.0).cuda().train()
+    x = torch.randn(2, 3, 4, 32, 32).cuda()
+    grads = {}
+    try:
+        for on in (False, True):
+            ops.set_block_chain(on)
+            ops._chain.hits = 0
+            m.zero_grad(set_to_none=True)
+            t = m.patch_embed(x, pos_embed=m._pos_on(x.device))
+            mids = []
+            for blk in m.blocks:
+                t = blk(t)
+                mids.append(t)
+            (t.mean() + 3.0 * mids[0].square().mean() + 2.0 * mids[1].abs().mean()).backward()
+            grads[on] = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+            assert ops._chain.hits == 0 and ops._chain.pending == 0   # both hand-offs are invalidated by the second consumers
+    finally:
+        ops.set_block_chain(True)
+    for k in grads[True]:
+        assert torch.equal(grads[True][k], grads[False][k]), k
+    pm = mp.PretrainVisionTransformer(img_size=32, patch_size=16, encoder_embed_dim=128, encoder_depth=3, encoder_num_heads=2,
+                                      decoder_num_classes=1536, decoder_embed_dim=64, decoder_depth=2, decoder_num_heads=1, mlp_ratio=4,
+                                      qkv_bias=True, init_values=0., tubelet_size=2).cuda().train()
+    clip = torch.randn(2, 3, 16, 32, 32).cuda()
+    mask = torch.zeros(2, 32, dtype=torch.bool)
+    mask[:, [1, 2, 3, 5, 6, 7, 9, 10, 11, 13, 14, 15, 17, 18, 19, 21, 22, 23, 25, 26, 27, 29, 30, 31]] = True
+    for it in range(3):
+        ops._chain.hits = 0
+        pm.zero_grad(set_to_none=True)
+        pm(clip, mask.cuda()).square().mean().backward()
+        assert ops._chain.hits == 2 + 1 and ops._chain.pending == 0, (it, ops._chain.hits, ops._chain.pending)
+
+
+def test_learnable_pos_embed_is_added_detached_as_in_the_reference():
+    """modeling_finetune.py:312-313 adds ``pos_embed.expand(...).clone().detach()``: the learnable table shapes the output but never
+    receives a gradient (so AdamW leaves it alone)."""
+    m = _model(128, 2, depth=1, use_learnable_pos_emb=True).cuda().train()
+    assert isinstance(m.pos_embed, torch.nn.Parameter) and float(m.pos_embed.abs().max()) > 0
+    x = torch.randn(2, 3, 4, 32, 32).cuda()
+    y0 = m.forward_features(x)
+    y0.sum().backward()
+    assert m.pos_embed.grad is None and m.patch_embed.proj.weight.grad is not None
+    with torch.no_grad():
+        m.pos_embed.add_(0.5)
+    assert (m.forward_features(x) - y0).abs().max() > 1e-3   # the table does take part in the forward
 
 
 def test_no_grad_forward_reuses_weight_copies_and_keeps_nothing_for_backward():
