@@ -66,6 +66,11 @@ int tad_transpose_cast_f32_bf16(const float* src /*[R,C]*/, uint16_t* dst /*[C,R
  * x [B,C,T,H,W] f32 contiguous.  cols [B*N, C*tub*p*p] bf16 is the tubelet patch matrix
  * (token n = t'*H'*W' + h'*W' + w', k = ((c*tub+kt)*p+kh)*p+kw) -- kept for backward.
  * w_bf16 [D,K], bias [D] f32 (nullable), pos [N,D] f32 (nullable), out [B*N,D] f32. */
+/* Row stride (elements) of the patch matrix and of the bf16 weight the patch-embed GEMM reads: K = C*tubelet*patch^2 rounded up to
+ * the GEMM's K-tile of 64.  Equal to K for patch sizes that are multiples of 8 (/16: 1536); for even patch sizes that are not
+ * (ViT-L/14: K = 1176 -> 1216) tad_im2col_tubelets writes rows of that stride with zeros in the padding columns and the caller
+ * passes a zero-padded weight [D, ldk] -- the product is the un-padded one exactly, and /14 is a pure configuration change. */
+int tad_patch_embed_ldk(int C, int tubelet, int patch);
 int tad_im2col_tubelets(const float* x, uint16_t* cols, int B, int C, int T, int H, int W, int tubelet,
                         int patch, tad_stream_t stream);
 int tad_patch_embed_fwd(const float* x, const uint16_t* w_bf16, const float* bias, const float* pos,
@@ -267,6 +272,24 @@ int tad_colsum_f32(const float* a, float* out, int64_t M, int N, tad_stream_t st
 
 /* ---- device info ------------------------------------------------------------------------ */
 int tad_device_info(int* cu_count, int* clock_khz, int* lds_bytes_per_cu, char* name, int name_len);
+
+/* ---- gradient exchange over RCCL / xGMI for C hosts --------------------------------------------------------------------------
+ * Replaces, for a host without torch, the two collectives of the reference's data-parallel wrap: DistributedDataParallel's
+ * gradient all-reduce (run_class_finetuning.py:446-448; process group from utils.init_distributed_mode, utils.py:283-333,
+ * backend 'nccl' at :325) and its initial parameter broadcast.  The Python host keeps torch.distributed (whose "nccl" backend is
+ * RCCL on ROCm): parallel.DataParallel.  One communicator per process, one process per GPU; rank 0 creates the 128-byte id with
+ * tad_rccl_unique_id and hands it to the other ranks by any host channel (file, environment, socket); every rank then calls
+ * tad_rccl_init with the device it will use already current (hipSetDevice).  All-reduce and broadcast are in place and ordered on
+ * `stream`; `average` != 0 divides by the number of ranks (ncclAvg).  librccl.so.1 is opened on first use (no link-time
+ * dependency): on a host without it these calls return TAD_ELAUNCH and the rest of the library is unaffected. */
+#define TAD_RCCL_UNIQUE_ID_BYTES 128
+typedef void* tad_comm_t;
+int tad_rccl_unique_id(void* id128);
+int tad_rccl_init(const void* id128, int nranks, int rank, tad_comm_t* comm);
+int tad_rccl_world_size(tad_comm_t comm, int* nranks);
+int tad_rccl_allreduce(tad_comm_t comm, void* buf, size_t count, int dtype, int average, tad_stream_t stream);
+int tad_rccl_broadcast(tad_comm_t comm, void* buf, size_t count, int dtype, int root, tad_stream_t stream);
+int tad_rccl_destroy(tad_comm_t comm);
 
 #ifdef __cplusplus
 }

@@ -19,6 +19,7 @@ SIGNATURES = {
     "tad_last_error_string": (C.c_char_p, []),
     "tad_cast_f32_bf16": (_i, [_vp, _vp, _i64, _vp]),
     "tad_transpose_cast_f32_bf16": (_i, [_vp, _vp, _i, _i, _vp]),
+    "tad_patch_embed_ldk": (_i, [_i, _i, _i]),
     "tad_im2col_tubelets": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "tad_patch_embed_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "tad_im2col_tubelets_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, C.POINTER(_f), C.POINTER(_f), _i, _i, _vp]),
@@ -65,6 +66,12 @@ SIGNATURES = {
     "tad_gelu_bwd_f32": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "tad_colsum_f32": (_i, [_vp, _vp, _i64, _i, _vp]),
     "tad_device_info": (_i, [C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.c_char_p, _i]),
+    "tad_rccl_unique_id": (_i, [_vp]),
+    "tad_rccl_init": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
+    "tad_rccl_world_size": (_i, [_vp, C.POINTER(_i)]),
+    "tad_rccl_allreduce": (_i, [_vp, _vp, _sz, _i, _i, _vp]),
+    "tad_rccl_broadcast": (_i, [_vp, _vp, _sz, _i, _i, _vp]),
+    "tad_rccl_destroy": (_i, [_vp]),
 }
 
 TAD_F32, TAD_BF16 = 0, 1

@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtad_mi355x.so")
-SOURCES = ["capi.hip", "elementwise.hip", "layernorm.hip", "gemm.hip", "attn_fwd.hip", "attn_bwd.hip", "precise.hip", "optim.hip", "mae.hip", "metrics.hip"]
+SOURCES = ["capi.hip", "elementwise.hip", "layernorm.hip", "gemm.hip", "attn_fwd.hip", "attn_bwd.hip", "precise.hip", "optim.hip", "mae.hip", "metrics.hip", "collective.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result",
          # keep MFMA accumulators in the (unified) VGPR file: without it the compiler parks them in AGPRs and pays a
          # v_accvgpr_read/write per element around every softmax / epilogue
@@ -50,7 +50,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

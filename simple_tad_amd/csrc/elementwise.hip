@@ -168,6 +168,43 @@ __global__ void im2col_tubelets_kernel(const float* __restrict__ x, uint16_t* __
   }
 }
 
+// Patch sizes that are even but not a multiple of 8 (ViT-L/14: p = 14, K = 3*2*14*14 = 1176): one thread moves 2 consecutive w.  The
+// patch matrix gets a row stride of ldk = K rounded up to the GEMM's K-tile (64); the thread that owns k = 0 of a token zeroes the
+// ldk - K padding columns of its row, so the padded matrix times a zero-padded weight is the un-padded product exactly.
+template <typename OutT>
+__global__ void im2col_tubelets_pairs_kernel(const float* __restrict__ x, OutT* __restrict__ cols, int B, int C, int T, int H, int W,
+                                             int tub, int p, int ldk) {
+  const int W2 = W >> 1;
+  const int64_t total = (int64_t)B * C * T * H * W2;
+  const int Hp = H / p, Wp = W / p, Tp = T / tub;
+  const int K = C * tub * p * p;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    int64_t r = i;
+    const int w2 = (int)(r % W2); r /= W2;
+    const int h = (int)(r % H); r /= H;
+    const int t = (int)(r % T); r /= T;
+    const int c = (int)(r % C); r /= C;
+    const int b = (int)r;
+    const int w = w2 << 1;
+    const float2 a = reinterpret_cast<const float2*>(x)[i];
+    const int tp = t / tub, kt = t - tp * tub, hp = h / p, kh = h - hp * p, wp = w / p, kw = w - wp * p;
+    const int64_t n = ((int64_t)(b * Tp + tp) * Hp + hp) * Wp + wp;
+    const int k = ((c * tub + kt) * p + kh) * p + kw;
+    OutT* row = cols + n * ldk;
+    if constexpr (sizeof(OutT) == 2) *reinterpret_cast<uint32_t*>(row + k) = pack_bf16x2(a.x, a.y);
+    else *reinterpret_cast<float2*>(row + k) = a;
+    if (k == 0) {
+      for (int z = K; z < ldk; z += 2) {
+        if constexpr (sizeof(OutT) == 2) *reinterpret_cast<uint32_t*>(row + z) = 0u;
+        else *reinterpret_cast<float2*>(row + z) = make_float2(0.f, 0.f);
+      }
+    }
+  }
+}
+template __global__ void im2col_tubelets_pairs_kernel<uint16_t>(const float*, uint16_t*, int, int, int, int, int, int, int, int);
+template __global__ void im2col_tubelets_pairs_kernel<float>(const float*, float*, int, int, int, int, int, int, int, int);
+
 // ---------------------------------------------------------------- mean-pool
 // partial[b][s][D]: block (x = column chunk of 256, y = split s, z = b); 4 waves stride over the rows of the split.
 __global__ void meanpool_partial_kernel(const float* __restrict__ x, float* __restrict__ partial, int N, int D) {
@@ -471,6 +508,16 @@ int launch_reduce_partials(const float* partial, float* out, int splits, int64_t
 
 }  // namespace tad
 
+namespace tad {
+// precise-mode (f32) patch matrix for even patch sizes that are not a multiple of 4; called from precise.hip
+int launch_im2col_pairs_f32(const float* x, float* cols, int B, int C, int T, int H, int W, int tubelet, int patch, int ldk, hipStream_t st) {
+  const int64_t pairs = (int64_t)B * C * T * H * (W / 2);
+  hipLaunchKernelGGL(im2col_tubelets_pairs_kernel<float>, dim3(capped_grid(pairs, 256)), dim3(256), 0, st, x, cols, B, C, T, H, W, tubelet,
+                     patch, ldk);
+  return check_launch("im2col_f32");
+}
+}  // namespace tad
+
 using namespace tad;
 
 extern "C" {
@@ -497,12 +544,23 @@ int tad_transpose_bf16_batched(const uint16_t* src, uint16_t* dst, const int32_t
   return check_launch("transpose_bf16_batched");
 }
 
+int tad_patch_embed_ldk(int C, int tubelet, int patch) {
+  const int K = C * tubelet * patch * patch;
+  return (K + 63) / 64 * 64;
+}
+
 int tad_im2col_tubelets(const float* x, uint16_t* cols, int B, int C, int T, int H, int W, int tubelet, int patch,
                         tad_stream_t stream) {
   TAD_REQUIRE(x && cols, "im2col: null pointer");
   TAD_REQUIRE(B > 0 && C > 0 && tubelet > 0 && patch > 0 && T % tubelet == 0 && H % patch == 0 && W % patch == 0,
               "im2col: T/H/W must be multiples of tubelet/patch (got T=%d H=%d W=%d tub=%d p=%d)", T, H, W, tubelet, patch);
-  TAD_REQUIRE(patch % 8 == 0, "im2col: patch size must be a multiple of 8 (got %d)", patch);
+  TAD_REQUIRE(patch % 2 == 0, "im2col: patch size must be even (got %d)", patch);
+  if (patch % 8) {  // row stride tad_patch_embed_ldk(): see im2col_tubelets_pairs_kernel
+    const int64_t pairs = (int64_t)B * C * T * H * (W / 2);
+    hipLaunchKernelGGL(im2col_tubelets_pairs_kernel<uint16_t>, dim3(capped_grid(pairs, 256)), dim3(256), 0, (hipStream_t)stream, x, cols, B,
+                       C, T, H, W, tubelet, patch, tad_patch_embed_ldk(C, tubelet, patch));
+    return check_launch("im2col_tubelets");
+  }
   const int64_t total = (int64_t)B * C * T * H * (W / 8);
   hipLaunchKernelGGL(im2col_tubelets_kernel, dim3(capped_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, cols, B, C, T,
                      H, W, tubelet, patch);

@@ -1251,7 +1251,7 @@ int tad_patch_embed_fwd(const float* x, const uint16_t* w_bf16, const float* bia
   const int ntok = (T / tubelet) * (H / patch) * (W / patch);
   GemmNT p{};
   p.A = cols; p.B = w_bf16; p.C = out; p.bias = bias; p.c_bf16 = 0;
-  p.M = B * ntok; p.N = D; p.K = C * tubelet * patch * patch;
+  p.M = B * ntok; p.N = D; p.K = tad_patch_embed_ldk(C, tubelet, patch);  // cols / w_bf16 row stride (= K unless the patch is /14-like)
   p.rows_per_scale = 1;
   p.epi = EPI_RESIDUAL;
   p.residual = pos;

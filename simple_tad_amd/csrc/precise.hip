@@ -374,6 +374,9 @@ static inline int grid_for(int64_t items) {
 
 }  // namespace tad
 
+namespace tad {
+int launch_im2col_pairs_f32(const float* x, float* cols, int B, int C, int T, int H, int W, int tubelet, int patch, int ldk, hipStream_t st);
+}
 using namespace tad;
 
 extern "C" {
@@ -386,8 +389,10 @@ int tad_split_bf16x3(const float* x, uint16_t* out, int64_t M, int K, int role_b
 
 int tad_im2col_tubelets_f32(const float* x, float* cols, int B, int C, int T, int H, int W, int tubelet, int patch, tad_stream_t stream) {
   TAD_REQUIRE(x && cols, "im2col_f32: null pointer");
-  TAD_REQUIRE(B > 0 && C > 0 && tubelet > 0 && patch > 0 && T % tubelet == 0 && H % patch == 0 && W % patch == 0 && patch % 4 == 0,
-              "im2col_f32: T/H/W must be multiples of tubelet/patch and patch a multiple of 4");
+  TAD_REQUIRE(B > 0 && C > 0 && tubelet > 0 && patch > 0 && T % tubelet == 0 && H % patch == 0 && W % patch == 0 && patch % 2 == 0,
+              "im2col_f32: T/H/W must be multiples of tubelet/patch and patch even");
+  if (patch % 8)  // same rule as the bf16 patch matrix: row stride tad_patch_embed_ldk(), zero padding (ViT-L/14)
+    return launch_im2col_pairs_f32(x, cols, B, C, T, H, W, tubelet, patch, tad_patch_embed_ldk(C, tubelet, patch), (hipStream_t)stream);
   hipLaunchKernelGGL(im2col_tubelets_f32_kernel, dim3(grid_for((int64_t)B * C * T * H * (W / 4))), dim3(256), 0, (hipStream_t)stream, x,
                      cols, B, C, T, H, W, tubelet, patch);
   return check_launch("im2col_f32");

@@ -185,11 +185,21 @@ def scale_cast_bf16(x, gamma=None, rowscale=None, rows_per_scale=1):
 
 
 # ----------------------------------------------------------------------------- patch embed
+def patch_embed_ldk(C: int, tubelet: int, patch: int) -> int:
+    """row stride of the patch matrix / the bf16 weight (K rounded up to 64; == K for /16)"""
+    return int(_lib.load().tad_patch_embed_ldk(int(C), int(tubelet), int(patch)))
+
+
+def pad_k(w: torch.Tensor, ldk: int) -> torch.Tensor:
+    """[N, K] -> [N, ldk] with zero columns (the weight operand of a patch-embed GEMM whose K is not a multiple of 64)"""
+    return w if w.shape[1] == ldk else torch.nn.functional.pad(w, (0, ldk - w.shape[1]))
+
+
 def im2col_tubelets(x: torch.Tensor, tubelet: int, patch: int) -> torch.Tensor:
     _req(x, torch.float32, "im2col.x")
     B, Cc, T, H, W = x.shape
     ntok = (T // tubelet) * (H // patch) * (W // patch)
-    cols = torch.empty((B * ntok, Cc * tubelet * patch * patch), dtype=torch.bfloat16, device=x.device)
+    cols = torch.empty((B * ntok, patch_embed_ldk(Cc, tubelet, patch)), dtype=torch.bfloat16, device=x.device)
     check(_lib.load().tad_im2col_tubelets(x.data_ptr(), cols.data_ptr(), B, Cc, T, H, W, tubelet, patch, _stream()),
           "tad_im2col_tubelets")
     return cols
@@ -239,8 +249,9 @@ def patch_embed_fwd(x, w_bf16, bias, pos, tubelet: int, patch: int):
     _req(w_bf16, torch.bfloat16, "patch_embed.w")
     B, Cc, T, H, W = x.shape
     D, K = w_bf16.shape
-    if K != Cc * tubelet * patch * patch:
-        raise _lib.TadError(f"patch_embed: weight K={K} does not match C*tub*p*p={Cc * tubelet * patch * patch}")
+    if K != patch_embed_ldk(Cc, tubelet, patch):
+        raise _lib.TadError(f"patch_embed: weight row stride {K} does not match tad_patch_embed_ldk = {patch_embed_ldk(Cc, tubelet, patch)} "
+                            f"(C*tub*p*p = {Cc * tubelet * patch * patch} rounded up to 64; kernels.pad_k)")
     ntok = (T // tubelet) * (H // patch) * (W // patch)
     if pos is not None:
         _req(pos, torch.float32, "patch_embed.pos")
@@ -612,7 +623,7 @@ def im2col_tubelets_f32(x, tubelet: int, patch: int):
     _req(x, torch.float32, "im2col_f32.x")
     B, Cc, T, H, W = x.shape
     ntok = (T // tubelet) * (H // patch) * (W // patch)
-    cols = torch.empty((B * ntok, Cc * tubelet * patch * patch), dtype=torch.float32, device=x.device)
+    cols = torch.empty((B * ntok, patch_embed_ldk(Cc, tubelet, patch)), dtype=torch.float32, device=x.device)
     check(_lib.load().tad_im2col_tubelets_f32(x.data_ptr(), cols.data_ptr(), B, Cc, T, H, W, tubelet, patch, _stream()),
           "tad_im2col_tubelets_f32")
     return cols

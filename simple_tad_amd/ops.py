@@ -312,7 +312,10 @@ class PatchEmbedFn(_Fn):
     def forward(ctx, x, weight, bias, pos, tubelet, patch):
         _need_gpu(x, "PatchEmbed")
         xc = _f32c(x)
-        out, cols = K.patch_embed_fwd(xc, w_bf16(weight, _differentiated(ctx)), _f32c(bias), _f32c(pos), tubelet, patch)
+        # patch sizes whose K = C*tub*p*p is not a multiple of 64 (ViT-L/14: 1176): the patch matrix and the weight operand carry zero
+        # columns up to tad_patch_embed_ldk (1216); a pure configuration change for the callers
+        ldk = K.patch_embed_ldk(xc.shape[1], tubelet, patch)
+        out, cols = K.patch_embed_fwd(xc, K.pad_k(w_bf16(weight, _differentiated(ctx)), ldk), _f32c(bias), _f32c(pos), tubelet, patch)
         ctx.save_for_backward(cols)
         ctx.params = (weight, bias)
         return out
@@ -323,6 +326,10 @@ class PatchEmbedFn(_Fn):
         weight, bias = ctx.params
         D = dy.shape[-1]
         dyb = K.cast_bf16(_f32c(dy).reshape(-1, D))
+        kw = weight.numel() // weight.shape[0]
+        if cols.shape[1] != kw:  # padded K: the gradient of the padding columns is dropped (no in-place sink for a [D, ldk] result)
+            dWp, db = K.linear_bwd_weight(dyb, cols, want_bias=bias is not None)
+            return None, dWp[:, :kw].reshape(weight.shape), db, None, None, None
         dW, db = linear_dw(dyb, cols, weight, bias)
         return None, (None if dW is None else dW.reshape(weight.shape)), db, None, None, None
 
@@ -724,7 +731,10 @@ class PrecisePatchEmbedFn(_Fn):
         cols = K.im2col_tubelets_f32(_f32c(x), tubelet, patch)
         ntok = cols.shape[0] // B
         res = _f32c(pos).repeat(B, 1) if pos is not None else None
-        y, _ = K.linear_fwd(K.split_bf16x3(cols, role_b=False), _cached_split(weight, _differentiated(ctx)), _f32c(bias),
+        kw = weight.numel() // weight.shape[0]
+        ws = (_cached_split(weight, _differentiated(ctx)) if cols.shape[1] == kw
+              else K.split_bf16x3(K.pad_k(_w2d(weight), cols.shape[1]).contiguous(), role_b=True))  # zero-padded K (patch 14)
+        y, _ = K.linear_fwd(K.split_bf16x3(cols, role_b=False), ws, _f32c(bias),
                             out_dtype=torch.float32, epilogue=EPI_BIAS_RESIDUAL if res is not None else EPI_BIAS, residual=res)
         ctx.save_for_backward(cols)
         ctx.wshape = weight.shape
@@ -735,4 +745,7 @@ class PrecisePatchEmbedFn(_Fn):
     def backward(ctx, dy):
         (cols,) = ctx.saved_tensors
         dW, db = precise_dw(_f32c(dy).reshape(-1, dy.shape[-1]), cols, want_bias=ctx.has_bias)
-        return None, dW.reshape(ctx.wshape), db, None, None, None
+        kw = 1
+        for d in ctx.wshape[1:]:
+            kw *= d
+        return None, dW[:, :kw].reshape(ctx.wshape), db, None, None, None

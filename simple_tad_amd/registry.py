@@ -15,17 +15,14 @@ _REGISTRY: Dict[str, Callable] = {}
 
 try:  # pragma: no cover - timm is not installed in the build image
     from timm.models.registry import register_model as _timm_register
-except Exception:  # noqa: BLE001
+except ImportError:
     _timm_register = None
 
 
 def register_model(fn: Callable) -> Callable:
     _REGISTRY[fn.__name__] = fn
     if _timm_register is not None:  # pragma: no cover
-        try:
-            _timm_register(fn)
-        except Exception:  # noqa: BLE001
-            pass
+        _timm_register(fn)  # an error here is a real incompatibility with the installed timm: let it surface
     return fn
 
 

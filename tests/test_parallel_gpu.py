@@ -141,3 +141,65 @@ def _two_rank_step(backend):
     for k, v in m.state_dict().items():
         d = (w10[k] - w00[k]).norm()
         assert ((w10[k] - v.cpu()).norm() <= 1e-3 * d + 1e-7), k   # same update
+
+
+# ------------------------------------------------------------------ RCCL through the C ABI (tad_rccl_*: the route of a host without torch)
+def _rccl_rank(rank, world, idbytes, q):
+    import ctypes as C
+    from simple_tad_amd import _lib
+    from simple_tad_amd._lib import TAD_BF16, TAD_F32, check
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    torch.cuda.set_device(rank)
+    lib = _lib.load()
+    comm = C.c_void_p()
+    check(lib.tad_rccl_init(idbytes, world, rank, C.byref(comm)), "tad_rccl_init")
+    n = C.c_int()
+    check(lib.tad_rccl_world_size(comm, C.byref(n)), "tad_rccl_world_size")
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(11)
+    parts = [torch.randn(1 << 20, generator=g) for _ in range(world)]          # every rank knows every rank's contribution
+    x = parts[rank].cuda()
+    check(lib.tad_rccl_allreduce(comm, x.data_ptr(), x.numel(), TAD_F32, 1, st), "tad_rccl_allreduce")      # average, in place
+    xb = parts[rank].cuda().bfloat16()
+    check(lib.tad_rccl_allreduce(comm, xb.data_ptr(), xb.numel(), TAD_BF16, 0, st), "tad_rccl_allreduce")   # sum, bf16
+    w = (parts[0] if rank == 0 else torch.zeros(1 << 20)).cuda()
+    check(lib.tad_rccl_broadcast(comm, w.data_ptr(), w.numel(), TAD_F32, 0, st), "tad_rccl_broadcast")
+    torch.cuda.synchronize()
+    mean = torch.stack(parts).mean(0)
+    ssum = torch.stack([p.bfloat16().float() for p in parts]).sum(0)
+    ok = (n.value == world and (x.cpu() - mean).abs().max().item() < 1e-6 and torch.equal(w.cpu(), parts[0])
+          and (xb.float().cpu() - ssum).abs().max().item() <= 2.0 ** -7 * ssum.abs().max().item())
+    assert lib.tad_rccl_allreduce(comm, x.data_ptr(), x.numel(), 7, 0, st) == -1  # bad dtype: refused on the host
+    check(lib.tad_rccl_destroy(comm), "tad_rccl_destroy")
+    if q is not None:
+        q.put((rank, ok))
+    return ok
+
+
+def _rccl_unique_id():
+    import ctypes as C
+    from simple_tad_amd import _lib
+    buf = C.create_string_buffer(128)
+    _lib.check(_lib.load().tad_rccl_unique_id(buf), "tad_rccl_unique_id")
+    return buf.raw
+
+
+def test_rccl_c_abi_single_rank():
+    """communicator of one rank on cuda:0: all-reduce (average / sum, f32 / bf16) and broadcast are identities, the calls are
+    ordered on the caller's stream, errors come back as codes"""
+    assert _rccl_rank(0, 1, _rccl_unique_id(), None)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank")
+def test_rccl_c_abi_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    idb = _rccl_unique_id()
+    procs = [ctx.Process(target=_rccl_rank, args=(r, 2, idb, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)
