@@ -442,6 +442,7 @@ extern "C" int tad_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint
   TAD_REQUIRE(B > 0 && N > 0 && H > 0 && H <= 65535 && B <= 65535, "attn_bwd: bad shape");
   TAD_REQUIRE(scale > 0.f, "attn_bwd: scale must be positive");
   TAD_REQUIRE((int64_t)B * H * N * 8 < (1ll << 31), "attn_bwd: B*H*N too large for the row-constant descriptor");
+  TAD_REQUIRE((int64_t)B * N * 3 * H * BHD * 2 < (1ll << 32), "attn_bwd: qkv exceeds the 4 GiB buffer descriptor (B=%d N=%d H=%d)", B, N, H);
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)(((N + 127) / 128) * H * B)), block(256);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, block, 0, st, qkv, out, dout, lse, delta, dqkv, N, H, B, scale);

@@ -247,6 +247,10 @@ extern "C" int tad_attn_fwd(const uint16_t* qkv, void* out, int out_dtype, float
   TAD_REQUIRE(B > 0 && N > 0 && H > 0 && H <= 65535 && B <= 65535, "attn_fwd: bad shape B=%d N=%d H=%d", B, N, H);
   TAD_REQUIRE(out_dtype == TAD_F32 || out_dtype == TAD_BF16, "attn_fwd: bad out_dtype %d", out_dtype);
   TAD_REQUIRE(scale > 0.f, "attn_fwd: scale must be positive");
+  // the kernel addresses qkv through ONE buffer descriptor with 32-bit byte offsets (K/V staging by LDS-DMA)
+  TAD_REQUIRE((int64_t)B * N * 3 * H * HD * 2 < (1ll << 32), "attn_fwd: qkv of %lld bytes exceeds the 4 GiB buffer descriptor (B=%d N=%d H=%d)",
+              (long long)B * N * 3 * H * HD * 2, B, N, H);
+  TAD_REQUIRE((int64_t)((N + Q_BLOCK - 1) / Q_BLOCK) * H * B < (1ll << 31), "attn_fwd: grid too large");
   const dim3 grid((unsigned)(((N + Q_BLOCK - 1) / Q_BLOCK) * H * B)), block(256);
   if (out_dtype == TAD_BF16)
     hipLaunchKernelGGL((attn_fwd_kernel<true>), grid, block, 0, (hipStream_t)stream, qkv, out, lse, N, H, B, scale);

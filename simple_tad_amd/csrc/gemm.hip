@@ -1024,8 +1024,29 @@ int launch_gemm_nt(const GemmNT& p_in, hipStream_t st) {
   if (!(p.M > 0 && p.N > 0 && p.K > 0)) { set_error("gemm_nt: empty problem"); return TAD_EINVAL; }
   if (p.K % BK) { set_error("gemm_nt: K=%d must be a multiple of %d", p.K, BK); return TAD_EINVAL; }
   if (p.N % 4) { set_error("gemm_nt: N=%d must be a multiple of 4", p.N); return TAD_EINVAL; }
-  if ((int64_t)p.M * p.K * 2 >= (1ll << 32) || (int64_t)p.N * p.K * 2 >= (1ll << 32)) { set_error("gemm_nt: operand exceeds 4 GiB"); return TAD_EINVAL; }
-  if ((int64_t)(p.M + 256) * p.N * 4 >= (1ll << 31)) { set_error("gemm_nt: output exceeds 2 GiB (f32) / 2^29 elements"); return TAD_EINVAL; }
+  if ((int64_t)p.N * p.K * 2 >= (1ll << 32)) { set_error("gemm_nt: weight operand exceeds 4 GiB"); return TAD_EINVAL; }
+  // The kernel addresses A through a buffer descriptor with 32-bit byte offsets (< 4 GiB), and C -- with the residual / pre-activation
+  // operands, which have C's shape -- through descriptors whose out-of-range lanes get offset 0x80000000, so every real offset,
+  // including the rows of the last, partly filled tile, must stay below 2^31: (M + 256) * N * element size < 2 GiB with the element
+  // size of the widest operand the epilogue touches (4 for an f32 output or an f32 residual, else 2).  Rows are independent, so a
+  // taller problem runs as row ranges that fit (ViT-B fc1, N = 3072 bf16: 222 clips of 1568 tokens per range; the f32 cap used to
+  // apply to bf16 outputs too and refused B > 111).
+  {
+    const int64_t esz = (p.c_bf16 && !p.residual) ? 2 : 4;
+    int64_t max_rows = ((1ll << 31) - 1) / ((int64_t)p.N * esz) - 256;
+    const int64_t a_rows = ((1ll << 32) - 1) / ((int64_t)p.K * 2);
+    if (a_rows < max_rows) max_rows = a_rows;
+    max_rows = max_rows / 256 * 256;
+    if (max_rows <= 0) { set_error("gemm_nt: N=%d / K=%d too wide for the 32-bit operand offsets", p.N, p.K); return TAD_EINVAL; }
+    if (p.M > max_rows) {
+      for (int64_t r0 = 0; r0 < p.M; r0 += max_rows) {
+        const int rows = (int)((p.M - r0) < max_rows ? (p.M - r0) : max_rows);
+        const int rc = launch_gemm_nt(row_range(p, (int)r0, rows), st);
+        if (rc) return rc;
+      }
+      return TAD_OK;
+    }
+  }
   static const int forced = env_int("TAD_GEMM_NT_VARIANT");
   static const int debug = env_int("TAD_GEMM_DEBUG");
   p.debug = debug;
