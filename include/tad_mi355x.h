@@ -170,6 +170,10 @@ int tad_attn_fwd(const uint16_t* qkv, void* out, int out_dtype, float* lse, int 
  * first kernel leaves -rowsum(dout*out) in [0, BHN) and -lse/scale in [BHN, 2 BHN) for the second one, which takes them as the
  * initial values of its accumulators). */
 size_t tad_attn_bwd_scratch_bytes(int B, int N, int H);
+/* Diagnostic, ablation builds only (see tad_linear_debug_stamps): while buf (device memory, 32 bytes per workgroup of the dK/dV grid
+ * = ceil(N/128)*H*B workgroups) is set, every dK/dV workgroup records {s_memrealtime, s_memtime} at the start and at the end of its
+ * tile loop: (d memtime / d memrealtime) x 100 MHz = the clock held inside the loop.  NULL switches it off. */
+int tad_attn_debug_stamps(void* buf);
 int tad_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* lse,
                  uint16_t* dqkv, float* delta, int B, int N, int H, int d, float scale,
                  tad_stream_t stream);

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
 // ------------------------------------------------------------------------------------------------ dK, dV
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
                                                            const float* __restrict__ rowc_g, uint16_t* __restrict__ dqkv, int N, int H, int B,
-                                                           float scale) {
+                                                           float scale, unsigned long long* stamps) {
   constexpr int TILE_BYTES = 64 * 128;
   constexpr int STAGE = 2 * TILE_BYTES + 512;  // Q tile, dO tile, 64 x (-lse/scale), 64 x (-delta)
   __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
@@ -333,6 +333,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
   LOAD_QDO(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+#ifdef TAD_GEMM_ABLATION  // diagnostic builds only (tad_attn_debug_stamps): shader clock / 100 MHz clock around the tile loop
+  if (stamps && tid == 0) {
+    stamps[(size_t)blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+    stamps[(size_t)blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
+  }
+#endif
   for (int t = 0; t < nt; ++t) {
     if (t + 1 < nt) LOAD_QDO((t + 1) & 1, (t + 1) * 64);
     const uint32_t so = (uint32_t)((t & 1) * STAGE);
@@ -407,6 +413,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
     __syncthreads();
   }
 
+#ifdef TAD_GEMM_ABLATION
+  if (stamps && tid == 0) {
+    stamps[(size_t)blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+    stamps[(size_t)blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime();
+  }
+#endif
   if (kvalid) {
     uint16_t* okp = dqkv + ((int64_t)b * N + krow) * tok + (int64_t)H * BHD + head * BHD;
     uint16_t* ovp = okp + (int64_t)H * BHD;
@@ -430,6 +442,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
 
 using namespace tad;
 
+static unsigned long long* g_attn_stamps = nullptr;
+
+// Diagnostic (ablation builds only, like tad_linear_debug_stamps): while buf (device memory, 32 bytes per workgroup of the dK/dV grid)
+// is set, workgroup w records {s_memrealtime, s_memtime} at the start and at the end of its tile loop in buf[4w .. 4w+3].
+extern "C" int tad_attn_debug_stamps(void* buf) {
+#ifndef TAD_GEMM_ABLATION
+  if (buf) { set_error("attn_debug_stamps: needs an ablation build (TAD_BUILD_ABLATION=1 python -m simple_tad_amd.build --force)"); return TAD_EINVAL; }
+#endif
+  g_attn_stamps = (unsigned long long*)buf;
+  return TAD_OK;
+}
+
 extern "C" size_t tad_attn_bwd_scratch_bytes(int B, int N, int H) {
   if (B <= 0 || N <= 0 || H <= 0) return 0;
   return (size_t)2 * B * H * N * sizeof(float);
@@ -448,6 +472,6 @@ extern "C" int tad_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint
   hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, block, 0, st, qkv, out, dout, lse, delta, dqkv, N, H, B, scale);
   int rc = check_launch("attn_bwd_dq");
   if (rc) return rc;
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, block, 0, st, qkv, dout, delta, dqkv, N, H, B, scale);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, block, 0, st, qkv, dout, delta, dqkv, N, H, B, scale, g_attn_stamps);
   return check_launch("attn_bwd_dkv");
 }

@@ -62,6 +62,7 @@ struct GemmNT {
   int M, N, K;
   int debug;  // ablation (TAD_GEMM_DEBUG, timing only, wrong results): 1 = no DMA inside the K loop, 2 = no MFMA, 4 = no epilogue,
               // 8 = (gemm_tn) no fragment reads and no MFMA: staging and barriers only, 16 = (gemm_tn) unswizzled DMA source
+  int group_m;        // tile raster: row panels swept per column panel before moving to the next column panel (L2 reuse)
   int stagger_ticks;  // persistent kernel: span (10 ns ticks of s_memrealtime) over which the workgroups of an XCD spread their start
   int stagger_group;  // workgroups of an XCD start in groups of this many (power of two)
   int* sched;        // persistent kernel: 8 tile counters (one per XCD) of this launch, or null = fixed tile lists
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
   // Optional staggered starts (stagger_ticks > 0: workgroup j of an XCD waits j / step of a K-loop time before its first tile, so the
   // store bursts of the epilogues spread over the K loops of the other CUs) were measured NOT to shorten the epilogues -- their own
   // LDS / VALU time, not HBM contention, is what is left -- and default to off (profiles/README.md).
-  constexpr int GROUP_M = 8;
+  const int GROUP_M = p.group_m;  // row panels per column-panel group (launch_nt_variant; tad_linear_tuning("group_m"))
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
   const int per_group = GROUP_M * tiles_n;
@@ -291,8 +292,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
 #endif
   bool first_tile = true;
 #ifdef TAD_GEMM_ABLATION
-#define STAMP(k) \
-  if (p.stamps && tid == 0 && stamp_i < 64) p.stamps[((size_t)blockIdx.x * 64 + stamp_i) * 32 + (k)] = __builtin_amdgcn_s_memrealtime()
+// slots 0..15: s_memrealtime (100 MHz) per event; slots 16 + k (k = 0, 1): s_memtime (shader clock) at tile start / K-loop end, so that
+// (d memtime / d memrealtime) x 100 MHz is the clock the chip holds INSIDE the K loop (MI355X_MICROARCH.md, DVFS item 6)
+#define STAMP(k)                                                                                          \
+  if (p.stamps && tid == 0 && stamp_i < 64) {                                                             \
+    p.stamps[((size_t)blockIdx.x * 64 + stamp_i) * 32 + (k)] = __builtin_amdgcn_s_memrealtime();          \
+    if ((k) < 2) p.stamps[((size_t)blockIdx.x * 64 + stamp_i) * 32 + 16 + (k)] = __builtin_amdgcn_s_memtime(); \
+  }
 #else
 #define STAMP(k) (void)0  // timeline stamps (tad_linear_debug_stamps) exist in ablation builds only
 #endif
@@ -878,6 +884,16 @@ static int g_nt_stagger_group = getenv("TAD_GEMM_STAGGER_GROUP") ? env_int("TAD_
 static int g_nt_direct = getenv("TAD_GEMM_DIRECT_EPI") ? env_int("TAD_GEMM_DIRECT_EPI") : 1;
 static int g_nt_split = getenv("TAD_GEMM_SPLIT_TAIL") ? env_int("TAD_GEMM_SPLIT_TAIL") : 1;
 static int g_nt_dynamic = getenv("TAD_GEMM_DYNAMIC") ? env_int("TAD_GEMM_DYNAMIC") : 0;  // measured: +7 % gemm_nt time in the full step
+static int g_nt_group_m = getenv("TAD_GEMM_GROUP_M") ? env_int("TAD_GEMM_GROUP_M") : 0;  // 0 = per-shape choice (nt_group_m)
+
+// Row panels per column-panel group of the tile raster.  The ~32 workgroups resident on an XCD (private 4 MiB L2) walk consecutive
+// tile ids, so at any time they touch GROUP_M A-panels and ~32 / GROUP_M W-panels; each panel streams K-tile by K-tile, and a
+// panel's K-tile is fetched from beyond L2 once per group of tiles that share it while they run together.  Per group of
+// GROUP_M x tiles_n tiles that is GROUP_M A-panel loads (algorithmic) + tiles_n W-panel loads (overhead, amortised over GROUP_M).
+static int nt_group_m(int tiles_m, int tiles_n) {
+  if (g_nt_group_m > 0) return g_nt_group_m;
+  return 8;
+}
 
 static unsigned long long* g_nt_stamps = nullptr;
 
@@ -918,6 +934,7 @@ static void launch_nt_variant(int v, GemmNT& p, hipStream_t st) {
   const int grid_p = cu_count() & ~7;
   const int bn = v == 1 ? 256 : 128;
   const bool persist = !no_persist && (v == 1 || v == 3) && grid_p >= 8 && tiles(256, bn) > grid_p + grid_p / 2;
+  p.group_m = nt_group_m((p.M + 255) / 256, (p.N + bn - 1) / bn);
   p.sched = p.sched_clear = nullptr;
   if (persist && g_nt_dynamic) {
     if (int* ring = sched_ring(st)) {
@@ -1224,6 +1241,7 @@ int tad_linear_tuning(const char* key, int value) {
   }
   else if (k == "direct_epilogue") { TAD_REQUIRE(value >= 0 && value <= 2, "linear_tuning: direct_epilogue=%d not in 0..2", value); g_nt_direct = value; }
   else if (k == "dynamic_tiles") g_nt_dynamic = value != 0;
+  else if (k == "group_m") { TAD_REQUIRE(value >= 0 && value <= 1024, "linear_tuning: group_m=%d out of range", value); g_nt_group_m = value; }
   else if (k == "split_tail") { TAD_REQUIRE(value >= 0 && value <= 2, "linear_tuning: split_tail=%d not in 0..2", value); g_nt_split = value; }
   else { set_error("linear_tuning: unknown key '%s'", key); return TAD_EINVAL; }
   return TAD_OK;

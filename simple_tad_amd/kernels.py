@@ -345,7 +345,7 @@ def linear_fwd(x, w, bias=None, out_dtype=torch.bfloat16, epilogue=EPI_BIAS, wan
     return y, pre
 
 
-LINEAR_TUNING_DEFAULTS = dict(persistent=1, stagger_pct=0, stagger_group=1, direct_epilogue=1, split_tail=1, dynamic_tiles=0)
+LINEAR_TUNING_DEFAULTS = dict(persistent=1, stagger_pct=0, stagger_group=1, direct_epilogue=1, split_tail=1, dynamic_tiles=0, group_m=0)
 
 
 def linear_tuning(**knobs):
