@@ -84,7 +84,7 @@ for name, n, k, mode in SHAPES:
     for i, c in enumerate(cfgs):
         med = float(np.median(t[i]))
         total[i] += med
-        line += f" | {','.join(f'{kk}={vv}' for kk, vv in c.items())}: {med:7.1f} us (min {t[i].min():7.1f}) {gf / med / 1e3 * 1e3:6.0f} TF"
+        line += f" | {','.join(f'{kk}={vv}' for kk, vv in c.items())}: {med:7.1f} us (min {t[i].min():7.1f}) {gf / med * 1e3:6.0f} TF"
     print(line, flush=True)
     del x, w, res, h
 K.linear_tuning(**K.LINEAR_TUNING_DEFAULTS)
