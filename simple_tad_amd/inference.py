@@ -77,6 +77,7 @@ class SlidingWindow:
             sig = (ops.weight_epoch(), tuple(p._version for p in self._params), tuple(p.data_ptr() for p in self._params[:4]))
             if sig != self._sig:
                 self._graphs.clear()
+                self._pool = None   # (the allocator retires a graph memory pool with its last graph: a new generation gets a new pool)
                 self._sig = sig
             ent = self._graphs.get(self.start)
             if ent is None:
