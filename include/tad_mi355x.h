@@ -169,6 +169,9 @@ int tad_attn_fwd(const uint16_t* qkv, void* out, int out_dtype, float* lse, int 
 /* dqkv [B,N,3,H,d] bf16 (fully overwritten).  delta: scratch of tad_attn_bwd_scratch_bytes(B, N, H) bytes = 2*B*H*N floats (the
  * first kernel leaves -rowsum(dout*out) in [0, BHN) and -lse/scale in [BHN, 2 BHN) for the second one, which takes them as the
  * initial values of its accumulators). */
+/* Scheduling knob of the three attention kernels; timing only, never results.  "dma_mode": 0 = the LDS-DMA pieces of the next K/V
+ * (Q/dO) tile are issued at the top of a tile, 1 = spread behind the score products of the two half tiles. */
+int tad_attn_tuning(const char* key, int value);
 size_t tad_attn_bwd_scratch_bytes(int B, int N, int H);
 /* Diagnostic, ablation builds only (see tad_linear_debug_stamps): while buf (device memory, 32 bytes per workgroup of the dK/dV grid
  * = ceil(N/128)*H*B workgroups) is set, every dK/dV workgroup records {s_memrealtime, s_memtime} at the start and at the end of its

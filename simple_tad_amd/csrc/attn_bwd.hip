@@ -16,6 +16,8 @@
 //
 // Tiles that are read both by rows (ds_read_b128) and transposed (ds_read_b64_tr_b16) use one LDS image with a
 // swizzle that is conflict-free for both (found by tools/lds_bank_sim.py).
+#include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 #include "common.h"
 
@@ -74,6 +76,11 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int s2) {
 }
 
 // ------------------------------------------------------------------------------------------------ dQ
+// DMA_MODE (tad_attn_tuning("dma_mode")): where the LDS-DMA pieces of the NEXT tile are issued.  0: all at the top of the tile (before the
+// first matrix instruction).  1: spread into the tile -- issuing a piece blocks the wave for 60-185 cycles depending on what else the
+// phase carries (MI355X_MICROARCH.md, 'LDS-DMA piece issue cost'), cheapest in VALU-only stretches.  2: ablation, no DMA inside the loop
+// (every tile reads the first one: wrong results, timing only; refused outside ablation builds).
+template <int DMA_MODE>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out,
                                                           const uint16_t* __restrict__ dout, const float* __restrict__ lse,
                                                           float* __restrict__ delta, uint16_t* __restrict__ dqkv, int N, int H, int B,
@@ -141,15 +148,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
     dma_k[i] = (uint32_t)(((int64_t)b * N + key) * tok * 2) + (uint32_t)((head + H) * BHD * 2) + (uint32_t)(((lane & 7) ^ sw_dual(key)) << 4);
   }
   const uint32_t v_off = (uint32_t)(H * BHD * 2), key_step = (uint32_t)(tok * 2);
-#define DMA_KV(buf, kv0)                                                                                                        \
+#define DMA_K_(buf, kv0)                                                                                                        \
   {                                                                                                                             \
     char* kl_ = lds + (buf) * 2 * TILE_BYTES;                                                                                   \
     const uint32_t adv_ = (uint32_t)(kv0) * key_step;                                                                           \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                             \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                               \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_qkv, LDS_PTR(kl_ + (wave + 4 * i) * 1024), 16, dma_k[i] + adv_, 0, 0, 0);     \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_qkv, LDS_PTR(kl_ + TILE_BYTES + (wave + 4 * i) * 1024), 16, dma_k[i] + v_off + adv_, 0, 0, 0); \
-    }                                                                                                                           \
   }
+#define DMA_V_(buf, kv0)                                                                                                        \
+  {                                                                                                                             \
+    char* kl_ = lds + (buf) * 2 * TILE_BYTES;                                                                                   \
+    const uint32_t adv_ = (uint32_t)(kv0) * key_step;                                                                           \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                               \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_qkv, LDS_PTR(kl_ + TILE_BYTES + (wave + 4 * i) * 1024), 16, dma_k[i] + v_off + adv_, 0, 0, 0); \
+  }
+#define DMA_KV(buf, kv0) { DMA_K_(buf, kv0); DMA_V_(buf, kv0); }
 
   f32x16 dq[2];
 #pragma unroll
@@ -169,7 +182,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
   auto dq_tile = [&](auto BUFC, int t) {
     constexpr int BUF = decltype(BUFC)::value;
     const int kv0 = t * 64;
-    if (t + 1 < nt) DMA_KV(BUF ^ 1, kv0 + 64);
+    const bool more = t + 1 < nt;
+    // (the second half of a tile is skipped only in the LAST tile, where nothing is staged any more: a live wave that has to stage
+    // runs both halves, so DMA_MODE 1 may hang its pieces on them)
+    if (more && (DMA_MODE == 0 || (DMA_MODE == 1 && !wave_live))) DMA_KV(BUF ^ 1, kv0 + 64);
     const char* kl = lds + BUF * 2 * TILE_BYTES;
     const char* vl = kl + TILE_BYTES;
     // a wave whose 32 query rows all lie past the sequence (the last block of N = 1568 has one live wave of four) only helps
@@ -204,6 +220,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
         for (int r = 0; r < 16; ++r) {
           const int kg = kv0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h5;
           if (kg >= N) s[r] = -1e30f;
+        }
+      }
+      if constexpr (DMA_MODE == 1) {  // next tile's K pieces behind the first half's score products, V pieces behind the second's
+        if (more) {
+          if constexpr (kt == 0) DMA_K_(BUF ^ 1, kv0 + 64) else DMA_V_(BUF ^ 1, kv0 + 64)
         }
       }
       f32x16 ds;
@@ -246,6 +267,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
+template <int DMA_MODE>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
                                                            const float* __restrict__ rowc_g, uint16_t* __restrict__ dqkv, int N, int H, int B,
                                                            float scale, unsigned long long* stamps) {
@@ -299,16 +321,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
   const int64_t bhn = (int64_t)B * H * N;
   const auto rs_rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rowc_g), 0, (int)(2 * bhn * 4), 0x00020000);
   const uint32_t rc_off = (uint32_t)(((wave == 0 ? bhn : 0) + ((int64_t)b * H + head) * N + lane) * 4);
-#define LOAD_QDO(buf, q0)                                                                                  \
+#define LOAD_Q_(buf, q0)                                                                                   \
   {                                                                                                        \
     char* ql_ = lds + (buf) * STAGE;                                                                       \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                        \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                          \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_qkv, LDS_PTR(ql_ + (wave + 4 * i) * 1024), 16, dma_q[i] + (uint32_t)(q0) * q_step, 0, 0, 0); \
+  }
+#define LOAD_DO_RC_(buf, q0)                                                                               \
+  {                                                                                                        \
+    char* ql_ = lds + (buf) * STAGE;                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                          \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_do, LDS_PTR(ql_ + TILE_BYTES + (wave + 4 * i) * 1024), 16, dma_do[i] + (uint32_t)(q0) * do_step, 0, 0, 0); \
-    }                                                                                                      \
     if (wave < 2) /* wave-uniform */                                                                       \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_rc, LDS_PTR(ql_ + 2 * TILE_BYTES + wave * 256), 4, rc_off + (uint32_t)(q0) * 4u, 0, 0, 0); \
   }
+#define LOAD_QDO(buf, q0) { LOAD_Q_(buf, q0); LOAD_DO_RC_(buf, q0); }
 
   f32x16 dk[2], dv[2];
 #pragma unroll
@@ -340,7 +367,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
   }
 #endif
   for (int t = 0; t < nt; ++t) {
-    if (t + 1 < nt) LOAD_QDO((t + 1) & 1, (t + 1) * 64);
+    const bool more = t + 1 < nt;
+    if (more && (DMA_MODE == 0 || (DMA_MODE == 1 && !wave_live))) LOAD_QDO((t + 1) & 1, (t + 1) * 64);
     const uint32_t so = (uint32_t)((t & 1) * STAGE);
     if (wave_live)  // (see the dQ kernel: waves whose 32 keys all lie past the sequence only stage tiles)
     static_for<0, 2>([&](auto qtc) {
@@ -392,6 +420,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[ks], vfr[ks], dp, 0, 0, 0);
       }
       TR_ISSUE(1);
+      if constexpr (DMA_MODE == 1) {  // next tile: Q pieces behind the first half's score products, dO + row constants behind the second's
+        if (more) {
+          if constexpr (qt == 0) LOAD_Q_((t + 1) & 1, (t + 1) * 64) else LOAD_DO_RC_((t + 1) & 1, (t + 1) * 64)
+        }
+      }
       f32x16 pm, ds;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -443,6 +476,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
 using namespace tad;
 
 static unsigned long long* g_attn_stamps = nullptr;
+int g_attn_dma_mode = getenv("TAD_ATTN_DMA_MODE") ? atoi(getenv("TAD_ATTN_DMA_MODE")) : 0;  // shared with attn_fwd.hip
+
+extern "C" int tad_attn_tuning(const char* key, int value) {
+  TAD_REQUIRE(key, "attn_tuning: null key");
+  if (!strcmp(key, "dma_mode")) {
+#ifdef TAD_GEMM_ABLATION
+    TAD_REQUIRE(value >= 0 && value <= 2, "attn_tuning: dma_mode=%d not in 0..2", value);
+#else
+    TAD_REQUIRE(value >= 0 && value <= 1, "attn_tuning: dma_mode=%d not in 0..1 (2 = timing-only ablation, ablation builds)", value);
+#endif
+    g_attn_dma_mode = value;
+    return TAD_OK;
+  }
+  set_error("attn_tuning: unknown key '%s'", key);
+  return TAD_EINVAL;
+}
 
 // Diagnostic (ablation builds only, like tad_linear_debug_stamps): while buf (device memory, 32 bytes per workgroup of the dK/dV grid)
 // is set, workgroup w records {s_memrealtime, s_memtime} at the start and at the end of its tile loop in buf[4w .. 4w+3].
@@ -469,9 +518,19 @@ extern "C" int tad_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint
   TAD_REQUIRE((int64_t)B * N * 3 * H * BHD * 2 < (1ll << 32), "attn_bwd: qkv exceeds the 4 GiB buffer descriptor (B=%d N=%d H=%d)", B, N, H);
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)(((N + 127) / 128) * H * B)), block(256);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, block, 0, st, qkv, out, dout, lse, delta, dqkv, N, H, B, scale);
-  int rc = check_launch("attn_bwd_dq");
-  if (rc) return rc;
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, block, 0, st, qkv, dout, delta, dqkv, N, H, B, scale, g_attn_stamps);
-  return check_launch("attn_bwd_dkv");
+  const int mode = g_attn_dma_mode;
+#define LAUNCH_BWD(M_)                                                                                                              \
+  {                                                                                                                                 \
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<M_>, grid, block, 0, st, qkv, out, dout, lse, delta, dqkv, N, H, B, scale);               \
+    int rc = check_launch("attn_bwd_dq");                                                                                           \
+    if (rc) return rc;                                                                                                              \
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<M_>, grid, block, 0, st, qkv, dout, delta, dqkv, N, H, B, scale, g_attn_stamps);         \
+    return check_launch("attn_bwd_dkv");                                                                                            \
+  }
+  if (mode == 1) LAUNCH_BWD(1)
+#ifdef TAD_GEMM_ABLATION
+  if (mode == 2) LAUNCH_BWD(2)
+#endif
+  LAUNCH_BWD(0)
+#undef LAUNCH_BWD
 }

@@ -35,7 +35,9 @@ __device__ __forceinline__ float half_swap_sum(float x) {
 
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 
-template <bool OUT_BF16>
+// DMA_MODE: see attn_bwd.hip (0: next tile's LDS-DMA pieces at the top of the tile; 1: K pieces behind the score products, V pieces
+// behind the exponentials; 2: timing-only ablation)
+template <bool OUT_BF16, int DMA_MODE>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, void* __restrict__ out,
                                                        float* __restrict__ lse, int N, int H, int B, float scale) {
   __shared__ __attribute__((aligned(1024))) char lds[2 * 2 * KV_TILE * HD * 2];  // [buf][K|V][64 keys][128 B]
@@ -83,15 +85,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
     dma_v[i] = rowb + (uint32_t)(2 * H * HD * 2) + (uint32_t)((dch ^ swv(key)) << 4);
   }
   const uint32_t tile_step = (uint32_t)(tok_stride * 2);  // bytes per key
-#define DMA_TILE(buf, kv0)                                                                                                  \
+#define DMA_K_(buf, kv0)                                                                                                    \
   {                                                                                                                         \
     char* kl_ = lds + (buf) * 2 * TILE_BYTES;                                                                               \
     const uint32_t adv_ = (uint32_t)(kv0) * tile_step;                                                                      \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                         \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                           \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_qkv, LDS_PTR(kl_ + (wave + 4 * i) * 1024), 16, dma_k[i] + adv_, 0, 0, 0); \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_qkv, LDS_PTR(kl_ + TILE_BYTES + (wave + 4 * i) * 1024), 16, dma_v[i] + adv_, 0, 0, 0); \
-    }                                                                                                                       \
   }
+#define DMA_V_(buf, kv0)                                                                                                    \
+  {                                                                                                                         \
+    char* kl_ = lds + (buf) * 2 * TILE_BYTES;                                                                               \
+    const uint32_t adv_ = (uint32_t)(kv0) * tile_step;                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                           \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_qkv, LDS_PTR(kl_ + TILE_BYTES + (wave + 4 * i) * 1024), 16, dma_v[i] + adv_, 0, 0, 0); \
+  }
+#define DMA_TILE(buf, kv0) { DMA_K_(buf, kv0); DMA_V_(buf, kv0); }
 
   f32x16 o[2];
 #pragma unroll
@@ -133,7 +141,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
 #define FWD_TILE(BUF, T)                                                                                                  \
   {                                                                                                                       \
     const int kv0 = (T) * KV_TILE;                                                                                        \
-    if ((T) + 1 < nt) DMA_TILE((BUF) ^ 1, kv0 + KV_TILE);                                                                   \
+    const bool more_ = (T) + 1 < nt;                                                                                      \
+    if (more_ && (DMA_MODE == 0 || (DMA_MODE == 1 && !wave_live))) DMA_TILE((BUF) ^ 1, kv0 + KV_TILE);                     \
     const char* kl = lds + (BUF) * 2 * TILE_BYTES;                                                                        \
     const char* vl = kl + TILE_BYTES;                                                                                     \
     if (wave_live) { /* waves whose 32 query rows all lie past the sequence only help staging the tiles */               \
@@ -153,6 +162,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
         if (key >= N) s[kt][r] = -1e30f;                                                                                  \
       }                                                                                                                   \
     }                                                                                                                     \
+    if (DMA_MODE == 1 && more_) DMA_K_((BUF) ^ 1, kv0 + KV_TILE);                                                          \
     float mloc = s[0][0];                                                                                                 \
     _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                                      \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[kt][r]);                                      \
@@ -174,6 +184,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
         _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2)                                                                  \
             _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                                 \
                 pf[kt][s2][j] = (__bf16)fast_exp2(s[kt][8 * s2 + j] * c - mc);                                            \
+    if (DMA_MODE == 1 && more_) DMA_V_((BUF) ^ 1, kv0 + KV_TILE);                                                          \
     f32x4 rs = {0.f, 0.f, 0.f, 0.f};                                                                                      \
     /* V^T fragments through the asm reads of common.h (the builtin made the compiler drain the DMA of the next tile here):  \
        group g = 2 kt + s2 covers keys 16g .. 16g+15; the reads of group g+1 are issued before the MFMAs of group g */     \
@@ -240,6 +251,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
 
 using namespace tad;
 
+extern int g_attn_dma_mode;  // attn_bwd.hip (tad_attn_tuning)
+
 extern "C" int tad_attn_fwd(const uint16_t* qkv, void* out, int out_dtype, float* lse, int B, int N, int H, int d, float scale,
                             tad_stream_t stream) {
   TAD_REQUIRE(qkv && out, "attn_fwd: null pointer");
@@ -252,9 +265,18 @@ extern "C" int tad_attn_fwd(const uint16_t* qkv, void* out, int out_dtype, float
               (long long)B * N * 3 * H * HD * 2, B, N, H);
   TAD_REQUIRE((int64_t)((N + Q_BLOCK - 1) / Q_BLOCK) * H * B < (1ll << 31), "attn_fwd: grid too large");
   const dim3 grid((unsigned)(((N + Q_BLOCK - 1) / Q_BLOCK) * H * B)), block(256);
-  if (out_dtype == TAD_BF16)
-    hipLaunchKernelGGL((attn_fwd_kernel<true>), grid, block, 0, (hipStream_t)stream, qkv, out, lse, N, H, B, scale);
-  else
-    hipLaunchKernelGGL((attn_fwd_kernel<false>), grid, block, 0, (hipStream_t)stream, qkv, out, lse, N, H, B, scale);
-  return check_launch("attn_fwd");
+#define LAUNCH_FWD(M_)                                                                                                      \
+  {                                                                                                                         \
+    if (out_dtype == TAD_BF16)                                                                                              \
+      hipLaunchKernelGGL((attn_fwd_kernel<true, M_>), grid, block, 0, (hipStream_t)stream, qkv, out, lse, N, H, B, scale);  \
+    else                                                                                                                    \
+      hipLaunchKernelGGL((attn_fwd_kernel<false, M_>), grid, block, 0, (hipStream_t)stream, qkv, out, lse, N, H, B, scale); \
+    return check_launch("attn_fwd");                                                                                        \
+  }
+  if (g_attn_dma_mode == 1) LAUNCH_FWD(1)
+#ifdef TAD_GEMM_ABLATION
+  if (g_attn_dma_mode == 2) LAUNCH_FWD(2)
+#endif
+  LAUNCH_FWD(0)
+#undef LAUNCH_FWD
 }

@@ -451,6 +451,12 @@ def attn_fwd(qkv, B: int, N: int, H: int, scale: float, out_dtype=torch.bfloat16
     return out, lse
 
 
+def attn_tuning(**knobs):
+    """Scheduling knobs of the attention kernels (include/tad_mi355x.h: tad_attn_tuning); timing only, never results."""
+    for k, v in knobs.items():
+        check(_lib.load().tad_attn_tuning(k.encode(), int(v)), f"tad_attn_tuning({k}={v})")
+
+
 def attn_bwd(qkv, out, dout, lse, B: int, N: int, H: int, scale: float):
     for t, n in ((qkv, "qkv"), (out, "out"), (dout, "dout")):
         _req(t, torch.bfloat16, "attn_bwd." + n)
