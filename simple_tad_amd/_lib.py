@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtad_mi355x.so")
+LIB_PATH = os.environ.get("TAD_LIB") or os.path.join(_HERE, "libtad_mi355x.so")  # TAD_LIB: an experiment build (simple_tad_amd/build.py)
 
 _vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 

@@ -6,7 +6,10 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "libtad_mi355x.so")
+# TAD_BUILD_LIB / TAD_BUILD_DEFINES: experiment builds next to the production library (own object directory), e.g.
+#   TAD_BUILD_LIB=libtad_spread.so TAD_BUILD_DEFINES="-DTAD_DMA_SPREAD=1" python -m simple_tad_amd.build --force
+# and TAD_LIB=<path> selects the library a process loads (_lib.py).
+LIB = os.path.join(HERE, os.environ.get("TAD_BUILD_LIB", "libtad_mi355x.so"))
 SOURCES = ["capi.hip", "elementwise.hip", "layernorm.hip", "gemm.hip", "attn_fwd.hip", "attn_bwd.hip", "precise.hip", "optim.hip", "mae.hip", "metrics.hip", "collective.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result",
          # keep MFMA accumulators in the (unified) VGPR file: without it the compiler parks them in AGPRs and pays a
@@ -32,7 +35,7 @@ def _deps_mtime():
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _deps_mtime():
         return LIB
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build" if "TAD_BUILD_LIB" not in os.environ else "build_" + os.path.splitext(os.path.basename(LIB))[0])
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
 
@@ -42,7 +45,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(srcp), os.path.getmtime(os.path.join(CSRC, "common.h")),
                                                                           os.path.getmtime(os.path.join(os.path.dirname(HERE), "include", "tad_mi355x.h")))):
             return obj
-        cmd = [hipcc, *FLAGS, *(["-DTAD_GEMM_ABLATION"] if os.environ.get("TAD_BUILD_ABLATION") == "1" else []), "-c", srcp, "-o", obj]
+        cmd = [hipcc, *FLAGS, *(["-DTAD_GEMM_ABLATION"] if os.environ.get("TAD_BUILD_ABLATION") == "1" else []),
+               *os.environ.get("TAD_BUILD_DEFINES", "").split(), "-c", srcp, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

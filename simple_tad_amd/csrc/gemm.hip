@@ -94,6 +94,18 @@ __device__ __forceinline__ void stage_tile(const void* gbase, int gbytes, char* 
   }
 }
 
+#ifndef TAD_DMA_SPREAD
+#define TAD_DMA_SPREAD 0
+#endif
+// piece I of a stage only (stage_tile issues all PIECES at once): for the build-time variant that spreads a stage's pieces between the
+// MFMA groups of a k-step (-DTAD_DMA_SPREAD=1)
+template <int NW, bool SCALAR_ADD = false>
+__device__ __forceinline__ void stage_piece(const void* gbase, int gbytes, char* tile, uint32_t off_i, uint32_t add, int wave, int i) {
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(gbase), 0, gbytes, 0x00020000);
+  if (SCALAR_ADD) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(tile + (i * NW + wave) * 1024), 16, off_i, add, 0, 0);
+  else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(tile + (i * NW + wave) * 1024), 16, off_i + add, 0, 0, 0);
+}
+
 // wait until at most `stages_in_flight` later stages (LOADS DMA instructions each, per wave) plus EXTRA younger vector-memory
 // instructions are still outstanding
 template <int LOADS, int EXTRA = 0>
@@ -270,6 +282,21 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
     _Pragma("unroll") for (int i = 0; i < MREP; ++i) asm volatile("" ::"v"(afr[i]));                     \
     _Pragma("unroll") for (int j = 0; j < NREP; ++j) asm volatile("" ::"v"(bfr_[j]));                    \
   }
+  // Build-time variant -DTAD_DMA_SPREAD=1 (TAD_BUILD_DEFINES, tools/exp_build_ab.sh): the DMA pieces of the next stage go out one per
+  // m-row of MFMAs instead of all in front of the k-step (an LDS-DMA piece blocks the issuing wave for 60-185 cycles depending on what
+  // the phase carries)
+  constexpr int APIECES = BM / (RPP * NW), BPIECES = BN / (RPP * NW);
+#define MFMA_BLOCK_DMA(afr, bfr_, buf, kt_, cond_)                                                                           \
+  {                                                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < MREP; ++i) {                                                                       \
+      _Pragma("unroll") for (int j = 0; j < NREP; ++j)                                                                       \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr_[j], afr[i], acc[i][j], 0, 0, 0);                           \
+      if (!(cond_)) continue; /* wave-uniform: a scalar branch around one buffer_load; the MFMAs are unconditional */        \
+      if (i < APIECES) stage_piece<NW, true>(p.A, a_bytes, lds + (buf) * STAGE_BYTES, a_off[i < APIECES ? i : 0], (uint32_t)(kt_) * ROWB, wave, i); \
+      else if (i - APIECES < BPIECES)                                                                                        \
+        stage_piece<NW, true>(p.B, b_bytes, lds + (buf) * STAGE_BYTES + A_BYTES, b_off[(i - APIECES) < BPIECES ? (i - APIECES) : 0], (uint32_t)(kt_) * ROWB, wave, i - APIECES); \
+    }                                                                                                                        \
+  }
   const bool late = wave >= NW / 2;  // wave-uniform (scalar branches); the MFMA code is shared by both halves
 
   // epilogue geometry (see the epilogue below)
@@ -432,16 +459,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
       // (wave w and w + NW/2) therefore issue them at different times: the older half before its first k-step, the younger
       // half between its two k-steps, so the SIMD's matrix pipe always has one wave feeding it.
       const bool dma = more && !(DBG_BITS(p) & 1);
+      constexpr bool spread = TAD_DMA_SPREAD && MREP >= APIECES + BPIECES && KSTEPS == 2;
       bf16x8 af[MREP], bfr[NREP];
-      if (dma && (!late || KSTEPS == 1)) { STAGE_NT(wr_now, kt_next); }
+      if (dma && !spread && (!late || KSTEPS == 1)) { STAGE_NT(wr_now, kt_next); }
       FRAG_B(bfr, sb, 0);
       FRAG_A(af, sa, 0);
-      MFMA_BLOCK(af, bfr);
+      if constexpr (spread) { MFMA_BLOCK_DMA(af, bfr, wr_now, kt_next, dma && !late); } else { MFMA_BLOCK(af, bfr); }
       if (KSTEPS == 2) {
-        if (dma && late) { STAGE_NT(wr_now, kt_next); }
+        if (dma && !spread && late) { STAGE_NT(wr_now, kt_next); }
         FRAG_B(bfr, sb, 1);
         FRAG_A(af, sa, 1);
-        MFMA_BLOCK(af, bfr);
+        if constexpr (spread) { MFMA_BLOCK_DMA(af, bfr, wr_now, kt_next, dma && late); } else { MFMA_BLOCK(af, bfr); }
       }
     }
   }
@@ -800,7 +828,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(const Ge
     const int wr_now = wr, t_next = t + STAGES - 1;
     rd = (rd + 1 == STAGES) ? 0 : rd + 1;
     wr = (wr + 1 == STAGES) ? 0 : wr + 1;
-#define KSTEP_TN(ks)                                                                                          \
+#define KSTEP_TN(ks) KSTEP_TN_(ks, false)
+#define KSTEP_TN_(ks, SPREAD_) /* SPREAD_: wave-uniform runtime condition (false: a literal, the branch folds away) */ \
   if (!(DBG_BITS(p) & 8)) {                                                                                   \
     s16x4 ql_[NREP], qh_[NREP], pl_[MREP], ph_[MREP];                                                         \
     _Pragma("unroll") for (int j = 0; j < NREP; ++j) {                                                        \
@@ -828,11 +857,19 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(const Ge
       }                                                                                                       \
       if (bias_now && (i % WAVES_N) == wn)                                                                    \
         bacc[i / WAVES_N] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, ones, bacc[i / WAVES_N], 0, 0, 0);    \
+      if (SPREAD_) { /* experiment: piece i of the next stage behind row fragment i's MFMAs */                \
+        if (i < P_PIECES) stage_piece<NW>(p.P, p_bytes, lds + wr_now * STAGE_BYTES, p_off[i < P_PIECES ? i : 0], (uint32_t)(t_next) * BKT * (uint32_t)(p.N * 2), wave, i); \
+        else if (i - P_PIECES < Q_PIECES) stage_piece<NW>(p.Q, q_bytes, lds + wr_now * STAGE_BYTES + P_BYTES, q_off[(i - P_PIECES) < Q_PIECES ? (i - P_PIECES) : 0], (uint32_t)(t_next) * BKT * (uint32_t)(p.K * 2), wave, i - P_PIECES); \
+      }                                                                                                       \
     });                                                                                                       \
   }
     const bool late = wave >= NW / 2;  // stagger the DMA issue of the two waves that share a SIMD (see gemm_nt_kernel)
     const bool dma = more && !(DBG_BITS(p) & 1);
-    if (KSTEPS == 2) {
+    constexpr bool spread = TAD_DMA_SPREAD && MREP >= P_PIECES + Q_PIECES;
+    if constexpr (KSTEPS == 2 && spread) {
+      KSTEP_TN_(0, dma && !late);
+      KSTEP_TN_(1, dma && late);
+    } else if (KSTEPS == 2) {
       if (dma && !late) { STAGE_TN(wr_now, t_next); }
       KSTEP_TN(0);
       if (dma && late) { STAGE_TN(wr_now, t_next); }
@@ -878,6 +915,7 @@ static int env_int(const char* name) {
 static int cu_count();
 
 // scheduling knobs (tad_linear_tuning; initial values from TAD_GEMM_NO_PERSIST / TAD_GEMM_STAGGER / TAD_GEMM_STAGGER_GROUP)
+static int g_gemm_debug = env_int("TAD_GEMM_DEBUG");  // ablation bits (GemmNT::debug); only ablation builds look at them
 static int g_nt_persist = !env_int("TAD_GEMM_NO_PERSIST");
 static int g_nt_stagger_pct = getenv("TAD_GEMM_STAGGER") ? env_int("TAD_GEMM_STAGGER") : 0;  // % of one tile's K-loop time
 static int g_nt_stagger_group = getenv("TAD_GEMM_STAGGER_GROUP") ? env_int("TAD_GEMM_STAGGER_GROUP") : 1;
@@ -1065,8 +1103,7 @@ int launch_gemm_nt(const GemmNT& p_in, hipStream_t st) {
     }
   }
   static const int forced = env_int("TAD_GEMM_NT_VARIANT");
-  static const int debug = env_int("TAD_GEMM_DEBUG");
-  p.debug = debug;
+  p.debug = g_gemm_debug;
   p.stamps = g_nt_stamps;
   if (forced) return launch_gemm_nt_one(p, forced, st);
   if (p.M < 2048 || p.N < 128) {
@@ -1164,8 +1201,7 @@ int launch_gemm_tn(const uint16_t* P, const uint16_t* Q, float* out, float* bias
   if (Mr * (int64_t)N * 2 >= (1ll << 32) || Mr * (int64_t)K * 2 >= (1ll << 32)) { set_error("gemm_tn: operand exceeds 4 GiB"); return TAD_EINVAL; }
   GemmTN p;
   p.P = P; p.Q = Q; p.slab = (float*)ws; p.Mr = (int)Mr; p.N = N; p.K = K;
-  static const int debug = env_int("TAD_GEMM_DEBUG");
-  p.debug = debug;
+  p.debug = g_gemm_debug;
   int splits;
   const int tiles = tn_plan(Mr, N, K, &splits, &p.rows_per_split);
   const int tiles_k = (K + (tn_variant() != 3 ? 256 : 128) - 1) / (tn_variant() != 3 ? 256 : 128);
@@ -1241,6 +1277,7 @@ int tad_linear_tuning(const char* key, int value) {
   }
   else if (k == "direct_epilogue") { TAD_REQUIRE(value >= 0 && value <= 2, "linear_tuning: direct_epilogue=%d not in 0..2", value); g_nt_direct = value; }
   else if (k == "dynamic_tiles") g_nt_dynamic = value != 0;
+  else if (k == "debug") g_gemm_debug = value;  // ablation bits (timing experiments; ignored by production builds)
   else if (k == "group_m") { TAD_REQUIRE(value >= 0 && value <= 1024, "linear_tuning: group_m=%d out of range", value); g_nt_group_m = value; }
   else if (k == "split_tail") { TAD_REQUIRE(value >= 0 && value <= 2, "linear_tuning: split_tail=%d not in 0..2", value); g_nt_split = value; }
   else { set_error("linear_tuning: unknown key '%s'", key); return TAD_EINVAL; }
