@@ -76,7 +76,7 @@ def main():
                                                   "max_launch_us": st["max_ns"] / 1e3,
                                                   "avg_launch_us_without_max": (st["total_ns"] - st["max_ns"]) / (st["calls"] - 1) / 1e3}
         rows = sorted(agg.items(), key=lambda kv: -kv[1]["total_ns"])
-        lines = [f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline   ({a.steps} steps incl. warm-up)",
+        lines = [f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras   ({a.steps} steps incl. warm-up)",
                  f"# total kernel time {total / 1e6:.1f} ms = {total / 1e6 / a.steps:.2f} ms/step",
                  f"{'kernel':44s} {'calls':>7s} {'ms/step':>9s} {'avg us':>9s} {'share':>7s}"]
         for k, d in rows[:40]:
