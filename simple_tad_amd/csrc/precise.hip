@@ -68,34 +68,38 @@ __global__ void im2col_tubelets_f32_kernel(const float* __restrict__ x, float* _
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// f32 attention forward.  Workgroup = 256 threads = 64 query rows of one (batch, head); thread (ty = tid>>4, tx = tid&15) owns
-// query rows 4ty..4ty+3 and, per 64-key tile, keys 4tx..4tx+3 (scores) / head-dim columns 4tx..4tx+3 (output).
+// f32 attention, any head dim HD that is a multiple of 16 (64: the precise mode of the small / base / large models; 80: the "huge"
+// configurations, modeling_finetune.py:390-398 / modeling_pretrain.py:364-386, which have no MFMA kernel).
+// Forward.  Workgroup = 256 threads = 64 query rows of one (batch, head); thread (ty = tid>>4, tx = tid&15) owns query rows
+// 4ty..4ty+3 and, per 64-key tile, keys 4tx..4tx+3 (scores) / head-dim columns CPT*tx .. CPT*tx+CPT-1 (output), CPT = HD / 16.
+template <int HD>
 __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out, float* __restrict__ lse,
                                                            int N, int H, float scale) {
-  __shared__ float Qs[64][65], Ks[64][65], Vs[64][65], Ps[64][65];
+  constexpr int CPT = HD / 16;
+  __shared__ float Qs[64][HD + 1], Ks[64][HD + 1], Vs[64][HD + 1], Ps[64][65];
   const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
   const int head = blockIdx.y, b = blockIdx.z, q0 = blockIdx.x * 64;
-  const int64_t tok = (int64_t)3 * H * 64;
-  const float* base = qkv + (int64_t)b * N * tok + head * 64;
-  for (int i = tid; i < 64 * 64; i += 256) {
-    const int r = i >> 6, c = i & 63;
+  const int64_t tok = (int64_t)3 * H * HD;
+  const float* base = qkv + (int64_t)b * N * tok + head * HD;
+  for (int i = tid; i < 64 * HD; i += 256) {
+    const int r = i / HD, c = i - r * HD;
     const int q = min(q0 + r, N - 1);
     Qs[r][c] = base[(int64_t)q * tok + c] * scale;
   }
-  float m_run[4], l_run[4], o[4][4];
+  float m_run[4], l_run[4], o[4][CPT];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     m_run[i] = -1e30f; l_run[i] = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[i][j] = 0.f;
+    for (int j = 0; j < CPT; ++j) o[i][j] = 0.f;
   }
   for (int kv0 = 0; kv0 < N; kv0 += 64) {
     __syncthreads();
-    for (int i = tid; i < 64 * 64; i += 256) {
-      const int r = i >> 6, c = i & 63;
+    for (int i = tid; i < 64 * HD; i += 256) {
+      const int r = i / HD, c = i - r * HD;
       const int key = min(kv0 + r, N - 1);
-      Ks[r][c] = base[(int64_t)key * tok + (int64_t)H * 64 + c];
-      Vs[r][c] = base[(int64_t)key * tok + (int64_t)2 * H * 64 + c];
+      Ks[r][c] = base[(int64_t)key * tok + (int64_t)H * HD + c];
+      Vs[r][c] = base[(int64_t)key * tok + (int64_t)2 * H * HD + c];
     }
     __syncthreads();
     float s[4][4];
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restri
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) s[i][j] = 0.f;
-    for (int d = 0; d < 64; ++d) {
+    for (int d = 0; d < HD; ++d) {
       float qa[4], kb[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) { qa[i] = Qs[4 * ty + i][d]; kb[i] = Ks[4 * tx + i][d]; }
@@ -136,17 +140,19 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restri
       l_run[i] = l_run[i] * alpha + ps;
       m_run[i] = m_new;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[i][j] *= alpha;
+      for (int j = 0; j < CPT; ++j) o[i][j] *= alpha;
     }
     __syncthreads();
     for (int k = 0; k < 64; ++k) {
-      float pa[4], vb[4];
+      float pa[4], vb[CPT];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { pa[i] = Ps[4 * ty + i][k]; vb[i] = Vs[k][4 * tx + i]; }
+      for (int i = 0; i < 4; ++i) pa[i] = Ps[4 * ty + i][k];
+#pragma unroll
+      for (int j = 0; j < CPT; ++j) vb[j] = Vs[k][CPT * tx + j];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[i][j] = fmaf(pa[i], vb[j], o[i][j]);
+        for (int j = 0; j < CPT; ++j) o[i][j] = fmaf(pa[i], vb[j], o[i][j]);
     }
   }
 #pragma unroll
@@ -154,27 +160,29 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restri
     const int q = q0 + 4 * ty + i;
     if (q >= N) continue;
     const float inv = 1.f / l_run[i];
-    float* op = out + (((int64_t)b * N + q) * H + head) * 64 + 4 * tx;
-    *reinterpret_cast<float4*>(op) = make_float4(o[i][0] * inv, o[i][1] * inv, o[i][2] * inv, o[i][3] * inv);
+    float* op = out + (((int64_t)b * N + q) * H + head) * HD + CPT * tx;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) op[j] = o[i][j] * inv;
     if (tx == 0 && lse) lse[((int64_t)b * H + head) * N + q] = m_run[i] + __logf(l_run[i]);
   }
 }
 
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// f32 attention backward (verification mode): delta, dQ pass (per 64 query rows) and dK/dV pass (per 64 keys); same thread
-// layout as the forward kernel.  No atomics.
+// f32 attention backward (verification mode / head dims without an MFMA kernel): delta, dQ pass (per 64 query rows) and dK/dV pass
+// (per 64 keys); same thread layout as the forward kernel.  No atomics.
+template <int HD>
 __global__ void attn_delta_f32_kernel(const float* __restrict__ o, const float* __restrict__ dout, float* __restrict__ delta, int B, int N,
                                       int H) {
+  constexpr int CPT = HD / 16;
   const int64_t rows = (int64_t)B * N * H;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t row = gid >> 4;
   const int sub = (int)(gid & 15);
   float s = 0.f;
   if (row < rows) {
-    const float4 a = *reinterpret_cast<const float4*>(o + row * 64 + sub * 4);
-    const float4 g = *reinterpret_cast<const float4*>(dout + row * 64 + sub * 4);
-    s = a.x * g.x + a.y * g.y + a.z * g.z + a.w * g.w;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) s = fmaf(o[row * HD + sub * CPT + j], dout[row * HD + sub * CPT + j], s);
   }
 #pragma unroll
   for (int off = 1; off < 16; off <<= 1) s += __shfl_xor(s, off, 64);
@@ -185,36 +193,38 @@ __global__ void attn_delta_f32_kernel(const float* __restrict__ o, const float* 
   }
 }
 
+template <int HD>
 __global__ __launch_bounds__(256) void attn_bwd_dq_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                               const float* __restrict__ lse, const float* __restrict__ delta,
                                                               float* __restrict__ dqkv, int N, int H, float scale) {
-  __shared__ float Qs[64][65], Gs[64][65], Ks[64][65], Vs[64][65], Ds[64][65];
+  constexpr int CPT = HD / 16;
+  __shared__ float Qs[64][HD + 1], Gs[64][HD + 1], Ks[64][HD + 1], Vs[64][HD + 1], Ds[64][65];
   const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
   const int head = blockIdx.y, b = blockIdx.z, q0 = blockIdx.x * 64;
-  const int64_t tok = (int64_t)3 * H * 64;
-  const float* base = qkv + (int64_t)b * N * tok + head * 64;
-  for (int i = tid; i < 64 * 64; i += 256) {
-    const int r = i >> 6, c = i & 63;
+  const int64_t tok = (int64_t)3 * H * HD;
+  const float* base = qkv + (int64_t)b * N * tok + head * HD;
+  for (int i = tid; i < 64 * HD; i += 256) {
+    const int r = i / HD, c = i - r * HD;
     const int q = min(q0 + r, N - 1);
     Qs[r][c] = base[(int64_t)q * tok + c] * scale;
-    Gs[r][c] = dout[(((int64_t)b * N + q) * H + head) * 64 + c];
+    Gs[r][c] = dout[(((int64_t)b * N + q) * H + head) * HD + c];
   }
-  float lq[4], dq_[4], acc[4][4];
+  float lq[4], dq_[4], acc[4][CPT];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int q = min(q0 + 4 * ty + i, N - 1);
     lq[i] = lse[((int64_t)b * H + head) * N + q];
     dq_[i] = delta[((int64_t)b * H + head) * N + q];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int j = 0; j < CPT; ++j) acc[i][j] = 0.f;
   }
   for (int kv0 = 0; kv0 < N; kv0 += 64) {
     __syncthreads();
-    for (int i = tid; i < 64 * 64; i += 256) {
-      const int r = i >> 6, c = i & 63;
+    for (int i = tid; i < 64 * HD; i += 256) {
+      const int r = i / HD, c = i - r * HD;
       const int key = min(kv0 + r, N - 1);
-      Ks[r][c] = base[(int64_t)key * tok + (int64_t)H * 64 + c];
-      Vs[r][c] = base[(int64_t)key * tok + (int64_t)2 * H * 64 + c];
+      Ks[r][c] = base[(int64_t)key * tok + (int64_t)H * HD + c];
+      Vs[r][c] = base[(int64_t)key * tok + (int64_t)2 * H * HD + c];
     }
     __syncthreads();
     float s[4][4], dp[4][4];
@@ -222,7 +232,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_f32_kernel(const float* __res
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) { s[i][j] = 0.f; dp[i][j] = 0.f; }
-    for (int d = 0; d < 64; ++d) {
+    for (int d = 0; d < HD; ++d) {
       float qa[4], ga[4], kb[4], vb[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) { qa[i] = Qs[4 * ty + i][d]; ga[i] = Gs[4 * ty + i][d]; kb[i] = Ks[4 * tx + i][d]; vb[i] = Vs[4 * tx + i][d]; }
@@ -240,51 +250,56 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_f32_kernel(const float* __res
       }
     __syncthreads();
     for (int k = 0; k < 64; ++k) {
-      float da[4], kb[4];
+      float da[4], kb[CPT];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { da[i] = Ds[4 * ty + i][k]; kb[i] = Ks[k][4 * tx + i]; }
+      for (int i = 0; i < 4; ++i) da[i] = Ds[4 * ty + i][k];
+#pragma unroll
+      for (int j = 0; j < CPT; ++j) kb[j] = Ks[k][CPT * tx + j];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(da[i], kb[j], acc[i][j]);
+        for (int j = 0; j < CPT; ++j) acc[i][j] = fmaf(da[i], kb[j], acc[i][j]);
     }
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int q = q0 + 4 * ty + i;
     if (q >= N) continue;
-    float* op = dqkv + ((int64_t)b * N + q) * tok + head * 64 + 4 * tx;
-    *reinterpret_cast<float4*>(op) = make_float4(acc[i][0] * scale, acc[i][1] * scale, acc[i][2] * scale, acc[i][3] * scale);
+    float* op = dqkv + ((int64_t)b * N + q) * tok + head * HD + CPT * tx;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) op[j] = acc[i][j] * scale;
   }
 }
 
+template <int HD>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
                                                                float* __restrict__ dqkv, int N, int H, float scale) {
-  __shared__ float Ks[64][65], Vs[64][65], Qs[64][65], Gs[64][65], Pt[64][65], Dt[64][65];
+  constexpr int CPT = HD / 16;
+  __shared__ float Ks[64][HD + 1], Vs[64][HD + 1], Qs[64][HD + 1], Gs[64][HD + 1], Pt[64][65], Dt[64][65];
   __shared__ float Ls[64], Es[64];
   const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
   const int head = blockIdx.y, b = blockIdx.z, k0 = blockIdx.x * 64;
-  const int64_t tok = (int64_t)3 * H * 64;
-  const float* base = qkv + (int64_t)b * N * tok + head * 64;
-  for (int i = tid; i < 64 * 64; i += 256) {
-    const int r = i >> 6, c = i & 63;
+  const int64_t tok = (int64_t)3 * H * HD;
+  const float* base = qkv + (int64_t)b * N * tok + head * HD;
+  for (int i = tid; i < 64 * HD; i += 256) {
+    const int r = i / HD, c = i - r * HD;
     const int key = min(k0 + r, N - 1);
-    Ks[r][c] = base[(int64_t)key * tok + (int64_t)H * 64 + c];
-    Vs[r][c] = base[(int64_t)key * tok + (int64_t)2 * H * 64 + c];
+    Ks[r][c] = base[(int64_t)key * tok + (int64_t)H * HD + c];
+    Vs[r][c] = base[(int64_t)key * tok + (int64_t)2 * H * HD + c];
   }
-  float dk[4][4], dv[4][4];
+  float dk[4][CPT], dv[4][CPT];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { dk[i][j] = 0.f; dv[i][j] = 0.f; }
+    for (int j = 0; j < CPT; ++j) { dk[i][j] = 0.f; dv[i][j] = 0.f; }
   for (int q0 = 0; q0 < N; q0 += 64) {
     __syncthreads();
-    for (int i = tid; i < 64 * 64; i += 256) {
-      const int r = i >> 6, c = i & 63;
+    for (int i = tid; i < 64 * HD; i += 256) {
+      const int r = i / HD, c = i - r * HD;
       const int q = min(q0 + r, N - 1);
       Qs[r][c] = base[(int64_t)q * tok + c] * scale;
-      Gs[r][c] = dout[(((int64_t)b * N + q) * H + head) * 64 + c];
+      Gs[r][c] = dout[(((int64_t)b * N + q) * H + head) * HD + c];
     }
     if (tid < 64) {
       const int q = min(q0 + tid, N - 1);
@@ -297,7 +312,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_f32_kernel(const float* __re
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) { s[i][j] = 0.f; dp[i][j] = 0.f; }
-    for (int d = 0; d < 64; ++d) {
+    for (int d = 0; d < HD; ++d) {
       float ka[4], va[4], qb[4], gb[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) { ka[i] = Ks[4 * ty + i][d]; va[i] = Vs[4 * ty + i][d]; qb[i] = Qs[4 * tx + i][d]; gb[i] = Gs[4 * tx + i][d]; }
@@ -317,23 +332,28 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_f32_kernel(const float* __re
       }
     __syncthreads();
     for (int q = 0; q < 64; ++q) {
-      float pa[4], da[4], gb[4], qb[4];
+      float pa[4], da[4], gb[CPT], qb[CPT];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { pa[i] = Pt[4 * ty + i][q]; da[i] = Dt[4 * ty + i][q]; gb[i] = Gs[q][4 * tx + i]; qb[i] = Qs[q][4 * tx + i]; }
+      for (int i = 0; i < 4; ++i) { pa[i] = Pt[4 * ty + i][q]; da[i] = Dt[4 * ty + i][q]; }
+#pragma unroll
+      for (int j = 0; j < CPT; ++j) { gb[j] = Gs[q][CPT * tx + j]; qb[j] = Qs[q][CPT * tx + j]; }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { dv[i][j] = fmaf(pa[i], gb[j], dv[i][j]); dk[i][j] = fmaf(da[i], qb[j], dk[i][j]); }
+        for (int j = 0; j < CPT; ++j) { dv[i][j] = fmaf(pa[i], gb[j], dv[i][j]); dk[i][j] = fmaf(da[i], qb[j], dk[i][j]); }
     }
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int key = k0 + 4 * ty + i;
     if (key >= N) continue;
-    float* okp = dqkv + ((int64_t)b * N + key) * tok + (int64_t)H * 64 + head * 64 + 4 * tx;
+    float* okp = dqkv + ((int64_t)b * N + key) * tok + (int64_t)H * HD + head * HD + CPT * tx;
     // Qs carried the softmax scale already: dK = dS^T (scale*Q)
-    *reinterpret_cast<float4*>(okp) = make_float4(dk[i][0], dk[i][1], dk[i][2], dk[i][3]);
-    *reinterpret_cast<float4*>(okp + (int64_t)H * 64) = make_float4(dv[i][0], dv[i][1], dv[i][2], dv[i][3]);
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+      okp[j] = dk[i][j];
+      okp[(int64_t)H * HD + j] = dv[i][j];
+    }
   }
 }
 
@@ -400,22 +420,30 @@ int tad_im2col_tubelets_f32(const float* x, float* cols, int B, int C, int T, in
 
 int tad_attn_fwd_f32(const float* qkv, float* out, float* lse, int B, int N, int H, int d, float scale, tad_stream_t stream) {
   TAD_REQUIRE(qkv && out, "attn_fwd_f32: null pointer");
-  TAD_REQUIRE(d == 64, "attn_fwd_f32: head_dim must be 64 (got %d)", d);
+  TAD_REQUIRE(d == 64 || d == 80, "attn_fwd_f32: head_dim must be 64 or 80 (got %d)", d);
   TAD_REQUIRE(B > 0 && N > 0 && H > 0 && H <= 65535 && B <= 65535 && scale > 0.f, "attn_fwd_f32: bad shape");
-  hipLaunchKernelGGL(attn_fwd_f32_kernel, dim3((N + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, qkv, out, lse, N, H, scale);
+  const dim3 grid((N + 63) / 64, H, B);
+  if (d == 64) hipLaunchKernelGGL(attn_fwd_f32_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, qkv, out, lse, N, H, scale);
+  else hipLaunchKernelGGL(attn_fwd_f32_kernel<80>, grid, dim3(256), 0, (hipStream_t)stream, qkv, out, lse, N, H, scale);
   return check_launch("attn_fwd_f32");
 }
 
 int tad_attn_bwd_f32(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, float* delta, int B, int N, int H,
                      int d, float scale, tad_stream_t stream) {
   TAD_REQUIRE(qkv && out && dout && lse && dqkv && delta, "attn_bwd_f32: null pointer");
-  TAD_REQUIRE(d == 64 && B > 0 && N > 0 && H > 0 && H <= 65535 && B <= 65535 && scale > 0.f, "attn_bwd_f32: bad shape");
+  TAD_REQUIRE((d == 64 || d == 80) && B > 0 && N > 0 && H > 0 && H <= 65535 && B <= 65535 && scale > 0.f,
+              "attn_bwd_f32: bad shape (head_dim 64 or 80)");
   hipStream_t st = (hipStream_t)stream;
   const int64_t rows = (int64_t)B * N * H;
-  hipLaunchKernelGGL(attn_delta_f32_kernel, dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, st, out, dout, delta, B, N, H);
-  const dim3 grid((N + 63) / 64, H, B);
-  hipLaunchKernelGGL(attn_bwd_dq_f32_kernel, grid, dim3(256), 0, st, qkv, dout, lse, delta, dqkv, N, H, scale);
-  hipLaunchKernelGGL(attn_bwd_dkv_f32_kernel, grid, dim3(256), 0, st, qkv, dout, lse, delta, dqkv, N, H, scale);
+  const dim3 dgrid((unsigned)((rows * 16 + 255) / 256)), grid((N + 63) / 64, H, B);
+#define BWD_F32(HD_)                                                                                                     \
+  {                                                                                                                      \
+    hipLaunchKernelGGL(attn_delta_f32_kernel<HD_>, dgrid, dim3(256), 0, st, out, dout, delta, B, N, H);                  \
+    hipLaunchKernelGGL(attn_bwd_dq_f32_kernel<HD_>, grid, dim3(256), 0, st, qkv, dout, lse, delta, dqkv, N, H, scale);   \
+    hipLaunchKernelGGL(attn_bwd_dkv_f32_kernel<HD_>, grid, dim3(256), 0, st, qkv, dout, lse, delta, dqkv, N, H, scale);  \
+  }
+  if (d == 64) BWD_F32(64) else BWD_F32(80)
+#undef BWD_F32
   return check_launch("attn_bwd_f32");
 }
 

@@ -128,8 +128,8 @@ class Attention(nn.Module):
             raise TadError("Attention: causal=True is never used by the reference (Block passes causal=False) and has no kernel")
 
     def _check(self):
-        if self.head_dim != 64:
-            raise TadError(f"Attention: the fused kernel supports head_dim 64 only (got {self.head_dim})")
+        if self.head_dim not in (64, 80):
+            raise TadError(f"Attention: head_dim {self.head_dim} has no kernel (64: fused bf16 MFMA kernels; 80: generic f32 kernels)")
         if self.training and self.attn_drop.p > 0:
             raise TadError("Attention: attn_drop > 0 in training is not supported by the fused kernel (reference jobs use 0)")
 

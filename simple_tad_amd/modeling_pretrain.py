@@ -5,7 +5,8 @@ backward run on the HIP kernels (shared Block stack of ``modeling_finetune`` + t
 Reference lines are cited per class (modeling_pretrain.py).  Differences, by design:
   * ``forward(x, mask, num_masked=None)``: ``num_masked`` (masked tokens per clip, identical for every clip as the reference's
     ``reshape(B, -1, C)`` requires) may be passed to avoid one device sync; otherwise it is read from ``mask[0]``.
-  * There is no CPU path; head_dim must be 64 (small / base / large; the huge configuration has head_dim 80).
+  * There is no CPU path.  head_dim 64 (small / base / large) runs the fused bf16 MFMA attention kernels, head_dim 80 (huge) the generic
+    f32 attention kernels between bf16 MFMA Linears.
 """
 from __future__ import annotations
 
@@ -263,6 +264,5 @@ def pretrain_videomae_large_patch16_224(pretrained=False, **kwargs):
 
 @register_model
 def pretrain_videomae_huge_patch16_224(pretrained=False, **kwargs):
-    """modeling_pretrain.py:364-386 (head_dim 80: constructible and state-dict compatible; forward raises until a d=80 attention
-    kernel exists)"""
+    """modeling_pretrain.py:364-386 (head_dim 80: attention through the generic f32 kernels)"""
     return _pretrain(pretrained, 1280, 32, 16, 640, 8, **kwargs)

@@ -242,7 +242,7 @@ def precise_linear(x2d, weight, bias, epilogue=EPI_BIAS, residual=None, rowscale
 
 def precise_attention(x2d, B, N, qkv_w, q_bias, v_bias, proj_w, proj_b, H, scale, residual=None):
     qkv = precise_linear(x2d, qkv_w, _qkv_bias(q_bias, v_bias))
-    ao, _ = K.attn_fwd_f32(qkv, B, N, H, scale)
+    ao, _ = K.attn_fwd_f32(qkv, B, N, H, scale, d=head_dim_of(qkv_w, H))
     return precise_linear(ao, proj_w, proj_b, EPI_BIAS_RESIDUAL if residual is not None else EPI_BIAS, residual=residual)
 
 
@@ -359,9 +359,21 @@ class PatchEmbedU8Fn(_Fn):
 
 
 # --------------------------------------------------------------------------- attention / mlp cores (2-D tensors)
+def head_dim_of(qkv_w, H):
+    return qkv_w.shape[0] // (3 * H)
+
+
 def _attn_fwd_core(xn, qkv_w, q_bias, v_bias, B, N, H, scale, train):
-    qkv = K.linear_fwd_qkv(xn, w_bf16(qkv_w, train), None if q_bias is None else _f32c(q_bias.detach()),
-                           None if v_bias is None else _f32c(v_bias.detach()), out_dtype=torch.bfloat16)
+    qb = None if q_bias is None else _f32c(q_bias.detach())
+    vb = None if v_bias is None else _f32c(v_bias.detach())
+    hd = head_dim_of(qkv_w, H)
+    if hd != 64:
+        # Head dims without an MFMA attention kernel (80: the "huge" configurations, modeling_finetune.py:390-398): the Linears stay on
+        # the bf16 MFMA GEMMs, the scaled-dot-product core runs through the generic f32 kernels (csrc/precise.hip) on an f32 qkv.
+        qkv = K.linear_fwd_qkv(xn, w_bf16(qkv_w, train), qb, vb, out_dtype=torch.float32)
+        ao32, lse = K.attn_fwd_f32(qkv, B, N, H, scale, want_lse=train, d=hd)
+        return qkv, K.cast_bf16(ao32), lse
+    qkv = K.linear_fwd_qkv(xn, w_bf16(qkv_w, train), qb, vb, out_dtype=torch.bfloat16)
     ao, lse = K.attn_fwd(qkv, B, N, H, scale, out_dtype=torch.bfloat16, want_lse=train)
     return qkv, ao, lse
 
@@ -369,7 +381,10 @@ def _attn_fwd_core(xn, qkv_w, q_bias, v_bias, B, N, H, scale, train):
 def _attn_bwd_core(d_ao, xn, qkv, ao, lse, qkv_w, has_qkv_bias, B, N, H, scale, dx_dtype, qv_params=None):
     """returns dxn, dWqkv, dq_bias, dv_bias (None for what went into gradient sinks)"""
     D = xn.shape[1]
-    dqkv = K.attn_bwd(qkv, ao, d_ao, lse, B, N, H, scale)
+    if qkv.dtype == torch.float32:  # generic head dim (see _attn_fwd_core)
+        dqkv = K.cast_bf16(K.attn_bwd_f32(qkv, ao.float(), d_ao.float(), lse, B, N, H, scale, d=head_dim_of(qkv_w, H)))
+    else:
+        dqkv = K.attn_bwd(qkv, ao, d_ao, lse, B, N, H, scale)
     dxn = K.linear_bwd_input(dqkv, wT_bf16(qkv_w, True), out_dtype=dx_dtype)
     if has_qkv_bias and qv_params is not None:
         ents = [_sink(qkv_w), _sink(qv_params[0]), _sink(qv_params[1])]
@@ -690,7 +705,7 @@ class PreciseBlockFn(_Fn):
         g1, b1, g2, b2 = _f32c(n1w), _f32c(n1b), _f32c(n2w), _f32c(n2b)
         xn1, mean1, rstd1 = K.layernorm_fwd(x0, g1, b1, eps, out_dtype=torch.float32)
         qkv = precise_linear(xn1, qkv_w, _qkv_bias(q_bias, v_bias), fresh=fr)
-        ao, lse = K.attn_fwd_f32(qkv, B, N, H, scale, want_lse=True)
+        ao, lse = K.attn_fwd_f32(qkv, B, N, H, scale, want_lse=True, d=head_dim_of(qkv_w, H))
         x1 = precise_linear(ao, proj_w, proj_b, EPI_BIAS_RESIDUAL, residual=x0, fresh=fr)
         xn2, mean2, rstd2 = K.layernorm_fwd(x1, g2, b2, eps, out_dtype=torch.float32)
         h = precise_linear(xn2, fc1_w, fc1_b, fresh=fr)
@@ -712,7 +727,7 @@ class PreciseBlockFn(_Fn):
         gmid, _, dg2, dbeta2, _ = K.layernorm_bwd(dxn2, x1, g2, mean2, rstd2, dres=g)
         d_ao = precise_dx(gmid, proj_w)
         dWp, dbp = precise_dw(gmid, ao)
-        dqkv = K.attn_bwd_f32(qkv, ao, d_ao, lse, B, N, H, scale)
+        dqkv = K.attn_bwd_f32(qkv, ao, d_ao, lse, B, N, H, scale, d=head_dim_of(qkv_w, H))
         dxn1 = precise_dx(dqkv, qkv_w)
         dWqkv, dbqkv = precise_dw(dqkv, xn1, want_bias=has_qb)
         dqb = dvb = None

@@ -201,11 +201,11 @@ ATT_SHAPES = [(2, 100, 2), (1, 1568, 2), (3, 64, 1), (2, 8, 3), (1, 784, 6), (1,
 
 
 def _attn_ref(qkv, B, N, H, scale, dout=None):
-    q = qkv.double().reshape(B, N, 3 * H * 64).requires_grad_()
+    q = qkv.double().reshape(B, N, -1).requires_grad_()
     y = O.attention_core(q, H, scale)
     if dout is None:
         return y, None
-    y.backward(dout.double().reshape(B, N, H * 64))
+    y.backward(dout.double().reshape(B, N, -1))
     return y, q.grad
 
 
@@ -306,15 +306,16 @@ def test_split_bf16x3_linear_matches_f32_product(K):
     check(K.gelu_bwd_f32(dev(dy), dev(h)), hd.grad, tol=1e-6, what="gelu bwd f32")
 
 
-@pytest.mark.parametrize("B,N,H", [(2, 100, 2), (1, 1568, 1), (2, 8, 3)])
-def test_attention_f32_fwd_bwd(K, B, N, H):
-    scale = 64 ** -0.5
-    qkv = R.tensor_for(f"attf.qkv{N}", (B * N, 3 * H * 64))
-    dout = R.tensor_for(f"attf.do{N}", (B * N, H * 64))
+@pytest.mark.parametrize("B,N,H,d", [(2, 100, 2, 64), (1, 1568, 1, 64), (2, 8, 3, 64), (2, 100, 2, 80), (1, 393, 3, 80)])
+def test_attention_f32_fwd_bwd(K, B, N, H, d):
+    """f32 attention kernels: head_dim 64 (precise mode) and 80 (the "huge" configurations, no MFMA kernel)"""
+    scale = d ** -0.5
+    qkv = R.tensor_for(f"attf.qkv{N}.{d}", (B * N, 3 * H * d))
+    dout = R.tensor_for(f"attf.do{N}.{d}", (B * N, H * d))
     ref, ref_dqkv = _attn_ref(qkv, B, N, H, scale, dout)
-    out, lse = K.attn_fwd_f32(dev(qkv), B, N, H, scale, want_lse=True)
+    out, lse = K.attn_fwd_f32(dev(qkv), B, N, H, scale, want_lse=True, d=d)
     check(out.reshape(B, N, -1), ref, tol=1e-5, what="attn f32 fwd")
-    dqkv = K.attn_bwd_f32(dev(qkv), out, dev(dout), lse, B, N, H, scale)
+    dqkv = K.attn_bwd_f32(dev(qkv), out, dev(dout), lse, B, N, H, scale, d=d)
     check(dqkv.reshape(B, N, -1), ref_dqkv, tol=1e-5, what="attn f32 bwd")
 
 

@@ -32,8 +32,9 @@ def _model(embed_dim, heads, depth=2, **kw):
     return m
 
 
-@pytest.mark.parametrize("D,H", [(384, 6), (1024, 16), (1280, 20)])
+@pytest.mark.parametrize("D,H", [(384, 6), (1024, 16), (1280, 20), (1280, 16)])
 def test_other_widths_forward_backward(D, H):
+    """(1280, 16) is the "huge" geometry (modeling_finetune.py:390-398): head_dim 80, attention through the generic f32 kernels"""
     m = _model(D, H).cuda().train()
     x = torch.randn(3, 3, 4, 32, 32)
     y = torch.tensor([0, 1, 1])
