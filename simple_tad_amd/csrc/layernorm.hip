@@ -71,7 +71,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 // Backward.  Each block owns a contiguous chunk of rows; each wave walks rows of the chunk with stride 4 and keeps
 // per-lane column partials of dgamma, dbeta and (optionally) colsum(dx) in registers; they are combined across the
 // block's 4 waves in LDS and written as one partial row per block -> reduced by reduce_partials_kernel.
-template <int NV, bool DY_BF16>
+// FULL: D == 256 * NV (768, 1024, 1280, 512 ...): no per-lane column guard, so the row loop is one basic block up to the optional bf16
+// store (the guards split every chunk into its own exec-masked region with its own waits).
+__device__ const float ln_one = 1.0f;
+template <int NV, bool DY_BF16, bool FULL>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const float* __restrict__ dres,
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
                                                             int rows_per_block, int want_colsum,
                                                             const float* __restrict__ rowscale, int rows_per_scale) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [4][3][D]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int D4 = D >> 2;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = min(rows, r0 + rows_per_block);
@@ -91,59 +94,90 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
     g[i] = (c < D4) ? reinterpret_cast<const float4*>(gamma)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
     dg[i] = db[i] = cs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  // One row per wave and iteration.  Everything the row needs (x, dy, the residual gradient, its statistics and its drop-path scale) is
+  // requested in ONE batch at the top -- the first version waited for each 256-column chunk on its own and fetched `dres` only behind
+  // the two reductions, six dependent HBM round trips per row, and its `s_waitcnt vmcnt(0)` in front of every chunk's store also drained
+  // the stores issued before it (CDNA4 counts stores in vmcnt) -- and the two row sums go through DPP / permlane steps instead of
+  // twelve ds_bpermute round trips (wave_sum_dpp, common.h).  Optional operands are made unconditional so that the loads stay in one
+  // block: without a residual gradient the row of x is read a second time and multiplied by 0, without row scales the scale comes from a
+  // constant.
+  const float* const rsrc = dres ? dres : x;
+  const float rmul = dres ? 1.f : 0.f;
+  const float* const scp = rowscale ? rowscale : &ln_one;
+  // index of the row's drop-path scale, kept incrementally (one division per wave instead of one 64-bit division per row and chunk)
+  int sidx = 0, srem = 0;
+  if (rowscale) {
+    sidx = (int)((r0 + wave) / rows_per_scale);
+    srem = (int)((r0 + wave) - (int64_t)sidx * rows_per_scale);
+  }
   for (int64_t row = r0 + wave; row < r1; row += 4) {
+    float4 xv[NV], dyv[NV], rv[NV];
+    uint2 dyp[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + 64 * i;
+      if (FULL || c < D4) {
+        xv[i] = reinterpret_cast<const float4*>(x + row * D)[c];
+        if (DY_BF16) dyp[i] = reinterpret_cast<const uint2*>((const uint16_t*)dy + row * D)[c];
+        else dyv[i] = reinterpret_cast<const float4*>((const float*)dy + row * D)[c];
+        rv[i] = reinterpret_cast<const float4*>(rsrc + row * D)[c];
+      }
+    }
     const float mu = mean[row], rs = rstd[row];
-    float4 xh[NV], dyv[NV];
+    const float sc = scp[sidx];
+    if (rowscale) {
+      srem += 4;
+      while (srem >= rows_per_scale) { srem -= rows_per_scale; ++sidx; }
+    }
+    // keep the whole batch of loads above the arithmetic: the scheduler otherwise sinks them chunk by chunk (one exposed round trip each)
+    __builtin_amdgcn_sched_barrier(0);
+    float4 xh[NV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = lane + 64 * i;
-      if (c < D4) {
-        const float4 xv = reinterpret_cast<const float4*>(x + row * D)[c];
-        if (DY_BF16) {
-          const uint2 p = reinterpret_cast<const uint2*>((const uint16_t*)dy + row * D)[c];
-          dyv[i] = make_float4(__uint_as_float(p.x << 16), __uint_as_float(p.x & 0xffff0000u), __uint_as_float(p.y << 16),
-                               __uint_as_float(p.y & 0xffff0000u));
-        } else {
-          dyv[i] = reinterpret_cast<const float4*>((const float*)dy + row * D)[c];
-        }
-        xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+      if (FULL || c < D4) {
+        if (DY_BF16)
+          dyv[i] = make_float4(__uint_as_float(dyp[i].x << 16), __uint_as_float(dyp[i].x & 0xffff0000u), __uint_as_float(dyp[i].y << 16),
+                               __uint_as_float(dyp[i].y & 0xffff0000u));
+        xh[i] = make_float4((xv[i].x - mu) * rs, (xv[i].y - mu) * rs, (xv[i].z - mu) * rs, (xv[i].w - mu) * rs);
         const float4 t = make_float4(dyv[i].x * g[i].x, dyv[i].y * g[i].y, dyv[i].z * g[i].z, dyv[i].w * g[i].w);
         s1 += (t.x + t.y) + (t.z + t.w);
         s2 += (t.x * xh[i].x + t.y * xh[i].y) + (t.z * xh[i].z + t.w * xh[i].w);
         dg[i].x += dyv[i].x * xh[i].x; dg[i].y += dyv[i].y * xh[i].y; dg[i].z += dyv[i].z * xh[i].z; dg[i].w += dyv[i].w * xh[i].w;
         db[i].x += dyv[i].x; db[i].y += dyv[i].y; db[i].z += dyv[i].z; db[i].w += dyv[i].w;
       } else {
-        xh[i] = dyv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        xh[i] = dyv[i] = rv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
-    const float c1 = wave_sum(s1) / (float)D;
-    const float c2 = wave_sum(s2) / (float)D;
+    const float c1 = wave_sum_dpp(s1) / (float)D;
+    const float c2 = wave_sum_dpp(s2) / (float)D;
+    float4 o[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      o[i].x = fmaf(rv[i].x, rmul, rs * (dyv[i].x * g[i].x - c1 - xh[i].x * c2));
+      o[i].y = fmaf(rv[i].y, rmul, rs * (dyv[i].y * g[i].y - c1 - xh[i].y * c2));
+      o[i].z = fmaf(rv[i].z, rmul, rs * (dyv[i].z * g[i].z - c1 - xh[i].z * c2));
+      o[i].w = fmaf(rv[i].w, rmul, rs * (dyv[i].w * g[i].w - c1 - xh[i].w * c2));
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = lane + 64 * i;
-      if (c < D4) {
-        float4 o;
-        o.x = rs * (dyv[i].x * g[i].x - c1 - xh[i].x * c2);
-        o.y = rs * (dyv[i].y * g[i].y - c1 - xh[i].y * c2);
-        o.z = rs * (dyv[i].z * g[i].z - c1 - xh[i].z * c2);
-        o.w = rs * (dyv[i].w * g[i].w - c1 - xh[i].w * c2);
-        if (dres) {
-          const float4 r = reinterpret_cast<const float4*>(dres + row * D)[c];
-          o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-        }
-        reinterpret_cast<float4*>(dx + row * D)[c] = o;
-        if (rowscale) {  // the bf16 copy and the column sums feed the branch Linear, whose output was scaled per sample (drop-path)
-          const float sc = rowscale[row / rows_per_scale];
-          o.x *= sc; o.y *= sc; o.z *= sc; o.w *= sc;
-        }
-        if (dxb) {
+      if (FULL || c < D4) reinterpret_cast<float4*>(dx + row * D)[c] = o[i];
+      // the bf16 copy and the column sums feed the branch Linear, whose output was scaled per sample (drop-path)
+      o[i].x *= sc; o[i].y *= sc; o[i].z *= sc; o[i].w *= sc;
+      if (FULL || c < D4) { cs[i].x += o[i].x; cs[i].y += o[i].y; cs[i].z += o[i].z; cs[i].w += o[i].w; }
+    }
+    if (dxb) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        if (FULL || c < D4) {
           uint2 p;
-          p.x = pack_bf16x2(o.x, o.y);
-          p.y = pack_bf16x2(o.z, o.w);
+          p.x = pack_bf16x2(o[i].x, o[i].y);
+          p.y = pack_bf16x2(o[i].z, o[i].w);
           reinterpret_cast<uint2*>(dxb + row * D)[c] = p;
         }
-        cs[i].x += o.x; cs[i].y += o.y; cs[i].z += o.z; cs[i].w += o.w;
       }
     }
   }
@@ -231,13 +265,13 @@ int tad_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float*
   hipStream_t st = (hipStream_t)stream;
   float* partial = (float*)ws;
   const int want_cs = colsum_dx != nullptr;
+  const bool full = (D == 256 * nv);
+#define LN_BWD_(NV, BF, FULL_)                                                                                                  \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<NV, BF, FULL_>), dim3(blocks), dim3(256), smem, st, dy, x, gamma, mean, rstd, dres, dx, \
+                     dx_bf16, partial, rows, D, rows_per_block, want_cs, rowscale, rows_per_scale)
 #define LN_BWD(NV)                                                                                                             \
-  if (dy_dtype == TAD_BF16)                                                                                                    \
-    hipLaunchKernelGGL((layernorm_bwd_kernel<NV, true>), dim3(blocks), dim3(256), smem, st, dy, x, gamma, mean, rstd, dres, dx, \
-                       dx_bf16, partial, rows, D, rows_per_block, want_cs, rowscale, rows_per_scale);                           \
-  else                                                                                                                         \
-    hipLaunchKernelGGL((layernorm_bwd_kernel<NV, false>), dim3(blocks), dim3(256), smem, st, dy, x, gamma, mean, rstd, dres, dx, \
-                       dx_bf16, partial, rows, D, rows_per_block, want_cs, rowscale, rows_per_scale);
+  if (dy_dtype == TAD_BF16) { if (full) LN_BWD_(NV, true, true); else LN_BWD_(NV, true, false); }                               \
+  else { if (full) LN_BWD_(NV, false, true); else LN_BWD_(NV, false, false); }
   switch (nv) {
     case 1: LN_BWD(1); break;
     case 2: LN_BWD(2); break;
@@ -248,6 +282,7 @@ int tad_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float*
     default: LN_BWD(8); break;
   }
 #undef LN_BWD
+#undef LN_BWD_
   int rc = check_launch("layernorm_bwd");
   if (rc) return rc;
   rc = launch_reduce_cols(partial, dgamma, dbeta, colsum_dx, colsum_dx ? 3 : 2, blocks, D, accumulate ? 1 : 0, st);
