@@ -355,6 +355,10 @@ def main():
                     ent.update({"bound": "hbm", "achieved": round(gbs, 1), "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)})
                 ra[k] = ent
             out["roofline_all"] = ra
+            if "adamw" in ra:  # the step with the AdamW update included (`value`) and excluded
+                ms_wo = out["ms_per_step"] - ra["adamw"]["ms_per_step"]
+                out["excluding_adamw"] = {"ms_per_step": round(ms_wo, 3), "value": round(B * 1e3 / ms_wo, 2), "unit": "clips/sec",
+                                          "note": "ms_per_step minus the fused AdamW launch (one HBM-bound kernel per step, roofline_all.adamw)"}
             if args.breakdown:
                 for k, e in ra.items():
                     print(f"   {k:16s} {e['launches_per_step']:7.1f} launches/step {e['ms_per_step']:9.3f} ms/step  {e['achieved']:9.1f} {e['unit']}", file=sys.stderr)
