@@ -115,6 +115,10 @@ template <int N, typename A, typename B, typename C, typename D>
 __device__ __forceinline__ void lds_wait(A& a, B& b, C& c, D& d) {
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : TAD_LGKM(N));
 }
+template <int N, typename A, typename B, typename C, typename D, typename E>
+__device__ __forceinline__ void lds_wait(A& a, B& b, C& c, D& d, E& e) {
+  asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : TAD_LGKM(N));
+}
 template <int N, typename A, typename B, typename C, typename D, typename E, typename F, typename G, typename H>
 __device__ __forceinline__ void lds_wait(A& a, B& b, C& c, D& d, E& e, F& f, G& g, H& h) {
   asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : TAD_LGKM(N));

@@ -97,6 +97,9 @@ __device__ __forceinline__ void stage_tile(const void* gbase, int gbytes, char* 
 #ifndef TAD_DMA_SPREAD
 #define TAD_DMA_SPREAD 0
 #endif
+#ifndef TAD_NT_PIPE
+#define TAD_NT_PIPE 0
+#endif
 // piece I of a stage only (stage_tile issues all PIECES at once): for the build-time variant that spreads a stage's pieces between the
 // MFMA groups of a k-step (-DTAD_DMA_SPREAD=1)
 template <int NW, bool SCALAR_ADD = false>
@@ -298,6 +301,22 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
     }                                                                                                                        \
   }
   const bool late = wave >= NW / 2;  // wave-uniform (scalar branches); the MFMA code is shared by both halves
+  // Build-time variant -DTAD_NT_PIPE=1 (256 x 256 tile): fragment reads as inline asm in a fixed software pipeline.  hipcc streams the A
+  // fragments just in time (2 ds_read_b128, s_waitcnt lgkmcnt(1), 4 MFMAs ...: each group of four MFMAs waits for a read issued right in
+  // front of it).  Here the 12 reads of k-step 0 go out back to back, row i's A register is refilled with its k-step-1 fragment as soon
+  // as row i's four MFMAs are issued (in place: no second A set), the four B fragments of k-step 1 go into a second B set behind rows
+  // 0..3, and every wait is a counted lgkmcnt that leaves the younger reads in flight: one exposed LDS latency per K-tile (behind the
+  // barrier; the next tile's data may not be read earlier) instead of one per MFMA group.
+  constexpr bool PIPE = TAD_NT_PIPE && BM == 256 && BN == 256 && KSTEPS == 2 && MREP == 8 && NREP == 4 && STAGES == 2 &&
+                        (EPI == EPI_PLAIN || EPI == EPI_GELU);  // (the residual / GELU-backward variants have no registers left: they spill)
+  uint32_t pa[PIPE ? MREP : 1], pb[PIPE ? NREP : 1];  // lane-constant LDS byte addresses (stage 0, k-step 0); k-step 1 = address ^ 64
+  if constexpr (PIPE) {
+    const uint32_t l0 = lds_addr(lds);
+#pragma unroll
+    for (int i = 0; i < MREP; ++i) pa[i] = l0 + a_rd[i] + (uint32_t)((kq ^ a_sw[i]) << 4);
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) pb[j] = l0 + b_rd[j] + (uint32_t)((kq ^ b_sw[j]) << 4);
+  }
 
   // epilogue geometry (see the epilogue below)
   constexpr int MREP_C = CROWS / (16 * WAVES_M);     // m-fragments each wave contributes to a chunk
@@ -460,6 +479,39 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
       // half between its two k-steps, so the SIMD's matrix pipe always has one wave feeding it.
       const bool dma = more && !(DBG_BITS(p) & 1);
       constexpr bool spread = TAD_DMA_SPREAD && MREP >= APIECES + BPIECES && KSTEPS == 2;
+      if constexpr (PIPE) {
+        const uint32_t so = (uint32_t)((sa - lds));  // byte offset of this K-tile's stage (0 or STAGE_BYTES)
+        bf16x8 a[MREP], b[NREP], b2[NREP];
+        if (dma && !late) { STAGE_NT(wr_now, kt_next); }
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) b[j] = lds_read_b128<bf16x8, A_BYTES>(pb[j] + so);
+#pragma unroll
+        for (int i = 0; i < MREP; ++i) a[i] = lds_read_b128<bf16x8, 0>(pa[i] + so);
+        // k-step 0.  Reads still in flight in front of row i: a[i+1 .. 7] and the 2 i (i <= 4; 8 + (i - 4) beyond) refills issued so far
+        static_for<0, MREP>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          constexpr int inflight = (MREP - 1 - i) + (i <= NREP ? 2 * i : 2 * NREP + (i - NREP));
+          if constexpr (i == 0) lds_wait<inflight>(b[0], b[1], b[2], b[3], a[0]);
+          else lds_wait<inflight>(a[i]);
+#pragma unroll
+          for (int j = 0; j < NREP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          a[i] = lds_read_b128<bf16x8, 0>((pa[i] ^ 64u) + so);
+          if constexpr (i < NREP) b2[i] = lds_read_b128<bf16x8, A_BYTES>((pb[i] ^ 64u) + so);
+        });
+        if (dma && late) { STAGE_NT(wr_now, kt_next); }
+        // k-step 1: issue order of its reads was a'0 b'0 a'1 b'1 a'2 b'2 a'3 b'3 a'4 a'5 a'6 a'7
+        static_for<0, MREP>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          constexpr int inflight = i < NREP ? MREP - NREP : MREP - 1 - i;
+          if constexpr (i == 0) lds_wait<inflight>(b2[0], b2[1], b2[2], b2[3], a[0], a[1], a[2], a[3]);
+          else lds_wait<inflight>(a[i]);
+#pragma unroll
+          for (int j = 0; j < NREP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b2[j], a[i], acc[i][j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        continue;
+      }
       bf16x8 af[MREP], bfr[NREP];
       if (dma && !spread && (!late || KSTEPS == 1)) { STAGE_NT(wr_now, kt_next); }
       FRAG_B(bfr, sb, 0);
