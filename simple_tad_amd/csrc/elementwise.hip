@@ -345,42 +345,59 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partial, float*
 // through LDS.  blockIdx.y selects one of up to 3 (partial, out) pairs so one launch serves all: pair q starts at
 // partial + q * q_stride and its partial rows are row_stride floats apart ([q][splits][n]: q_stride = splits * n, row_stride = n;
 // column ranges of one [splits][N] array: q_stride = distance between the ranges, row_stride = N).
+// Block = 16 float4 columns x 64 row lanes (lane = 16 * row-sub + column inside a wave: 256 contiguous bytes per partial row and
+// wave quarter): a [1024][3][768] LayerNorm partial is spread over 36 blocks instead of 9 (round 1: 64 columns per block, 12 us per launch
+// with 9 of 256 CUs pulling 9.4 MB).
 __global__ __launch_bounds__(1024) void reduce_cols_kernel(const float* __restrict__ partial, float* out0, float* out1, float* out2,
                                                            int splits, int n, int accumulate, int64_t q_stride, int row_stride) {
-  __shared__ float4 red[16][64];
+  __shared__ float4 red[64][16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 15, rl = wave * 4 + (lane >> 4);  // row lane 0..63
   const int q = blockIdx.y;
   float* out = q == 0 ? out0 : (q == 1 ? out1 : out2);
   const float* base = partial + (int64_t)q * q_stride;
-  const int c4 = blockIdx.x * 64 + lane;
+  const int c4 = blockIdx.x * 16 + col;
   const int n4 = n >> 2;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c4 < n4) {
-    int s = wave;
-    for (; s + 48 < splits; s += 64) {
+    int s = rl;
+    for (; s + 192 < splits; s += 256) {
       const float4 a = reinterpret_cast<const float4*>(base + (int64_t)s * row_stride)[c4];
-      const float4 b = reinterpret_cast<const float4*>(base + (int64_t)(s + 16) * row_stride)[c4];
-      const float4 c = reinterpret_cast<const float4*>(base + (int64_t)(s + 32) * row_stride)[c4];
-      const float4 d = reinterpret_cast<const float4*>(base + (int64_t)(s + 48) * row_stride)[c4];
+      const float4 b = reinterpret_cast<const float4*>(base + (int64_t)(s + 64) * row_stride)[c4];
+      const float4 c = reinterpret_cast<const float4*>(base + (int64_t)(s + 128) * row_stride)[c4];
+      const float4 d = reinterpret_cast<const float4*>(base + (int64_t)(s + 192) * row_stride)[c4];
       acc.x += (a.x + b.x) + (c.x + d.x); acc.y += (a.y + b.y) + (c.y + d.y);
       acc.z += (a.z + b.z) + (c.z + d.z); acc.w += (a.w + b.w) + (c.w + d.w);
     }
-    for (; s < splits; s += 16) {
+    for (; s < splits; s += 64) {
       const float4 a = reinterpret_cast<const float4*>(base + (int64_t)s * row_stride)[c4];
       acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
     }
   }
-  red[wave][lane] = acc;
+  red[rl][col] = acc;
   __syncthreads();
-  if (wave == 0 && c4 < n4) {
-    float4 t = red[0][lane];
+  // 64 -> 16 -> 1 per column in a fixed order (deterministic); every barrier is reached by all 16 waves
+  const int fc = threadIdx.x & 15, fg = (threadIdx.x >> 4) & 15;  // thread < 256: folds rows 4 fg .. 4 fg + 3 of column fc
+  float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (threadIdx.x < 256) {
+    t4 = red[4 * fg][fc];
 #pragma unroll
-    for (int w = 1; w < 16; ++w) { t.x += red[w][lane].x; t.y += red[w][lane].y; t.z += red[w][lane].z; t.w += red[w][lane].w; }
+    for (int w = 1; w < 4; ++w) { const float4 v = red[4 * fg + w][fc]; t4.x += v.x; t4.y += v.y; t4.z += v.z; t4.w += v.w; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 256) red[fg][fc] = t4;
+  __syncthreads();
+  if (threadIdx.x < 16 && blockIdx.x * 16 + (int)threadIdx.x < n4) {
+    const int c = threadIdx.x;
+    float4 t = red[0][c];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) { const float4 v = red[w][c]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+    float* o = out + (int64_t)(blockIdx.x * 16 + c) * 4;
     if (accumulate) {
-      const float4 o = reinterpret_cast<float4*>(out)[c4];
-      t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+      const float4 p = *reinterpret_cast<float4*>(o);
+      t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
     }
-    reinterpret_cast<float4*>(out)[c4] = t;
+    *reinterpret_cast<float4*>(o) = t;
   }
 }
 
@@ -422,7 +439,7 @@ __global__ void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __re
 // up to three outputs reduced from partial[q][splits][n] in one launch (n % 4 == 0)
 int launch_reduce_cols(const float* partial, float* out0, float* out1, float* out2, int nq, int splits, int n, int accumulate,
                        hipStream_t st) {
-  hipLaunchKernelGGL(reduce_cols_kernel, dim3((n / 4 + 63) / 64, nq), dim3(1024), 0, st, partial, out0, out1, out2, splits, n, accumulate,
+  hipLaunchKernelGGL(reduce_cols_kernel, dim3((n / 4 + 15) / 16, nq), dim3(1024), 0, st, partial, out0, out1, out2, splits, n, accumulate,
                      (int64_t)splits * n, n);
   return check_launch("reduce_cols");
 }
@@ -430,7 +447,7 @@ int launch_reduce_cols(const float* partial, float* out0, float* out1, float* ou
 // two column ranges [c0, c0 + n) and [c1, c1 + n) of partial[splits][N] reduced into out0 / out1 in one launch (n, c0, c1, N % 4 == 0)
 int launch_reduce_col_ranges(const float* partial, int N, int splits, int c0, float* out0, int c1, float* out1, int n, int accumulate,
                              hipStream_t st) {
-  hipLaunchKernelGGL(reduce_cols_kernel, dim3((n / 4 + 63) / 64, 2), dim3(1024), 0, st, partial + c0, out0, out1, nullptr, splits, n, accumulate,
+  hipLaunchKernelGGL(reduce_cols_kernel, dim3((n / 4 + 15) / 16, 2), dim3(1024), 0, st, partial + c0, out0, out1, nullptr, splits, n, accumulate,
                      (int64_t)(c1 - c0), N);
   return check_launch("reduce_col_ranges");
 }
