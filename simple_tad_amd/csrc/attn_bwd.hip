@@ -80,13 +80,17 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int s2) {
 // first matrix instruction).  1: spread into the tile -- issuing a piece blocks the wave for 60-185 cycles depending on what else the
 // phase carries (MI355X_MICROARCH.md, 'LDS-DMA piece issue cost'), cheapest in VALU-only stretches.  2: ablation, no DMA inside the loop
 // (every tile reads the first one: wrong results, timing only; refused outside ablation builds).
-template <int DMA_MODE>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out,
+// NST (tad_attn_tuning("stages")): depth of the K/V (Q/dO) tile ring.  2: the next tile is requested at the top of a tile and the end of the
+// tile waits for ALL of it (s_waitcnt vmcnt(0)): whatever part of its latency the tile's arithmetic did not cover is exposed.  3: the
+// tile after next is requested instead and the end of the tile waits with a COUNTED vmcnt that leaves it in flight (raw s_barrier: a
+// __syncthreads() would drain the DMA), so a request has two tile times to land.
+template <int DMA_MODE, int NST>
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out,
                                                           const uint16_t* __restrict__ dout, const float* __restrict__ lse,
                                                           float* __restrict__ delta, uint16_t* __restrict__ dqkv, int N, int H, int B,
                                                           float scale) {
   constexpr int TILE_BYTES = 64 * 128;
-  __shared__ __attribute__((aligned(1024))) char lds[2 * 2 * TILE_BYTES];  // [buf][K|V]
+  __shared__ __attribute__((aligned(1024))) char lds[NST * 2 * TILE_BYTES];  // [buf][K|V]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nblk = (N + 127) / 128;  // 1-D XCD-aware grid: the blocks of one (batch, head) pair share an L2 (see attn_fwd.hip)
@@ -172,9 +176,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
 
   const int nt = (N + 63) / 64;
   DMA_KV(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  // the tile loop runs in pairs so that the LDS buffer index is a literal in each copy of the body: every LDS address is then a
+  if (NST == 3 && nt > 1) {
+    DMA_KV(1, 64);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // tile 0 landed (this wave's 4 pieces of tile 1 may still be in flight)
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  // the tile loop runs in pairs (triples with three stages) so that the LDS buffer index is a literal in each copy of the body: every LDS address is then a
   // lane constant + immediate instead of a handful of v_add / v_or per fragment read
   uint32_t ktr[2][2];  // K^T fragment addresses (tile 0 of buffer 0), [d tile][first / second read]
   tr_dual_addr(lds_addr(lds), 0, lane, ktr[0]);
@@ -182,10 +193,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
   auto dq_tile = [&](auto BUFC, int t) {
     constexpr int BUF = decltype(BUFC)::value;
     const int kv0 = t * 64;
-    const bool more = t + 1 < nt;
+    const bool more = NST == 3 ? (t + 2 < nt) : (t + 1 < nt);  // is there a tile to request during this one?
+    constexpr int NBUF = NST == 3 ? (BUF + 2) % 3 : (BUF ^ 1);  // its buffer ...
+    const int nkv0 = NST == 3 ? kv0 + 128 : kv0 + 64;           // ... and first key
     // (the second half of a tile is skipped only in the LAST tile, where nothing is staged any more: a live wave that has to stage
     // runs both halves, so DMA_MODE 1 may hang its pieces on them)
-    if (more && (DMA_MODE == 0 || (DMA_MODE == 1 && !wave_live))) DMA_KV(BUF ^ 1, kv0 + 64);
+    if (more && (DMA_MODE == 0 || (DMA_MODE == 1 && !wave_live))) DMA_KV(NBUF, nkv0);
     const char* kl = lds + BUF * 2 * TILE_BYTES;
     const char* vl = kl + TILE_BYTES;
     // a wave whose 32 query rows all lie past the sequence (the last block of N = 1568 has one live wave of four) only helps
@@ -224,7 +237,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
       }
       if constexpr (DMA_MODE == 1) {  // next tile's K pieces behind the first half's score products, V pieces behind the second's
         if (more) {
-          if constexpr (kt == 0) DMA_K_(BUF ^ 1, kv0 + 64) else DMA_V_(BUF ^ 1, kv0 + 64)
+          if constexpr (kt == 0) DMA_K_(NBUF, nkv0) else DMA_V_(NBUF, nkv0)
         }
       }
       f32x16 ds;
@@ -243,12 +256,29 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
         for (int dt = 0; dt < 2; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_tr(tl[1][dt], th[1][dt]), dsf, dq[dt], 0, 0, 0);
       }
     });
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (NST == 3) {
+      // the next tile (requested one tile ago) must have landed; the one requested during this tile (4 pieces per wave) stays in flight
+      if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
   };
-  for (int t = 0; t < nt; t += 2) {
-    dq_tile(std::integral_constant<int, 0>{}, t);
-    if (t + 1 < nt) dq_tile(std::integral_constant<int, 1>{}, t + 1);
+  if constexpr (NST == 3) {
+    for (int t = 0; t < nt; t += 3) {
+      dq_tile(std::integral_constant<int, 0>{}, t);
+      if (t + 1 < nt) dq_tile(std::integral_constant<int, 1>{}, t + 1);
+      if (t + 2 < nt) dq_tile(std::integral_constant<int, 2>{}, t + 2);
+    }
+  } else {
+    for (int t = 0; t < nt; t += 2) {
+      dq_tile(std::integral_constant<int, 0>{}, t);
+      if (t + 1 < nt) dq_tile(std::integral_constant<int, 1>{}, t + 1);
+    }
   }
 
   if (qvalid) {
@@ -267,13 +297,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
-template <int DMA_MODE>
+template <int DMA_MODE, int NST>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
                                                            const float* __restrict__ rowc_g, uint16_t* __restrict__ dqkv, int N, int H, int B,
                                                            float scale, unsigned long long* stamps) {
   constexpr int TILE_BYTES = 64 * 128;
   constexpr int STAGE = 2 * TILE_BYTES + 512;  // Q tile, dO tile, 64 x (-lse/scale), 64 x (-delta)
-  __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
+  __shared__ __attribute__((aligned(1024))) char lds[NST * STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nblk = (N + 127) / 128;  // 1-D XCD-aware grid (see attn_fwd.hip)
@@ -358,18 +388,30 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
 
   const int nt = (N + 63) / 64;
   LOAD_QDO(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  if (NST == 3 && nt > 1) {
+    LOAD_QDO(1, 64);
+    // tile 0 landed; this wave's pieces of tile 1 (4, and the row constants from waves 0 and 1) may still be in flight
+    if (wave < 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
 #ifdef TAD_GEMM_ABLATION  // diagnostic builds only (tad_attn_debug_stamps): shader clock / 100 MHz clock around the tile loop
   if (stamps && tid == 0) {
     stamps[(size_t)blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memrealtime();
     stamps[(size_t)blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
   }
 #endif
+  int cur = 0;  // ring slot of tile t
   for (int t = 0; t < nt; ++t) {
-    const bool more = t + 1 < nt;
-    if (more && (DMA_MODE == 0 || (DMA_MODE == 1 && !wave_live))) LOAD_QDO((t + 1) & 1, (t + 1) * 64);
-    const uint32_t so = (uint32_t)((t & 1) * STAGE);
+    const bool more = NST == 3 ? (t + 2 < nt) : (t + 1 < nt);           // is there a tile to request during this one?
+    const int nbuf = NST == 3 ? (cur == 0 ? 2 : cur - 1) : (cur ^ 1);    // its ring slot ((t + 2) % 3 resp. (t + 1) % 2) ...
+    const int nq0 = NST == 3 ? (t + 2) * 64 : (t + 1) * 64;             // ... and first query row
+    if (more && (DMA_MODE == 0 || (DMA_MODE == 1 && !wave_live))) LOAD_QDO(nbuf, nq0);
+    const uint32_t so = (uint32_t)(cur * STAGE);
     if (wave_live)  // (see the dQ kernel: waves whose 32 keys all lie past the sequence only stage tiles)
     static_for<0, 2>([&](auto qtc) {
       constexpr int qt = decltype(qtc)::value;
@@ -422,7 +464,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
       TR_ISSUE(1);
       if constexpr (DMA_MODE == 1) {  // next tile: Q pieces behind the first half's score products, dO + row constants behind the second's
         if (more) {
-          if constexpr (qt == 0) LOAD_Q_((t + 1) & 1, (t + 1) * 64) else LOAD_DO_RC_((t + 1) & 1, (t + 1) * 64)
+          if constexpr (qt == 0) LOAD_Q_(nbuf, nq0) else LOAD_DO_RC_(nbuf, nq0)
         }
       }
       f32x16 pm, ds;
@@ -442,8 +484,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
 #undef TR_ISSUE
 #undef TR_MFMA
     });
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (NST == 3) {
+      if (more) {
+        if (wave < 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      cur = cur == 2 ? 0 : cur + 1;
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      cur ^= 1;
+    }
   }
 
 #ifdef TAD_GEMM_ABLATION
@@ -477,6 +533,7 @@ using namespace tad;
 
 static unsigned long long* g_attn_stamps = nullptr;
 int g_attn_dma_mode = getenv("TAD_ATTN_DMA_MODE") ? atoi(getenv("TAD_ATTN_DMA_MODE")) : 0;  // shared with attn_fwd.hip
+static int g_attn_bwd_stages = getenv("TAD_ATTN_BWD_STAGES") ? atoi(getenv("TAD_ATTN_BWD_STAGES")) : 2;
 
 extern "C" int tad_attn_tuning(const char* key, int value) {
   TAD_REQUIRE(key, "attn_tuning: null key");
@@ -487,6 +544,11 @@ extern "C" int tad_attn_tuning(const char* key, int value) {
     TAD_REQUIRE(value >= 0 && value <= 1, "attn_tuning: dma_mode=%d not in 0..1 (2 = timing-only ablation, ablation builds)", value);
 #endif
     g_attn_dma_mode = value;
+    return TAD_OK;
+  }
+  if (!strcmp(key, "bwd_stages")) {
+    TAD_REQUIRE(value == 2 || value == 3, "attn_tuning: bwd_stages=%d not in {2, 3}", value);
+    g_attn_bwd_stages = value;
     return TAD_OK;
   }
   set_error("attn_tuning: unknown key '%s'", key);
@@ -519,18 +581,19 @@ extern "C" int tad_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)(((N + 127) / 128) * H * B)), block(256);
   const int mode = g_attn_dma_mode;
-#define LAUNCH_BWD(M_)                                                                                                              \
+#define LAUNCH_BWD(M_, S_)                                                                                                          \
   {                                                                                                                                 \
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<M_>, grid, block, 0, st, qkv, out, dout, lse, delta, dqkv, N, H, B, scale);               \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<M_, S_>), grid, block, 0, st, qkv, out, dout, lse, delta, dqkv, N, H, B, scale);         \
     int rc = check_launch("attn_bwd_dq");                                                                                           \
     if (rc) return rc;                                                                                                              \
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<M_>, grid, block, 0, st, qkv, dout, delta, dqkv, N, H, B, scale, g_attn_stamps);         \
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<M_, S_>), grid, block, 0, st, qkv, dout, delta, dqkv, N, H, B, scale, g_attn_stamps);   \
     return check_launch("attn_bwd_dkv");                                                                                            \
   }
-  if (mode == 1) LAUNCH_BWD(1)
+  if (g_attn_bwd_stages == 3) LAUNCH_BWD(0, 3)
+  if (mode == 1) LAUNCH_BWD(1, 2)
 #ifdef TAD_GEMM_ABLATION
-  if (mode == 2) LAUNCH_BWD(2)
+  if (mode == 2) LAUNCH_BWD(2, 2)
 #endif
-  LAUNCH_BWD(0)
+  LAUNCH_BWD(0, 2)
 #undef LAUNCH_BWD
 }
