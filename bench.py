@@ -39,7 +39,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU (weak scaling: fixed per-GPU work)")
+    ap.add_argument("--global-batch", type=int, default=0, help="strong scaling: fixed TOTAL clips per step, split over the ranks "
+                                                               "(SURVEY 8d cfg4: 256); overrides --batch")
     ap.add_argument("--model", default="vit_base_patch16_224")
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--mode", default="train", choices=["train", "fwd"])
@@ -174,6 +176,9 @@ def main():
 
     torch.manual_seed(0 + rank)  # per-rank data seed (run_class_finetuning.py:222)
     B = args.batch
+    if args.global_batch:
+        assert args.global_batch % world == 0, "--global-batch must be a multiple of the number of ranks"
+        B = args.global_batch // world
     x = torch.randn(B, 3, args.frames, 224, 224, device=dev)
     y = torch.randint(0, 2, (B,), device=dev)
     total_steps = args.steps + args.warmup + 64  # (+ the un-timed extra steps after the region)
@@ -281,7 +286,8 @@ def main():
     out = {
         "metric": "clips/sec (16x224^2 ViT-B) " + ("fwd+bwd" if args.mode == "train" else "forward"),
         "value": round(clips_per_s, 2), "unit": "clips/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak",
+        "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"{args.model} {args.frames}x224x224, {B} clips/GPU, " +
                                ("fwd+bwd+AdamW fine-tune step with CE loss on synthetic labels (BASELINE configs[2]/[3])"
