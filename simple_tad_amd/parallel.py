@@ -156,6 +156,9 @@ class DataParallel(nn.Module):
         # read the bucket before the kernels queued on the current stream had written it: drain the stream first.  RCCL ("nccl")
         # orders its kernels after the current stream itself.
         self._drain_first = bool(dist.is_initialized() and dist.get_backend(self.pg) == "gloo" and self.flat_grad.is_cuda)
+        # RCCL averages inside the collective (ncclAvg): no separate pass over the bucket; gloo has no AVG, so there the bucket is
+        # divided by the world size first (which also keeps the sum in range)
+        self._avg_in_collective = bool(dist.is_initialized() and dist.get_backend(self.pg) == "nccl")
         self._announced = set()
         self._sunk = set()
         self._works = []
@@ -190,10 +193,16 @@ class DataParallel(nn.Module):
         if b["ready"] == b["n"]:
             b["ready"] = 0
             view = self.flat_grad[b["lo"]:b["hi"]]
-            view.div_(self.world)  # mean; pre-division keeps the sum in range and works for gloo (no AVG op)
-            if self._drain_first:
-                torch.cuda.current_stream().synchronize()
-            self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            self._works.append(self._exchange(view, async_op=True))
+
+    def _exchange(self, view, async_op):
+        """mean over the ranks of one bucket, in place"""
+        if self._avg_in_collective:
+            return dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.pg, async_op=async_op)
+        view.div_(self.world)
+        if self._drain_first:
+            torch.cuda.current_stream().synchronize()
+        return dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op)
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
@@ -210,11 +219,7 @@ class DataParallel(nn.Module):
         for b in self.buckets:  # a parameter that received no gradient this step leaves its bucket incomplete
             if b["ready"] or not self.overlap:
                 b["ready"] = 0
-                view = self.flat_grad[b["lo"]:b["hi"]]
-                view.div_(self.world)
-                if self._drain_first:
-                    torch.cuda.current_stream().synchronize()
-                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg)
+                self._exchange(self.flat_grad[b["lo"]:b["hi"]], async_op=False)
 
     def zero_grad(self, set_to_none: bool = False):
         """Gradients are views into the flat buffer and must stay allocated: zero in place.  Difference from the reference's
