@@ -158,7 +158,14 @@ class DataParallel(nn.Module):
         self._drain_first = bool(dist.is_initialized() and dist.get_backend(self.pg) == "gloo" and self.flat_grad.is_cuda)
         # RCCL averages inside the collective (ncclAvg): no separate pass over the bucket; gloo has no AVG, so there the bucket is
         # divided by the world size first (which also keeps the sum in range)
-        self._avg_in_collective = bool(dist.is_initialized() and dist.get_backend(self.pg) == "nccl")
+        self._avg_in_collective = False
+        if dist.is_initialized() and dist.get_backend(self.pg) == "nccl" and self.flat_grad.is_cuda:
+            try:  # probed once on every rank (a collective): an RCCL / torch build without AVG falls back to divide-then-sum
+                probe = torch.ones(1, dtype=torch.float32, device=self.flat_grad.device)
+                dist.all_reduce(probe, op=dist.ReduceOp.AVG, group=self.pg)
+                self._avg_in_collective = abs(float(probe.item()) - 1.0) < 1e-6
+            except Exception:  # noqa: BLE001
+                self._avg_in_collective = False
         self._announced = set()
         self._sunk = set()
         self._works = []

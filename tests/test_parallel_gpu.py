@@ -203,3 +203,38 @@ def test_rccl_c_abi_two_ranks():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res)
+
+
+def _nccl_world1(q):
+    """one rank over the REAL nccl (= RCCL) backend on cuda:0: process-group creation through init_distributed_mode, DataParallel's
+    probe of ReduceOp.AVG and its bucket exchange (an identity with one rank) -- the RCCL code path that the two-rank tests cannot
+    reach on a one-GPU box"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from simple_tad_amd.parallel import DataParallel
+    dist.init_process_group(backend="nccl", init_method="env://", world_size=1, rank=0, device_id=torch.device("cuda", 0))
+    try:
+        torch.cuda.set_device(0)
+        m = _model(seed=3).cuda()
+        dp = DataParallel(m, bucket_mb=0.25)
+        g = torch.randn_like(dp.flat_grad)
+        dp.flat_grad.copy_(g)
+        works = [dp._exchange(dp.flat_grad[b["lo"]:b["hi"]], async_op=True) for b in dp.buckets]
+        for w in works:
+            w.wait()
+        torch.cuda.synchronize()
+        q.put((dist.get_backend(), bool(dp._avg_in_collective), torch.equal(dp.flat_grad, g), len(dp.buckets)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_nccl_backend_single_rank_bucket_exchange():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_world1, args=(q,))
+    p.start()
+    backend, avg, same, nb = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0 and backend == "nccl" and same and nb >= 3
+    print("ReduceOp.AVG inside the RCCL collective:", avg)
