@@ -445,9 +445,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
     dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_tr(dol[s2_][dt], doh[s2_][dt]), pf_, dv[dt], 0, 0, 0);               \
     dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_tr(qtl[s2_][dt], qth[s2_][dt]), dsf_, dk[dt], 0, 0, 0);              \
   }
-      TR_ISSUE(0);
-      lds_wait<16>(si[0], si[1], si[2], si[3], di[0], di[1], di[2], di[3]);  // (the counter saturates at 15: this also covers the row fragments)
-      lds_wait<8>(qa[0], qa[1], qa[2], qa[3], da[0], da[1], da[2], da[3]);
+      if constexpr (DMA_MODE != 3) {
+        TR_ISSUE(0);
+        lds_wait<16>(si[0], si[1], si[2], si[3], di[0], di[1], di[2], di[3]);  // (the counter saturates at 15: this also covers the row fragments)
+        lds_wait<8>(qa[0], qa[1], qa[2], qa[3], da[0], da[1], da[2], da[3]);
+      } else {  // ablation (timing only): no transposed reads at all -- how much of the kernel is LDS read traffic?
+        lds_wait<0>(si[0], si[1], si[2], si[3], di[0], di[1], di[2], di[3]);
+        lds_wait<0>(qa[0], qa[1], qa[2], qa[3], da[0], da[1], da[2], da[3]);
+      }
       f32x16 s, dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[r] = si[r >> 2][r & 3]; dp[r] = di[r >> 2][r & 3]; }
@@ -461,7 +466,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks], kfr[ks], s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[ks], vfr[ks], dp, 0, 0, 0);
       }
-      TR_ISSUE(1);
+      if constexpr (DMA_MODE != 3) { TR_ISSUE(1); }
       if constexpr (DMA_MODE == 1) {  // next tile: Q pieces behind the first half's score products, dO + row constants behind the second's
         if (more) {
           if constexpr (qt == 0) LOAD_Q_(nbuf, nq0) else LOAD_DO_RC_(nbuf, nq0)
@@ -473,13 +478,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
         pm[r] = fast_exp2(s[r] * c);
         ds[r] = pm[r] * dp[r];
       }
-      {
-        const bf16x8 pf = pack8(pm, 0), dsf = pack8(ds, 0);
-        TR_MFMA(0, 8, pf, dsf);
-      }
-      {
-        const bf16x8 pf = pack8(pm, 1), dsf = pack8(ds, 1);
-        TR_MFMA(1, 0, pf, dsf);
+      if constexpr (DMA_MODE != 3) {
+        {
+          const bf16x8 pf = pack8(pm, 0), dsf = pack8(ds, 0);
+          TR_MFMA(0, 8, pf, dsf);
+        }
+        {
+          const bf16x8 pf = pack8(pm, 1), dsf = pack8(ds, 1);
+          TR_MFMA(1, 0, pf, dsf);
+        }
+      } else {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8 pf = pack8(pm, s2), dsf = pack8(ds, s2);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[2 * s2 + dt], pf, dv[dt], 0, 0, 0);
+            dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[2 * s2 + dt], dsf, dk[dt], 0, 0, 0);
+          }
+        }
       }
 #undef TR_ISSUE
 #undef TR_MFMA
@@ -539,7 +556,7 @@ extern "C" int tad_attn_tuning(const char* key, int value) {
   TAD_REQUIRE(key, "attn_tuning: null key");
   if (!strcmp(key, "dma_mode")) {
 #ifdef TAD_GEMM_ABLATION
-    TAD_REQUIRE(value >= 0 && value <= 2, "attn_tuning: dma_mode=%d not in 0..2", value);
+    TAD_REQUIRE(value >= 0 && value <= 3, "attn_tuning: dma_mode=%d not in 0..3", value);
 #else
     TAD_REQUIRE(value >= 0 && value <= 1, "attn_tuning: dma_mode=%d not in 0..1 (2 = timing-only ablation, ablation builds)", value);
 #endif
@@ -593,6 +610,7 @@ extern "C" int tad_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint
   if (mode == 1) LAUNCH_BWD(1, 2)
 #ifdef TAD_GEMM_ABLATION
   if (mode == 2) LAUNCH_BWD(2, 2)
+  if (mode == 3) LAUNCH_BWD(3, 2)  // (dQ kernel: as mode 0; dK/dV kernel: no transposed LDS reads)
 #endif
   LAUNCH_BWD(0, 2)
 #undef LAUNCH_BWD
