@@ -544,6 +544,262 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
   }
 }
 
+// ---- 64 keys per wave, ONE wave per SIMD (tad_attn_tuning("dkv_keys", 64)).  The 32-key kernel above re-reads every Q / dO tile from the LDS
+// once per 32 keys (row fragments, transposed fragments and the row constants: 96 LDS cycles per half tile and wave against 512 matrix
+// cycles; rocprofv3: LDS array 34 % busy at 45 % matrix-pipe utilisation, 13.6 % of the wave lifetime stalled at LDS issue; without
+// its transposed reads -- ablation mode 3 -- the kernel runs 26 % faster).  Here a wave pins the K / V fragments of TWO 32-key groups
+// and every fragment read from the LDS feeds both, which halves the LDS traffic per MFMA; that takes ~300 registers, i.e. one wave per
+// SIMD (4-wave workgroups of 256 keys, one per CU), and the overlap of matrix and vector work then has to come from inside the wave: the
+// score products of both groups are issued before the exponentials of the first, the dV / dK products of the first before the
+// exponentials of the second.
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
+                                                           const float* __restrict__ rowc_g, uint16_t* __restrict__ dqkv, int N, int H, int B,
+                                                           float scale, unsigned long long* stamps) {
+  constexpr int TILE_BYTES = 64 * 128;
+  constexpr int STAGE = 2 * TILE_BYTES + 512;  // Q tile, dO tile, 64 x (-lse/scale), 64 x (-delta)
+  constexpr int NST = 2, DMA_MODE = 0;
+  __shared__ __attribute__((aligned(1024))) char lds[NST * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nblk = (N + 255) / 256;  // 1-D XCD-aware grid (see attn_fwd.hip)
+  const int lin = xcd_remap(blockIdx.x, gridDim.x);
+  const int head = (lin / nblk) % H, b = lin / nblk / H;
+  const int key0 = (lin % nblk) * 256 + wave * 64;  // the wave's two key groups: key0 + 32 g + (lane & 31)
+  const int kl_ = lane & 31, h5 = lane >> 5;
+  const int64_t tok = (int64_t)3 * H * BHD;
+  const uint16_t* base = qkv + (int64_t)b * N * tok + head * BHD;
+  const uint16_t* kbase = base + (int64_t)H * BHD;
+  const uint16_t* vbase = base + (int64_t)2 * H * BHD;
+  const uint16_t* dobase = dout + ((int64_t)b * N * H + head) * BHD;  // row q at + q*H*64
+  const float c = scale * LOG2E;
+
+  const bool wave_live = key0 < N;        // wave-uniform
+  const bool g1_live = key0 + 32 < N;     // wave-uniform: the second key group has keys inside the sequence
+  bf16x8 kfr[2][4], vfr[2][4];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    int krow = key0 + 32 * g + kl_;
+    if (krow > N - 1) krow = N - 1;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      kfr[g][ks] = *reinterpret_cast<const bf16x8*>(kbase + (int64_t)krow * tok + 16 * ks + 8 * h5);
+      vfr[g][ks] = *reinterpret_cast<const bf16x8*>(vbase + (int64_t)krow * tok + 16 * ks + 8 * h5);
+    }
+  }
+
+  // Q / dO tiles go global -> LDS by LDS-DMA (1-KiB piece = 8 rows x 128 B, wave w moves pieces w and w+4 of each; swizzle on the
+  // per-lane SOURCE chunk); rows past the tensor read as zero, rows >= N are neutralised through the row constants below.
+  const uint32_t qkv_bytes = (uint32_t)B * (uint32_t)N * (uint32_t)tok * 2u;
+  const uint32_t do_bytes = (uint32_t)B * (uint32_t)N * (uint32_t)(H * BHD) * 2u;
+  const auto rs_qkv = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(qkv), 0, (int)qkv_bytes, 0x00020000);
+  const auto rs_do = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(dout), 0, (int)do_bytes, 0x00020000);
+  uint32_t dma_q[2], dma_do[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wave + 4 * i) * 8 + (lane >> 3);
+    const uint32_t ch = (uint32_t)(((lane & 7) ^ sw_dual(row)) << 4);
+    dma_q[i] = (uint32_t)(((int64_t)b * N + row) * tok * 2) + (uint32_t)(head * BHD * 2) + ch;
+    dma_do[i] = (uint32_t)((((int64_t)b * N + row) * H + head) * BHD * 2) + ch;
+  }
+  const uint32_t q_step = (uint32_t)(tok * 2), do_step = (uint32_t)(H * BHD * 2);
+  // Row constants (initial accumulator values, written by the dQ kernel): rows [0, BHN) of `rowc` hold -delta, rows [BHN, 2 BHN)
+  // hold -lse/scale.  They are staged by LDS-DMA as well (4 bytes per lane: wave 0 moves the 64 -lse/scale values of the tile,
+  // wave 1 the 64 -delta values), so the tile loop holds no ordinary global load and no LDS store -- with either of them in the loop
+  // the compiler drained the DMA of the next tile (s_waitcnt vmcnt(0)) right after issuing it.
+  const int64_t bhn = (int64_t)B * H * N;
+  const auto rs_rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rowc_g), 0, (int)(2 * bhn * 4), 0x00020000);
+  const uint32_t rc_off = (uint32_t)(((wave == 0 ? bhn : 0) + ((int64_t)b * H + head) * N + lane) * 4);
+#define LOAD_Q_(buf, q0)                                                                                   \
+  {                                                                                                        \
+    char* ql_ = lds + (buf) * STAGE;                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                          \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_qkv, LDS_PTR(ql_ + (wave + 4 * i) * 1024), 16, dma_q[i] + (uint32_t)(q0) * q_step, 0, 0, 0); \
+  }
+#define LOAD_DO_RC_(buf, q0)                                                                               \
+  {                                                                                                        \
+    char* ql_ = lds + (buf) * STAGE;                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                          \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_do, LDS_PTR(ql_ + TILE_BYTES + (wave + 4 * i) * 1024), 16, dma_do[i] + (uint32_t)(q0) * do_step, 0, 0, 0); \
+    if (wave < 2) /* wave-uniform */                                                                       \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_rc, LDS_PTR(ql_ + 2 * TILE_BYTES + wave * 256), 4, rc_off + (uint32_t)(q0) * 4u, 0, 0, 0); \
+  }
+#define LOAD_QDO(buf, q0) { LOAD_Q_(buf, q0); LOAD_DO_RC_(buf, q0); }
+
+  f32x16 dk[2][2], dv[2][2];  // [key group][d tile]
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dk[g][dt][r] = 0.f; dv[g][dt][r] = 0.f; }
+
+  // Every LDS read of the tile loop is inline asm (common.h): the compiler can then neither drain the DMA of the next tile in front
+  // of a read nor serialise read -> wait -> MFMA one fragment at a time; the reads of a half tile are issued in three batches and
+  // waited for where their consumers start.  Lane-constant addresses (stage 0); the stage offset is added per tile, the half
+  // tile / fragment position is an instruction immediate.
+  const uint32_t lds0 = lds_addr(lds);
+  uint32_t qtr[2][2];  // transposed fragments of the Q tile, [d tile][first / second read]; dO tile: + TILE_BYTES
+  tr_dual_addr(lds0, 0, lane, qtr[0]);
+  tr_dual_addr(lds0, 32, lane, qtr[1]);
+  uint32_t rfa[4];     // row fragments (row lane&31 of a half tile, chunk 2ks + h5) of the Q tile; dO tile: + TILE_BYTES
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) rfa[ks] = lds0 + (uint32_t)(kl_ * 128 + (((2 * ks + h5) ^ sw_dual(kl_)) << 4));
+  const uint32_t rca = lds0 + 2 * TILE_BYTES + 16 * h5;  // row constants: 4 floats at [8 r4 + 4 h5]
+
+  const int nt = (N + 63) / 64;
+  LOAD_QDO(0, 0);
+  if (NST == 3 && nt > 1) {
+    LOAD_QDO(1, 64);
+    // tile 0 landed; this wave's pieces of tile 1 (4, and the row constants from waves 0 and 1) may still be in flight
+    if (wave < 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#ifdef TAD_GEMM_ABLATION  // diagnostic builds only (tad_attn_debug_stamps): shader clock / 100 MHz clock around the tile loop
+  if (stamps && tid == 0) {
+    stamps[(size_t)blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+    stamps[(size_t)blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
+  }
+#endif
+  int cur = 0;  // ring slot of tile t
+  for (int t = 0; t < nt; ++t) {
+    const bool more = NST == 3 ? (t + 2 < nt) : (t + 1 < nt);           // is there a tile to request during this one?
+    const int nbuf = NST == 3 ? (cur == 0 ? 2 : cur - 1) : (cur ^ 1);    // its ring slot ((t + 2) % 3 resp. (t + 1) % 2) ...
+    const int nq0 = NST == 3 ? (t + 2) * 64 : (t + 1) * 64;             // ... and first query row
+    if (more && (DMA_MODE == 0 || (DMA_MODE == 1 && !wave_live))) LOAD_QDO(nbuf, nq0);
+    const uint32_t so = (uint32_t)(cur * STAGE);
+    if (wave_live)  // (see the dQ kernel: waves whose 32 keys all lie past the sequence only stage tiles)
+    static_for<0, 2>([&](auto qtc) {
+      constexpr int qt = decltype(qtc)::value;
+      constexpr int HT = qt * 32 * 128;  // byte offset of the half tile inside a tile
+      if (t * 64 + 32 * qt >= N) return;  // half tile of query rows past the sequence: P = dS = 0 there anyway
+      // batch 1: initial accumulators (per-row constants; accumulator register r <-> row (r&3) + 8*(r>>2) + 4*h5) and row fragments
+      f32x4 si[4], di[4];
+      bf16x8 qa[4], da[4];
+      static_for<0, 4>([&](auto r4c) {
+        constexpr int r4 = decltype(r4c)::value;
+        si[r4] = lds_read_b128<f32x4, (qt * 32 + 8 * r4) * 4>(rca + so);
+        di[r4] = lds_read_b128<f32x4, 256 + (qt * 32 + 8 * r4) * 4>(rca + so);
+      });
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        qa[ks] = lds_read_b128<bf16x8, HT>(rfa[ks] + so);
+        da[ks] = lds_read_b128<bf16x8, TILE_BYTES + HT>(rfa[ks] + so);
+      }
+      // batch 2 / 3: transposed fragments for the dV / dK products of rows 0..15 / 16..31 of the half tile
+      s16x4 dol[2][2], doh[2][2], qtl[2][2], qth[2][2];  // [s2][dt]
+#define TR_ISSUE(s2_)                                                                         \
+  _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) {                                          \
+    dol[s2_][dt] = lds_tr16_b64<TILE_BYTES + HT + 16 * (s2_) * 128>(qtr[dt][0] + so);         \
+    doh[s2_][dt] = lds_tr16_b64<TILE_BYTES + HT + 16 * (s2_) * 128>(qtr[dt][1] + so);         \
+    qtl[s2_][dt] = lds_tr16_b64<HT + 16 * (s2_) * 128>(qtr[dt][0] + so);                      \
+    qth[s2_][dt] = lds_tr16_b64<HT + 16 * (s2_) * 128>(qtr[dt][1] + so);                      \
+  }
+      if constexpr (DMA_MODE != 3) {
+        TR_ISSUE(0);
+        lds_wait<16>(si[0], si[1], si[2], si[3], di[0], di[1], di[2], di[3]);  // (the counter saturates at 15: this also covers the row fragments)
+        lds_wait<8>(qa[0], qa[1], qa[2], qa[3], da[0], da[1], da[2], da[3]);
+      }
+      f32x16 s[2], dp[2];
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[g][r] = si[r >> 2][r & 3]; dp[g][r] = di[r >> 2][r & 3]; }
+      if (t * 64 + 32 * qt + 32 > N) {  // ragged half tile (N % 32 != 0): rows >= N get exp2(c*(s - 3e30)) = 0 and delta = 0
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (t * 64 + 32 * qt + (r & 3) + 8 * (r >> 2) + 4 * h5 >= N) { s[0][r] = s[1][r] = -3.0e30f; dp[0][r] = dp[1][r] = 0.f; }
+      }
+      // score products of both key groups first (16 MFMAs): the exponentials of group 0 then run beside the tail of this block and
+      // beside the dV / dK products of ... nothing yet, so the compiler is free to start them as soon as s[0] / dp[0] are complete
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        if (g == 1 && !g1_live) continue;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          s[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks], kfr[g][ks], s[g], 0, 0, 0);
+          dp[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[ks], vfr[g][ks], dp[g], 0, 0, 0);
+        }
+      }
+      TR_ISSUE(1);
+      bf16x8 pf[2][2], dsf[2][2];  // [key group][s2]
+      {
+        f32x16 pm, ds;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { pm[r] = fast_exp2(s[0][r] * c); ds[r] = pm[r] * dp[0][r]; }
+        pf[0][0] = pack8(pm, 0); pf[0][1] = pack8(pm, 1); dsf[0][0] = pack8(ds, 0); dsf[0][1] = pack8(ds, 1);
+      }
+      lds_wait<8>(dol[0][0], doh[0][0], qtl[0][0], qth[0][0], dol[0][1], doh[0][1], qtl[0][1], qth[0][1]);
+      bf16x8 dot_[2][2], qt_[2][2];  // [s2][dt] joined transposed fragments (shared by both key groups)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) { dot_[0][dt] = join_tr(dol[0][dt], doh[0][dt]); qt_[0][dt] = join_tr(qtl[0][dt], qth[0][dt]); }
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {  // group 0, rows 0..15 of the half tile
+        dv[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot_[0][dt], pf[0][0], dv[0][dt], 0, 0, 0);
+        dk[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt_[0][dt], dsf[0][0], dk[0][dt], 0, 0, 0);
+      }
+      if (g1_live) {
+        f32x16 pm, ds;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { pm[r] = fast_exp2(s[1][r] * c); ds[r] = pm[r] * dp[1][r]; }
+        pf[1][0] = pack8(pm, 0); pf[1][1] = pack8(pm, 1); dsf[1][0] = pack8(ds, 0); dsf[1][1] = pack8(ds, 1);
+      }
+      lds_wait<0>(dol[1][0], doh[1][0], qtl[1][0], qth[1][0], dol[1][1], doh[1][1], qtl[1][1], qth[1][1]);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) { dot_[1][dt] = join_tr(dol[1][dt], doh[1][dt]); qt_[1][dt] = join_tr(qtl[1][dt], qth[1][dt]); }
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {  // group 0, rows 16..31
+        dv[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot_[1][dt], pf[0][1], dv[0][dt], 0, 0, 0);
+        dk[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt_[1][dt], dsf[0][1], dk[0][dt], 0, 0, 0);
+      }
+      if (g1_live) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            dv[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot_[s2][dt], pf[1][s2], dv[1][dt], 0, 0, 0);
+            dk[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt_[s2][dt], dsf[1][s2], dk[1][dt], 0, 0, 0);
+          }
+      }
+#undef TR_ISSUE
+    });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+
+#ifdef TAD_GEMM_ABLATION
+  if (stamps && tid == 0) {
+    stamps[(size_t)blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+    stamps[(size_t)blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime();
+  }
+#endif
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int krow = key0 + 32 * g + kl_;
+    if (krow >= N) continue;
+    uint16_t* okp = dqkv + ((int64_t)b * N + krow) * tok + (int64_t)H * BHD + head * BHD;
+    uint16_t* ovp = okp + (int64_t)H * BHD;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int d = dt * 32 + 8 * r4 + 4 * h5;
+        uint2 pk, pv;
+        pk.x = pack_bf16x2(dk[g][dt][4 * r4 + 0] * scale, dk[g][dt][4 * r4 + 1] * scale);
+        pk.y = pack_bf16x2(dk[g][dt][4 * r4 + 2] * scale, dk[g][dt][4 * r4 + 3] * scale);
+        pv.x = pack_bf16x2(dv[g][dt][4 * r4 + 0], dv[g][dt][4 * r4 + 1]);
+        pv.y = pack_bf16x2(dv[g][dt][4 * r4 + 2], dv[g][dt][4 * r4 + 3]);
+        *reinterpret_cast<uint2*>(okp + d) = pk;
+        *reinterpret_cast<uint2*>(ovp + d) = pv;
+      }
+  }
+}
+
 }  // namespace tad
 
 using namespace tad;
@@ -551,6 +807,7 @@ using namespace tad;
 static unsigned long long* g_attn_stamps = nullptr;
 int g_attn_dma_mode = getenv("TAD_ATTN_DMA_MODE") ? atoi(getenv("TAD_ATTN_DMA_MODE")) : 0;  // shared with attn_fwd.hip
 static int g_attn_bwd_stages = getenv("TAD_ATTN_BWD_STAGES") ? atoi(getenv("TAD_ATTN_BWD_STAGES")) : 2;
+static int g_attn_dkv_keys = getenv("TAD_ATTN_DKV_KEYS") ? atoi(getenv("TAD_ATTN_DKV_KEYS")) : 32;  // keys per wave of the dK/dV kernel
 
 extern "C" int tad_attn_tuning(const char* key, int value) {
   TAD_REQUIRE(key, "attn_tuning: null key");
@@ -561,6 +818,11 @@ extern "C" int tad_attn_tuning(const char* key, int value) {
     TAD_REQUIRE(value >= 0 && value <= 1, "attn_tuning: dma_mode=%d not in 0..1 (2 = timing-only ablation, ablation builds)", value);
 #endif
     g_attn_dma_mode = value;
+    return TAD_OK;
+  }
+  if (!strcmp(key, "dkv_keys")) {
+    TAD_REQUIRE(value == 32 || value == 64, "attn_tuning: dkv_keys=%d not in {32, 64}", value);
+    g_attn_dkv_keys = value;
     return TAD_OK;
   }
   if (!strcmp(key, "bwd_stages")) {
@@ -598,6 +860,14 @@ extern "C" int tad_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)(((N + 127) / 128) * H * B)), block(256);
   const int mode = g_attn_dma_mode;
+  if (g_attn_dkv_keys == 64) {
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<0, 2>), grid, block, 0, st, qkv, out, dout, lse, delta, dqkv, N, H, B, scale);
+    int rc = check_launch("attn_bwd_dq");
+    if (rc) return rc;
+    const dim3 grid64((unsigned)(((N + 255) / 256) * H * B));
+    hipLaunchKernelGGL(attn_bwd_dkv64_kernel, grid64, block, 0, st, qkv, dout, delta, dqkv, N, H, B, scale, g_attn_stamps);
+    return check_launch("attn_bwd_dkv64");
+  }
 #define LAUNCH_BWD(M_, S_)                                                                                                          \
   {                                                                                                                                 \
     hipLaunchKernelGGL((attn_bwd_dq_kernel<M_, S_>), grid, block, 0, st, qkv, out, dout, lse, delta, dqkv, N, H, B, scale);         \
