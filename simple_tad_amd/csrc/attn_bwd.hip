@@ -704,67 +704,77 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(const uint16_t* 
         lds_wait<16>(si[0], si[1], si[2], si[3], di[0], di[1], di[2], di[3]);  // (the counter saturates at 15: this also covers the row fragments)
         lds_wait<8>(qa[0], qa[1], qa[2], qa[3], da[0], da[1], da[2], da[3]);
       }
-      f32x16 s[2], dp[2];
+      // the row constants are the C operand of the FIRST product of each group's chain (D goes to the group's own registers): no copies
+      f32x16 sinit, dinit, s[2], dp[2];
 #pragma unroll
-      for (int g = 0; g < 2; ++g)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s[g][r] = si[r >> 2][r & 3]; dp[g][r] = di[r >> 2][r & 3]; }
+      for (int r = 0; r < 16; ++r) { sinit[r] = si[r >> 2][r & 3]; dinit[r] = di[r >> 2][r & 3]; }
       if (t * 64 + 32 * qt + 32 > N) {  // ragged half tile (N % 32 != 0): rows >= N get exp2(c*(s - 3e30)) = 0 and delta = 0
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          if (t * 64 + 32 * qt + (r & 3) + 8 * (r >> 2) + 4 * h5 >= N) { s[0][r] = s[1][r] = -3.0e30f; dp[0][r] = dp[1][r] = 0.f; }
+          if (t * 64 + 32 * qt + (r & 3) + 8 * (r >> 2) + 4 * h5 >= N) { sinit[r] = -3.0e30f; dinit[r] = 0.f; }
       }
-      // score products of both key groups first (16 MFMAs): the exponentials of group 0 then run beside the tail of this block and
-      // beside the dV / dK products of ... nothing yet, so the compiler is free to start them as soon as s[0] / dp[0] are complete
+      // One wave per SIMD: matrix and vector work overlap only if they alternate in THIS wave's instruction stream, so the half tile is
+      // laid out in four regions and the scheduler is told the interleave (sched_group_barrier: mask 0x8 = MFMA, 0x2 = VALU):
+      //   A  score products of group 0                                   (8 MFMAs; the LDS reads of batch 2 are in flight)
+      //   B  score products of group 1  beside  exponentials of group 0  (8 x [1 MFMA, 8 VALU])
+      //   C  dV / dK products of group 0  beside  exponentials of group 1 (8 x [1 MFMA, 8 VALU])
+      //   D  dV / dK products of group 1                                 (8 MFMAs)
+      // A dead second group (only in the last workgroup of a sequence) is computed and dropped: no branch may split the regions.
 #pragma unroll
-      for (int g = 0; g < 2; ++g) {
-        if (g == 1 && !g1_live) continue;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          s[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks], kfr[g][ks], s[g], 0, 0, 0);
-          dp[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[ks], vfr[g][ks], dp[g], 0, 0, 0);
-        }
+      for (int ks = 0; ks < 4; ++ks) {  // A
+        s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks], kfr[0][ks], ks == 0 ? sinit : s[0], 0, 0, 0);
+        dp[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[ks], vfr[0][ks], ks == 0 ? dinit : dp[0], 0, 0, 0);
       }
       TR_ISSUE(1);
       bf16x8 pf[2][2], dsf[2][2];  // [key group][s2]
-      {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {  // B: matrix half
+        s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks], kfr[1][ks], ks == 0 ? sinit : s[1], 0, 0, 0);
+        dp[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[ks], vfr[1][ks], ks == 0 ? dinit : dp[1], 0, 0, 0);
+      }
+      {  // B: vector half
         f32x16 pm, ds;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { pm[r] = fast_exp2(s[0][r] * c); ds[r] = pm[r] * dp[0][r]; }
         pf[0][0] = pack8(pm, 0); pf[0][1] = pack8(pm, 1); dsf[0][0] = pack8(ds, 0); dsf[0][1] = pack8(ds, 1);
       }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+      }
       lds_wait<8>(dol[0][0], doh[0][0], qtl[0][0], qth[0][0], dol[0][1], doh[0][1], qtl[0][1], qth[0][1]);
+      lds_wait<0>(dol[1][0], doh[1][0], qtl[1][0], qth[1][0], dol[1][1], doh[1][1], qtl[1][1], qth[1][1]);
       bf16x8 dot_[2][2], qt_[2][2];  // [s2][dt] joined transposed fragments (shared by both key groups)
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt) { dot_[0][dt] = join_tr(dol[0][dt], doh[0][dt]); qt_[0][dt] = join_tr(qtl[0][dt], qth[0][dt]); }
+      for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {  // group 0, rows 0..15 of the half tile
-        dv[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot_[0][dt], pf[0][0], dv[0][dt], 0, 0, 0);
-        dk[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt_[0][dt], dsf[0][0], dk[0][dt], 0, 0, 0);
-      }
-      if (g1_live) {
+        for (int dt = 0; dt < 2; ++dt) { dot_[s2][dt] = join_tr(dol[s2][dt], doh[s2][dt]); qt_[s2][dt] = join_tr(qtl[s2][dt], qth[s2][dt]); }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)  // C: matrix half
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          dv[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot_[s2][dt], pf[0][s2], dv[0][dt], 0, 0, 0);
+          dk[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt_[s2][dt], dsf[0][s2], dk[0][dt], 0, 0, 0);
+        }
+      {  // C: vector half
         f32x16 pm, ds;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { pm[r] = fast_exp2(s[1][r] * c); ds[r] = pm[r] * dp[1][r]; }
         pf[1][0] = pack8(pm, 0); pf[1][1] = pack8(pm, 1); dsf[1][0] = pack8(ds, 0); dsf[1][1] = pack8(ds, 1);
       }
-      lds_wait<0>(dol[1][0], doh[1][0], qtl[1][0], qth[1][0], dol[1][1], doh[1][1], qtl[1][1], qth[1][1]);
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt) { dot_[1][dt] = join_tr(dol[1][dt], doh[1][dt]); qt_[1][dt] = join_tr(qtl[1][dt], qth[1][dt]); }
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {  // group 0, rows 16..31
-        dv[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot_[1][dt], pf[0][1], dv[0][dt], 0, 0, 0);
-        dk[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt_[1][dt], dsf[0][1], dk[0][dt], 0, 0, 0);
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 1);
       }
-      if (g1_live) {
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
+      for (int s2 = 0; s2 < 2; ++s2)  // D
 #pragma unroll
-          for (int dt = 0; dt < 2; ++dt) {
-            dv[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot_[s2][dt], pf[1][s2], dv[1][dt], 0, 0, 0);
-            dk[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt_[s2][dt], dsf[1][s2], dk[1][dt], 0, 0, 0);
-          }
-      }
+        for (int dt = 0; dt < 2; ++dt) {
+          dv[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot_[s2][dt], pf[1][s2], dv[1][dt], 0, 0, 0);
+          dk[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt_[s2][dt], dsf[1][s2], dk[1][dt], 0, 0, 0);
+        }
 #undef TR_ISSUE
     });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
