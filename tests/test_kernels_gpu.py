@@ -402,3 +402,23 @@ def test_linear_taller_than_the_32bit_epilogue_offsets(K):
     # bf16 output of the same shape stays ONE launch range (1.1 GB < 2 GiB with 2-byte elements): exercised for the cap arithmetic
     yb, _ = K.linear_fwd(x, w, b, out_dtype=torch.bfloat16)
     assert torch.equal(yb[-300:].float(), K.linear_fwd(x[-300:].contiguous(), w, b, out_dtype=torch.bfloat16)[0].float())
+
+
+def test_attention_schedule_variants_are_bit_identical(K):
+    """The scheduling variants of the attention kernels kept as tuning options (tad_attn_tuning: where the next tile's LDS-DMA pieces are
+    issued, a three-deep tile ring in the backward kernels, 64 keys per wave at one wave per SIMD in dK/dV) compute the same arithmetic
+    in the same order: outputs and gradients equal the default kernels' bit for bit, ragged N and dead waves included."""
+    B, N, H = 2, 1568, 2
+    qkv = bf(R.tensor_for("attv.qkv", (B * N, 3 * H * 64))).bfloat16().cuda()
+    dout = bf(R.tensor_for("attv.do", (B * N, H * 64))).bfloat16().cuda()
+    try:
+        K.attn_tuning(dma_mode=0, bwd_stages=2, dkv_keys=32)
+        out0, lse0 = K.attn_fwd(qkv, B, N, H, 0.125)
+        dq0 = K.attn_bwd(qkv, out0, dout, lse0, B, N, H, 0.125)
+        for cfg in (dict(dma_mode=1), dict(bwd_stages=3), dict(dkv_keys=64)):
+            K.attn_tuning(**{**dict(dma_mode=0, bwd_stages=2, dkv_keys=32), **cfg})
+            out, lse = K.attn_fwd(qkv, B, N, H, 0.125)
+            dq = K.attn_bwd(qkv, out0, dout, lse0, B, N, H, 0.125)
+            assert torch.equal(out, out0) and torch.equal(lse, lse0) and torch.equal(dq, dq0), cfg
+    finally:
+        K.attn_tuning(dma_mode=0, bwd_stages=2, dkv_keys=32)
