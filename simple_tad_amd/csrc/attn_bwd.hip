@@ -300,15 +300,10 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
 template <int DMA_MODE, int NST>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
                                                            const float* __restrict__ rowc_g, uint16_t* __restrict__ dqkv, int N, int H, int B,
-                                                           float scale, unsigned long long* stamps, int stagger) {
+                                                           float scale, unsigned long long* stamps) {
   constexpr int TILE_BYTES = 64 * 128;
   constexpr int STAGE = 2 * TILE_BYTES + 512;  // Q tile, dO tile, 64 x (-lse/scale), 64 x (-delta)
   __shared__ __attribute__((aligned(1024))) char lds[NST * STAGE];
-  // experiment (tad_attn_tuning("dkv_stagger"), default 0): every other workgroup starts `stagger` x 64 cycles late, so that the two
-  // workgroups that share a CU (one wave each per SIMD) are more likely to run their matrix and vector phases out of step
-  if (stagger > 0 && (blockIdx.x & 8)) {
-    for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(1);
-  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nblk = (N + 127) / 128;  // 1-D XCD-aware grid (see attn_fwd.hip)
@@ -823,7 +818,6 @@ static unsigned long long* g_attn_stamps = nullptr;
 int g_attn_dma_mode = getenv("TAD_ATTN_DMA_MODE") ? atoi(getenv("TAD_ATTN_DMA_MODE")) : 0;  // shared with attn_fwd.hip
 static int g_attn_bwd_stages = getenv("TAD_ATTN_BWD_STAGES") ? atoi(getenv("TAD_ATTN_BWD_STAGES")) : 2;
 static int g_attn_dkv_keys = getenv("TAD_ATTN_DKV_KEYS") ? atoi(getenv("TAD_ATTN_DKV_KEYS")) : 32;  // keys per wave of the dK/dV kernel
-static int g_attn_dkv_stagger = 0;
 
 extern "C" int tad_attn_tuning(const char* key, int value) {
   TAD_REQUIRE(key, "attn_tuning: null key");
@@ -834,11 +828,6 @@ extern "C" int tad_attn_tuning(const char* key, int value) {
     TAD_REQUIRE(value >= 0 && value <= 1, "attn_tuning: dma_mode=%d not in 0..1 (2 = timing-only ablation, ablation builds)", value);
 #endif
     g_attn_dma_mode = value;
-    return TAD_OK;
-  }
-  if (!strcmp(key, "dkv_stagger")) {
-    TAD_REQUIRE(value >= 0 && value <= 4096, "attn_tuning: dkv_stagger=%d out of range", value);
-    g_attn_dkv_stagger = value;
     return TAD_OK;
   }
   if (!strcmp(key, "dkv_keys")) {
@@ -894,8 +883,7 @@ extern "C" int tad_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint
     hipLaunchKernelGGL((attn_bwd_dq_kernel<M_, S_>), grid, block, 0, st, qkv, out, dout, lse, delta, dqkv, N, H, B, scale);         \
     int rc = check_launch("attn_bwd_dq");                                                                                           \
     if (rc) return rc;                                                                                                              \
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<M_, S_>), grid, block, 0, st, qkv, dout, delta, dqkv, N, H, B, scale, g_attn_stamps,    \
-                       g_attn_dkv_stagger);                                                                                         \
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<M_, S_>), grid, block, 0, st, qkv, dout, delta, dqkv, N, H, B, scale, g_attn_stamps);   \
     return check_launch("attn_bwd_dkv");                                                                                            \
   }
   if (g_attn_bwd_stages == 3) LAUNCH_BWD(0, 3)

@@ -20,7 +20,7 @@ ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--B", type=int, default=32)
 a = ap.parse_args()
-DEFAULTS = dict(dma_mode=0, bwd_stages=2, dkv_keys=32, dkv_stagger=0)
+DEFAULTS = dict(dma_mode=0, bwd_stages=2, dkv_keys=32)
 if a.configs:
     modes = [dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in c.split(",")) for c in a.configs.split(";")]
 else:
