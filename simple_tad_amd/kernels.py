@@ -327,6 +327,8 @@ def linear_fwd(x, w, bias=None, out_dtype=torch.bfloat16, epilogue=EPI_BIAS, wan
     """x [M,K] bf16, w [N,K] bf16 -> y [M,N]; returns (y, preact|None)"""
     _req(x, torch.bfloat16, "linear.x")
     _req(w, torch.bfloat16, "linear.w")
+    if x.shape[1] == w.shape[1] and x.shape[1] % 64:
+        x, w = _pad_reduction(x, w)  # reduction length off the 64-deep K-tile (a 1176-wide MAE decoder head of a /14 model): zero columns
     M, K = x.shape
     N, K2 = w.shape
     if K != K2:
@@ -345,6 +347,12 @@ def linear_fwd(x, w, bias=None, out_dtype=torch.bfloat16, epilogue=EPI_BIAS, wan
     return y, pre
 
 
+def _pad_reduction(a, b, mult: int = 64):
+    """zero-pad the shared last (reduction) dimension of two operands to a multiple of the GEMM's K-tile: the product is unchanged"""
+    pad = (-a.shape[1]) % mult
+    return torch.nn.functional.pad(a, (0, pad)).contiguous(), torch.nn.functional.pad(b, (0, pad)).contiguous()
+
+
 LINEAR_TUNING_DEFAULTS = dict(persistent=1, stagger_pct=0, stagger_group=1, direct_epilogue=1, split_tail=1, dynamic_tiles=0, group_m=0)
 
 
@@ -358,6 +366,8 @@ def linear_bwd_input(dy, wT, out_dtype=torch.bfloat16, gelu_preact=None):
     """dy [M,N] bf16, wT [K,N] bf16 -> dx [M,K]"""
     _req(dy, torch.bfloat16, "linear_bwd_input.dy")
     _req(wT, torch.bfloat16, "linear_bwd_input.wT")
+    if dy.shape[1] == wT.shape[1] and dy.shape[1] % 64:
+        dy, wT = _pad_reduction(dy, wT)
     M, N = dy.shape
     K, N2 = wT.shape
     assert N == N2, (N, N2)
