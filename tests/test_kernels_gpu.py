@@ -274,10 +274,27 @@ def test_errors_are_loud(K):
     from simple_tad_amd._lib import TadError
     with pytest.raises(TadError):
         K.cast_bf16(torch.zeros(8))  # CPU tensor: no fallback
-    with pytest.raises(TadError):
-        K.linear_fwd(torch.zeros(4, 60, dtype=torch.bfloat16, device="cuda"), torch.zeros(8, 60, dtype=torch.bfloat16, device="cuda"))
+    with pytest.raises(TadError, match="K=64 vs w K=128"):
+        K.linear_fwd(torch.zeros(4, 64, dtype=torch.bfloat16, device="cuda"), torch.zeros(8, 128, dtype=torch.bfloat16, device="cuda"))
+    from simple_tad_amd import _lib
+    a, b, y = (torch.zeros(n, dtype=torch.bfloat16, device="cuda") for n in (4 * 60, 8 * 60, 4 * 8))
+    rc = _lib.load().tad_linear_fwd(a.data_ptr(), b.data_ptr(), None, y.data_ptr(), 1, 0, None, None, None, None, 1, 4, 8, 60, None)
+    assert rc != 0 and b"multiple of 64" in _lib.load().tad_last_error_string()  # the C ABI itself keeps the K-tile contract; the wrapper pads (next test)
     with pytest.raises(TadError):
         K.attn_fwd(torch.zeros(4, 3 * 64, dtype=torch.bfloat16, device="cuda"), 1, 5, 1, 0.125)  # wrong element count
+
+
+def test_linear_reduction_off_the_k_tile_is_zero_padded(K):
+    """K=60 / K=1176 (MAE decoder head of a /14 model): the wrappers pad the reduction to the 64-deep K-tile, results unchanged"""
+    for Kd in (60, 1176):
+        x = R.tensor_for(f"padk.x{Kd}", (70, Kd)).to(torch.bfloat16)
+        w = R.tensor_for(f"padk.w{Kd}", (136, Kd), scale=0.05).to(torch.bfloat16)
+        y, _ = K.linear_fwd(dev(x), dev(w), None, out_dtype=torch.float32)
+        check(y, x.double() @ w.double().t(), tol=2e-5, what=f"linear K={Kd}")
+        dy = R.tensor_for(f"padk.dy{Kd}", (70, Kd)).to(torch.bfloat16)      # input gradient reduces over the layer's OUTPUT width
+        wT = R.tensor_for(f"padk.wT{Kd}", (128, Kd), scale=0.05).to(torch.bfloat16)
+        dx = K.linear_bwd_input(dev(dy), dev(wT), out_dtype=torch.float32)
+        check(dx, dy.double() @ wT.double().t(), tol=2e-5, what=f"linear dX N={Kd}")
 
 
 # ------------------------------------------------------------------ precise-mode kernels (parity gate): 1e-3 is met with margin
