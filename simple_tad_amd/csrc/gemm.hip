@@ -100,6 +100,9 @@ __device__ __forceinline__ void stage_tile(const void* gbase, int gbytes, char* 
 #ifndef TAD_NT_PIPE
 #define TAD_NT_PIPE 0
 #endif
+#ifndef TAD_NT_TWO_WG
+#define TAD_NT_TWO_WG 0  // build-time variant: tile configuration 6 (two independent 4-wave workgroups per CU), see launch_nt_variant
+#endif
 // piece I of a stage only (stage_tile issues all PIECES at once): for the build-time variant that spreads a stage's pieces between the
 // MFMA groups of a k-step (-DTAD_DMA_SPREAD=1)
 template <int NW, bool SCALAR_ADD = false>
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
   static_assert(BM % (RPP * NW) == 0 && BN % (RPP * NW) == 0, "tile rows must split into whole DMA pieces per wave");
   // one epilogue chunk: CROWS rows of f32, padded stride.  The persistent kernel keeps ring slot 0 out of the epilogue's way
   // (the next tile's first K-tile lands there meanwhile), so its chunks must fit the LDS behind slot 0.
-  constexpr int CROWS = BM < 128 ? BM : ((BN > 128 && IS_RES && !OUT_BF16) ? 32 : (((PERSIST && BN > 128) || NW == 4) ? 64 : 128));
+  constexpr int CROWS = BM < 128 ? BM : (((BN > 128 || (NW == 4 && BM == 256)) && IS_RES && !OUT_BF16) ? 32 : (((PERSIST && BN > 128) || NW == 4) ? 64 : 128));
   constexpr int EPI_OFF = PERSIST ? STAGE_BYTES : 0;
   constexpr int EPI_BYTES = DIRECT ? 0 : CROWS * (BN * 4 + 16);
   constexpr int LDS_BYTES = STAGES * STAGE_BYTES > EPI_OFF + EPI_BYTES ? STAGES * STAGE_BYTES : EPI_OFF + EPI_BYTES;
@@ -974,6 +977,7 @@ static int g_nt_stagger_group = getenv("TAD_GEMM_STAGGER_GROUP") ? env_int("TAD_
 static int g_nt_direct = getenv("TAD_GEMM_DIRECT_EPI") ? env_int("TAD_GEMM_DIRECT_EPI") : 1;
 static int g_nt_split = getenv("TAD_GEMM_SPLIT_TAIL") ? env_int("TAD_GEMM_SPLIT_TAIL") : 1;
 static int g_nt_dynamic = getenv("TAD_GEMM_DYNAMIC") ? env_int("TAD_GEMM_DYNAMIC") : 0;  // measured: +7 % gemm_nt time in the full step
+static int g_nt_variant = env_int("TAD_GEMM_NT_VARIANT");  // 0 = planned per shape (launch_gemm_nt), else the tile configuration for every launch
 static int g_nt_group_m = getenv("TAD_GEMM_GROUP_M") ? env_int("TAD_GEMM_GROUP_M") : 0;  // 0 = per-shape choice (nt_group_m)
 
 // Row panels per column-panel group of the tile raster.  The ~32 workgroups resident on an XCD (private 4 MiB L2) walk consecutive
@@ -1015,6 +1019,9 @@ static long long g_nt_launches = 0;  // gemm_nt kernel launches so far (tad_line
 // Tile configurations.  NT: 1 = 256x256 (2x4 waves) 2 stages; 2 = 128x128 (2x2) 2 stages, 2 workgroups/CU;
 // 3 = 256x128 (4x2) 3 stages; 4 = 128x64, 5 = 64x64 (2x2 waves, 2 stages: small problems).  0 = auto.  The epilogue kind and output type are compile-time (the epilogue is VALU-bound).
 // Variants 1 and 3 run as persistent kernels (one workgroup per CU walks a tile list) once there are more than 1.5 tiles per CU.
+// 6 (only with -DTAD_NT_TWO_WG=1) = 256x128 with FOUR waves (2x2, 128x64 per wave as in variant 1), K-tile 32, 3 stages, 72 KiB of LDS
+// and 256 registers: TWO independent persistent workgroups per CU, one wave of each per SIMD, so that the epilogue of one runs beside the
+// K loop of the other.  Bit-identical results; measured 13-30 % SLOWER than the planned variants at all eight ViT-B shapes.
 template <int EPI, bool OUT_BF16>
 static void launch_nt_variant(int v, GemmNT& p, hipStream_t st) {
   auto tiles = [&](int bm, int bn) { return ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
@@ -1023,7 +1030,8 @@ static void launch_nt_variant(int v, GemmNT& p, hipStream_t st) {
   if (v != 2 && v != 4 && v != 5 && p.rowscale && p.rows_per_scale < 256) v = 2;  // the 256-row tiles take at most two row-scale groups per tile
   const int grid_p = cu_count() & ~7;
   const int bn = v == 1 ? 256 : 128;
-  const bool persist = !no_persist && (v == 1 || v == 3) && grid_p >= 8 && tiles(256, bn) > grid_p + grid_p / 2;
+  const bool persist = !no_persist && (v == 1 || v == 3 || v == 6) && grid_p >= 8 && tiles(256, bn) > (v == 6 ? 3 : 1) * grid_p + grid_p / 2;
+  if (v == 6 && (!persist || !TAD_NT_TWO_WG)) v = 3;
   p.group_m = nt_group_m((p.M + 255) / 256, (p.N + bn - 1) / bn);
   p.sched = p.sched_clear = nullptr;
   if (persist && g_nt_dynamic) {
@@ -1060,6 +1068,12 @@ static void launch_nt_variant(int v, GemmNT& p, hipStream_t st) {
       if (persist) { if (direct) NT_LAUNCH(256, 128, 4, 2, 3, true, true, grid_p, 512); else NT_LAUNCH(256, 128, 4, 2, 3, true, false, grid_p, 512); }
       else { if (direct) NT_LAUNCH(256, 128, 4, 2, 3, false, true, tiles(256, 128), 512); else NT_LAUNCH(256, 128, 4, 2, 3, false, false, tiles(256, 128), 512); }
       break;
+#if TAD_NT_TWO_WG
+    case 6:
+      if (direct) hipLaunchKernelGGL((gemm_nt_kernel<256, 128, 2, 2, 3, 32, 2, EPI, OUT_BF16, true, true, false>), dim3(2 * grid_p), dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((gemm_nt_kernel<256, 128, 2, 2, 3, 32, 2, EPI, OUT_BF16, true, false, false>), dim3(2 * grid_p), dim3(256), 0, st, p);
+      break;
+#endif
     case 4:
       if (direct) NT_LAUNCH(128, 64, 2, 2, 2, false, true, tiles(128, 64), 256); else NT_LAUNCH(128, 64, 2, 2, 2, false, false, tiles(128, 64), 256);
       break;
@@ -1154,7 +1168,7 @@ int launch_gemm_nt(const GemmNT& p_in, hipStream_t st) {
       return TAD_OK;
     }
   }
-  static const int forced = env_int("TAD_GEMM_NT_VARIANT");
+  const int forced = g_nt_variant;
   p.debug = g_gemm_debug;
   p.stamps = g_nt_stamps;
   if (forced) return launch_gemm_nt_one(p, forced, st);
@@ -1331,6 +1345,7 @@ int tad_linear_tuning(const char* key, int value) {
   else if (k == "dynamic_tiles") g_nt_dynamic = value != 0;
   else if (k == "debug") g_gemm_debug = value;  // ablation bits (timing experiments; ignored by production builds)
   else if (k == "group_m") { TAD_REQUIRE(value >= 0 && value <= 1024, "linear_tuning: group_m=%d out of range", value); g_nt_group_m = value; }
+  else if (k == "variant") { TAD_REQUIRE(value >= 0 && value <= 6, "linear_tuning: variant=%d not in 0..6", value); g_nt_variant = value; }
   else if (k == "split_tail") { TAD_REQUIRE(value >= 0 && value <= 2, "linear_tuning: split_tail=%d not in 0..2", value); g_nt_split = value; }
   else { set_error("linear_tuning: unknown key '%s'", key); return TAD_EINVAL; }
   return TAD_OK;

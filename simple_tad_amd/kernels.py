@@ -353,7 +353,7 @@ def _pad_reduction(a, b, mult: int = 64):
     return torch.nn.functional.pad(a, (0, pad)).contiguous(), torch.nn.functional.pad(b, (0, pad)).contiguous()
 
 
-LINEAR_TUNING_DEFAULTS = dict(persistent=1, stagger_pct=0, stagger_group=1, direct_epilogue=1, split_tail=1, dynamic_tiles=0, group_m=0)
+LINEAR_TUNING_DEFAULTS = dict(persistent=1, stagger_pct=0, stagger_group=1, direct_epilogue=1, split_tail=1, dynamic_tiles=0, group_m=0, variant=0)
 
 
 def linear_tuning(**knobs):

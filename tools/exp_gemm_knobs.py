@@ -26,6 +26,7 @@ ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--shapes", default="")
 ap.add_argument("--trace", action="store_true")
+ap.add_argument("--check", action="store_true", help="every configuration's outputs must be bit-identical to the first one's")
 a = ap.parse_args()
 cfgs = ([dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in c.split(",")) for c in a.configs.split(";")] if a.configs
         else [{a.knob: int(v)} for v in a.values.split(",")])
@@ -73,6 +74,16 @@ for name, n, k, mode in SHAPES:
         continue
     for _ in range(3):
         fn()
+    if a.check:
+        outs = []
+        for c in cfgs:
+            K.linear_tuning(**{**K.LINEAR_TUNING_DEFAULTS, **c})
+            o = fn()
+            outs.append([t_.clone() for t_ in (o if isinstance(o, tuple) else (o,)) if t_ is not None])
+        for i, o in enumerate(outs[1:], 1):
+            for u, v in zip(outs[0], o):
+                assert torch.equal(u, v), f"{name}: configuration {cfgs[i]} differs from {cfgs[0]}: max |d| {(u.float() - v.float()).abs().max().item():.3e}"
+        del outs
     t = np.zeros((len(cfgs), a.rounds))
     for r in range(a.rounds):
         for i, c in enumerate(cfgs):
