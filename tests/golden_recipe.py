@@ -120,6 +120,18 @@ TINY = dict(img_size=16, patch_size=8, embed_dim=128, depth=2, num_heads=2, all_
             num_classes=2)
 
 
+# ---- G12: fine-tune trajectory of the tiny model through the reference's real engine (three optimizer steps, update_freq 2)
+G12 = dict(micro_batches=6, update_freq=2, steps=3, base_lr=2e-3, min_lr=1e-5, warmup_epochs=1, warmup_steps=1, start_warmup_value=2e-4, weight_decay=0.05, weight_decay_end=0.1,
+           layer_decay=0.75, clip_grad=1.5, labels=[[0, 1], [1, 1], [0, 0], [1, 0], [0, 1], [1, 1]])
+
+
+def g12_batches(dtype=torch.float32):
+    """the six micro-batches of G12: (samples [2,3,T,H,W], targets [2], None, None) -- the tuple engine_for_finetuning iterates over"""
+    c = TINY
+    return [(tensor_for(f"g12.x{i}", (2, 3, c["all_frames"], c["img_size"], c["img_size"]), seed=12 + i).to(dtype),
+             torch.tensor(G12["labels"][i]), None, None) for i in range(G12["micro_batches"])]
+
+
 # ---- real-size fixtures (G10 ViT-L/16 MAE, G11 ViT-B/16 gradients): weights come from the model's own seeded init, inputs from here
 G10_ROWS = [0, 1, 587, 1175]   # masked-token rows of each clip whose whole 1536-wide prediction / label is stored
 

@@ -283,6 +283,30 @@ def g4(mf, ris):
     save("g4_real_shape", **arrs)
 
 
+def g5_stubs():
+    """third-party modules the reference's utils.py / optim_factory.py import at module level and this image lacks (tensorboardX,
+    timm.utils, the timm optimizer zoo): empty stand-ins, none of them is on a path the fixtures exercise"""
+    sys.path.insert(0, REF)
+    for name in ("tensorboardX",):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.SummaryWriter = object
+            sys.modules[name] = m
+    timm_utils = types.ModuleType("timm.utils")
+    timm_utils.get_state_dict = lambda *a, **k: None
+    timm_utils.accuracy = None
+    timm_utils.ModelEma = object
+    sys.modules["timm.utils"] = timm_utils
+    for sub in ("adafactor", "adahessian", "adamp", "lookahead", "nadam", "novograd", "nvnovograd", "radam",
+                "rmsprop_tf", "sgdp"):
+        m = types.ModuleType("timm.optim." + sub)
+        for cls in ("Adafactor", "Adahessian", "AdamP", "Lookahead", "Nadam", "NovoGrad", "NvNovoGrad", "RAdam",
+                    "RMSpropTF", "SGDP"):
+            setattr(m, cls, object)
+        sys.modules["timm.optim." + sub] = m
+    sys.modules.setdefault("timm.optim", types.ModuleType("timm.optim"))
+
+
 def g5():
     sys.path.insert(0, REF)
     # utils.py imports tensorboardX etc.; restate-free approach: exec only the function's module deps are heavy,
@@ -527,6 +551,67 @@ def g11(mf):
     save("g11_vitb_grads", **arrs)
 
 
+def g12(mf):
+    """Fine-tune trajectory (SURVEY 8a rows 12-14 + 8f-1 together): the tiny fp64 model driven by the REAL
+    engine_for_finetuning.train_one_epoch for six micro-batches at update_freq 2 = three optimizer steps, with the reference's own
+    utils.NativeScalerWithGradNormCount (gradient clipping), utils.cosine_scheduler (lr with one warm-up step, weight decay 0.05 -> 0.1)
+    and optim_factory.create_optimizer + LayerDecayValueAssigner (layer decay 0.75).  CPU: GradScaler / autocast disable themselves
+    (scale 1, fp64 throughout); torch.cuda.synchronize is patched out."""
+    import argparse as _ap
+    import unittest.mock as mock
+    g5_stubs()
+    import utils as ref_utils
+    import optim_factory as of
+    import engine_for_finetuning as eff
+    c = R.G12
+    model, P = build_tiny(mf, torch.float64)
+    num_layers = model.get_num_layers()
+    assigner = of.LayerDecayValueAssigner([c["layer_decay"] ** (num_layers + 1 - i) for i in range(num_layers + 2)])   # run_class_finetuning.py:430-434
+    args = _ap.Namespace(opt="adamw", lr=c["base_lr"], weight_decay=c["weight_decay"], opt_eps=1e-8, opt_betas=(0.9, 0.999), momentum=0.9)
+    opt = of.create_optimizer(args, model, skip_list=model.no_weight_decay(), get_num_layer=assigner.get_layer_id,
+                              get_layer_scale=assigner.get_scale)
+    lr_sched = ref_utils.cosine_scheduler(c["base_lr"], c["min_lr"], 1, c["steps"], warmup_epochs=c["warmup_epochs"],
+                                          start_warmup_value=c["start_warmup_value"], warmup_steps=c["warmup_steps"])
+    wd_sched = ref_utils.cosine_scheduler(c["weight_decay"], c["weight_decay_end"], 1, c["steps"])
+    class _Scaler(ref_utils.NativeScalerWithGradNormCount):   # the real scaler; on CPU its GradScaler is disabled and reports no scale
+        def state_dict(self):
+            d = super().state_dict()
+            return d if "scale" in d else {"scale": 1.0}   # (only logged: engine_for_finetuning.py:100)
+
+    scaler = _Scaler()
+    losses, norms, lrs, min_lrs = [], [], [], []
+
+    class _Logger(ref_utils.MetricLogger):   # the real logger; update() is tapped to keep every per-step value
+        def update(self, **kw):
+            if "loss" in kw:
+                losses.append(float(kw["loss"]))
+            if "grad_norm" in kw:
+                norms.append(None if kw["grad_norm"] is None else float(kw["grad_norm"]))
+            if "lr" in kw:
+                lrs.append(float(kw["lr"]))
+            if "min_lr" in kw:
+                min_lrs.append(float(kw["min_lr"]))
+            super().update(**kw)
+
+    batches = [(x.double(), y, a, b) for x, y, a, b in R.g12_batches()]
+    with mock.patch.object(ref_utils, "MetricLogger", _Logger), mock.patch("torch.cuda.synchronize"):
+        avg = eff.train_one_epoch(model, nn.CrossEntropyLoss(), batches, opt, torch.device("cpu"), 0, scaler, max_norm=c["clip_grad"],
+                                  start_steps=0, lr_schedule_values=lr_sched, wd_schedule_values=wd_sched,
+                                  num_training_steps_per_epoch=c["steps"], update_freq=c["update_freq"])
+    print("G12 losses", losses, "grad norms", norms, "lr", lrs)
+    assert len(losses) == c["micro_batches"] and sum(n is not None for n in norms) == c["steps"]
+    arrs = {"loss": np.array(losses), "grad_norm": np.array([np.nan if n is None else n for n in norms]), "lr": np.array(lrs),
+            "min_lr": np.array(min_lrs), "lr_schedule": np.asarray(lr_sched), "wd_schedule": np.asarray(wd_sched),
+            "avg_keys": np.array(sorted(avg.keys())), "avg_vals": np.array([float(avg[k]) for k in sorted(avg.keys())]),
+            "group_lr_scale": np.array([g["lr_scale"] for g in opt.param_groups]),
+            "group_weight_decay": np.array([g["weight_decay"] for g in opt.param_groups]),
+            "group_size": np.array([len(g["params"]) for g in opt.param_groups]), "keys": np.array(list(P.keys()))}
+    for k, p in model.named_parameters():
+        for kk, v in R.summarize(p.detach().float()).items():
+            arrs[f"after.{k}.{kk}"] = v
+    save("g12_finetune_trajectory", **arrs)
+
+
 def g9():
     """Evaluation metrics: the reference's anaysis/metrics.py (numpy + scikit-learn 1.7.2, both installed here) on
     seeded class-1 probabilities with ties on the threshold grid."""
@@ -552,7 +637,7 @@ def main():
     ris, mf, mg = import_reference()
     jobs = {"g1": lambda: g1(mf), "g2": lambda: g2(mf), "g3": lambda: g3(mf), "g4": lambda: g4(mf, ris),
             "g5": g5, "g6": lambda: g6(mg), "g7": lambda: g7(ris), "g8": lambda: g8(mf), "g9": g9,
-            "g10": lambda: g10(mf, mg), "g11": lambda: g11(mf)}
+            "g10": lambda: g10(mf, mg), "g11": lambda: g11(mf), "g12": lambda: g12(mf)}
     for k, fn in jobs.items():
         if a.only and a.only != k:
             continue
