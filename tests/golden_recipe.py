@@ -132,6 +132,26 @@ def g12_batches(dtype=torch.float32):
              torch.tensor(G12["labels"][i]), None, None) for i in range(G12["micro_batches"])]
 
 
+# ---- G13: three MAE pre-training steps of the tiny model through the reference's real engine (AdamW, lr / wd schedules, clipping)
+G13 = dict(steps=3, base_lr=1.5e-3, min_lr=1e-5, warmup_epochs=1, warmup_steps=1, start_warmup_value=3e-4, weight_decay=0.05,
+           weight_decay_end=0.08, clip_grad=0.005, betas=(0.9, 0.95))
+
+
+def g13_batches(dtype=torch.float32):
+    """(videos [2,3,16,32,32], tube mask [2,32] bool) per step: masks from a seeded RandomState as in G8 (2x2 grid, 0.75, 8 slots)"""
+    import numpy as np
+    rng = np.random.RandomState(13)
+    per = np.hstack([np.zeros(1), np.ones(3)])
+    out = []
+    for i in range(G13["steps"]):
+        masks = []
+        for _ in range(2):
+            rng.shuffle(per)
+            masks.append(np.tile(per, (8, 1)).flatten())
+        out.append((tensor_for(f"g13.x{i}", (2, 3, 16, 32, 32), seed=130 + i).to(dtype), torch.from_numpy(np.stack(masks)).bool()))
+    return out
+
+
 # ---- real-size fixtures (G10 ViT-L/16 MAE, G11 ViT-B/16 gradients): weights come from the model's own seeded init, inputs from here
 G10_ROWS = [0, 1, 587, 1175]   # masked-token rows of each clip whose whole 1536-wide prediction / label is stored
 

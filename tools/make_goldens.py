@@ -612,6 +612,64 @@ def g12(mf):
     save("g12_finetune_trajectory", **arrs)
 
 
+def g13(mf):
+    """MAE pre-training trajectory: the tiny fp64 PretrainVisionTransformer of G8 driven by the REAL engine_for_pretraining.train_one_epoch
+    for three steps with the reference's own optimizer factory (optim_factory.create_optimizer(args, model): AdamW, no-decay groups, as
+    run_mae_pretraining.py:289-290), utils.NativeScalerWithGradNormCount (clipping) and utils.cosine_scheduler for lr and weight decay."""
+    import argparse as _ap
+    import contextlib
+    import unittest.mock as mock
+    g5_stubs()
+    import utils as ref_utils            # the real utils first (scaler, scheduler) ...
+    import optim_factory as of
+    scaler_cls, cosine = ref_utils.NativeScalerWithGradNormCount, ref_utils.cosine_scheduler
+    mp, efp, _ = _pretrain_engine(mf)    # ... then the engine, whose `utils` import is the logger mock of _pretrain_engine
+    c = R.G13
+    torch.manual_seed(0)
+    model = mp.PretrainVisionTransformer(img_size=32, patch_size=16, encoder_embed_dim=128, encoder_depth=2, encoder_num_heads=2,
+                                         decoder_num_classes=1536, decoder_embed_dim=64, decoder_depth=1, decoder_num_heads=1,
+                                         mlp_ratio=4, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), init_values=0.,
+                                         use_flash_attn=False, tubelet_size=2).double()
+    P = R.params_for({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=8)
+    model.load_state_dict({k: v.double() for k, v in P.items()})
+    args = _ap.Namespace(opt="adamw", lr=c["base_lr"], weight_decay=c["weight_decay"], opt_eps=1e-8, opt_betas=c["betas"], momentum=0.9)
+    opt = of.create_optimizer(args, model)
+    lr_sched = cosine(c["base_lr"], c["min_lr"], 1, c["steps"], warmup_epochs=c["warmup_epochs"], start_warmup_value=c["start_warmup_value"],
+                      warmup_steps=c["warmup_steps"])
+    wd_sched = cosine(c["weight_decay"], c["weight_decay_end"], 1, c["steps"])
+
+    class _Scaler(scaler_cls):
+        def __init__(self):
+            super().__init__()
+            self.losses, self.norms = [], []
+
+        def __call__(self, loss, optimizer, **kw):
+            self.losses.append(float(loss.item()))
+            n = super().__call__(loss, optimizer, **kw)
+            self.norms.append(float(n))
+            return n
+
+        def state_dict(self):
+            d = super().state_dict()
+            return d if "scale" in d else {"scale": 1.0}
+
+    scaler = _Scaler()
+    batches = [(x.double(), m) for x, m in R.g13_batches()]
+    with mock.patch("torch.cuda.empty_cache"), mock.patch("torch.cuda.synchronize"), \
+            mock.patch("torch.cuda.amp.autocast", lambda *a, **k: contextlib.nullcontext()):
+        efp.train_one_epoch(model, batches, opt, torch.device("cpu"), 0, scaler, max_norm=c["clip_grad"], patch_size=16, normlize_target=True,
+                            start_steps=0, lr_schedule_values=lr_sched, wd_schedule_values=wd_sched)
+    print("G13 losses", scaler.losses, "grad norms", scaler.norms)
+    arrs = {"loss": np.array(scaler.losses), "grad_norm": np.array(scaler.norms), "lr_schedule": np.asarray(lr_sched), "wd_schedule": np.asarray(wd_sched),
+            "group_weight_decay": np.array([g["weight_decay"] for g in opt.param_groups]), "group_size": np.array([len(g["params"]) for g in opt.param_groups]),
+            "group_lr": np.array([g["lr"] for g in opt.param_groups]), "keys": np.array(list(P.keys())),
+            "masks": np.stack([m.numpy() for _, m in batches])}
+    for k, p in model.named_parameters():
+        for kk, v in R.summarize(p.detach()).items():   # fp64: the encoder's updates here are ~1e-6 (gradients far below Adam's eps), under f32 resolution at 1.0
+            arrs[f"after.{k}.{kk}"] = v
+    save("g13_pretrain_trajectory", **arrs)
+
+
 def g9():
     """Evaluation metrics: the reference's anaysis/metrics.py (numpy + scikit-learn 1.7.2, both installed here) on
     seeded class-1 probabilities with ties on the threshold grid."""
@@ -637,7 +695,7 @@ def main():
     ris, mf, mg = import_reference()
     jobs = {"g1": lambda: g1(mf), "g2": lambda: g2(mf), "g3": lambda: g3(mf), "g4": lambda: g4(mf, ris),
             "g5": g5, "g6": lambda: g6(mg), "g7": lambda: g7(ris), "g8": lambda: g8(mf), "g9": g9,
-            "g10": lambda: g10(mf, mg), "g11": lambda: g11(mf), "g12": lambda: g12(mf)}
+            "g10": lambda: g10(mf, mg), "g11": lambda: g11(mf), "g12": lambda: g12(mf), "g13": lambda: g13(mf)}
     for k, fn in jobs.items():
         if a.only and a.only != k:
             continue
