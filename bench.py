@@ -427,6 +427,20 @@ def main():
         except Exception as e:  # noqa: BLE001
             out.setdefault("precise", {})["parity_error"] = repr(e)
 
+        # ---- torch_route: the reference's own operator route (stock torch modules under bf16 autocast, torch's fused attention,
+        # torch.optim.AdamW; tools/bench_torch_eager.py) for the same workload on THIS GPU, beside `value`.  Calibration only.
+        if args.model == "vit_base_patch16_224" and args.frames == 16:
+            try:
+                import importlib.util
+                spec = importlib.util.spec_from_file_location("bench_torch_eager", os.path.join(ROOT, "tools", "bench_torch_eager.py"))
+                bte = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(bte)
+                r = bte.run("sdpa", B, steps=5, warmup=3, device=dev)
+                r["speedup_of_value"] = round(out["value"] / r["clips_per_s"], 2)
+                out["torch_route"] = r
+            except Exception as e:  # noqa: BLE001
+                out["torch_route"] = {"error": repr(e)}
+
     if world == 1 and not args.no_cpu_baseline and args.model == "vit_base_patch16_224":
         try:
             out["cpu_baseline"] = cpu_baseline(sd_cpu, args.frames, all_cores=args.cpu_all_cores)
