@@ -10,7 +10,6 @@ attention, torch's elementwise / LayerNorm kernels.  BASELINE configs[2]: ViT-B/
 """
 import argparse
 import json
-import math
 import time
 
 import torch
