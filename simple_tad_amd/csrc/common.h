@@ -245,4 +245,33 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + idx;
 }
 
+
+// global accesses with a compile-time cache policy: NT = non-temporal ("streamed": the line is the first to leave the caches)
+template <bool NT>
+__device__ __forceinline__ float4 ldg_f4(const float4* p) {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  const v4 t = NT ? __builtin_nontemporal_load(reinterpret_cast<const v4*>(p)) : *reinterpret_cast<const v4*>(p);
+  return make_float4(t[0], t[1], t[2], t[3]);
+}
+template <bool NT>
+__device__ __forceinline__ uint2 ldg_u2(const uint2* p) {
+  typedef unsigned v2 __attribute__((ext_vector_type(2)));
+  const v2 t = NT ? __builtin_nontemporal_load(reinterpret_cast<const v2*>(p)) : *reinterpret_cast<const v2*>(p);
+  return make_uint2(t[0], t[1]);
+}
+template <bool NT>
+__device__ __forceinline__ void stg_f4(float4* p, const float4& v) {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  const v4 t = {v.x, v.y, v.z, v.w};
+  if (NT) __builtin_nontemporal_store(t, reinterpret_cast<v4*>(p));
+  else *reinterpret_cast<v4*>(p) = t;
+}
+template <bool NT>
+__device__ __forceinline__ void stg_u2(uint2* p, const uint2& v) {
+  typedef unsigned v2 __attribute__((ext_vector_type(2)));
+  const v2 t = {v.x, v.y};
+  if (NT) __builtin_nontemporal_store(t, reinterpret_cast<v2*>(p));
+  else *reinterpret_cast<v2*>(p) = t;
+}
+
 }  // namespace tad

@@ -100,6 +100,14 @@ __device__ __forceinline__ void stage_tile(const void* gbase, int gbytes, char* 
 #ifndef TAD_NT_PIPE
 #define TAD_NT_PIPE 0
 #endif
+#ifndef TAD_STORE_AUX
+#define TAD_STORE_AUX 2  // cache policy of the gemm_nt output stores: 2 = nt (streamed: the 77-308 MB outputs do not displace the operand panels the
+                         // other workgroups of the XCD are re-reading; measured 691.3 -> 695.8 clips/s over four alternating pairs of runs; 0 = default,
+                         // 16 = sc1 measured neutral)
+#endif
+#ifndef TAD_EPI_LOAD_AUX
+#define TAD_EPI_LOAD_AUX 0  // cache policy of what the epilogue reads once (f32 residual rows, bf16 pre-activation rows): build-time experiment
+#endif
 #ifndef TAD_NT_TWO_WG
 #define TAD_NT_TWO_WG 0  // build-time variant: tile configuration 6 (two independent 4-wave workgroups per CU), see launch_nt_variant
 #endif
@@ -388,19 +396,19 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
       if (IS_RES) {                                                                                        \
         if (EPI == EPI_RESMOD) o = (nn < p.N && m < p.M) ? (uint32_t)((m + p.row_base) % p.res_mod) * (uint32_t)p.N + (uint32_t)nn : OOB;  \
         const uint32_t rb = o == OOB ? OOB : o * 4;                                                                     \
-        extra[buf][jj][0] = __builtin_amdgcn_raw_buffer_load_b128(res_rs, rb, 0, 0);                                    \
-        if (CPL == 8) extra[buf][jj][EXW - 1] = __builtin_amdgcn_raw_buffer_load_b128(res_rs, fulld ? rb + 16 : OOB, 0, 0); \
+        extra[buf][jj][0] = __builtin_amdgcn_raw_buffer_load_b128(res_rs, rb, 0, TAD_EPI_LOAD_AUX);                                    \
+        if (CPL == 8) extra[buf][jj][EXW - 1] = __builtin_amdgcn_raw_buffer_load_b128(res_rs, fulld ? rb + 16 : OOB, 0, TAD_EPI_LOAD_AUX); \
       } else {                                                                                                          \
         const uint32_t hb = o == OOB ? OOB : o * 2;                                                                     \
         if (CPL == 8) {                                                                                                 \
-          if (n8) extra[buf][jj][0] = __builtin_amdgcn_raw_buffer_load_b128(h_rs, hb, 0, 0);                            \
+          if (n8) extra[buf][jj][0] = __builtin_amdgcn_raw_buffer_load_b128(h_rs, hb, 0, TAD_EPI_LOAD_AUX);                            \
           else {                                                                                                        \
-            const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(h_rs, hb, 0, 0);                                      \
-            const u32x2 hi = __builtin_amdgcn_raw_buffer_load_b64(h_rs, fulld ? hb + 8 : OOB, 0, 0);                    \
+            const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(h_rs, hb, 0, TAD_EPI_LOAD_AUX);                                      \
+            const u32x2 hi = __builtin_amdgcn_raw_buffer_load_b64(h_rs, fulld ? hb + 8 : OOB, 0, TAD_EPI_LOAD_AUX);                    \
             extra[buf][jj][0] = u32x4{lo[0], lo[1], hi[0], hi[1]};                                                      \
           }                                                                                                             \
         } else {                                                                                                        \
-          const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(h_rs, hb, 0, 0);                                        \
+          const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(h_rs, hb, 0, TAD_EPI_LOAD_AUX);                                        \
           extra[buf][jj][0] = u32x4{lo[0], lo[1], 0u, 0u};                                                              \
         }                                                                                                               \
       }                                                                                                                 \
@@ -415,19 +423,19 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
       if (IS_RES) {                                                                                        \
         if (EPI == EPI_RESMOD) o = (nvalid && m < p.M) ? (uint32_t)((m + p.row_base) % p.res_mod) * (uint32_t)p.N + (uint32_t)n : OOB;     \
         const uint32_t rb = o == OOB ? OOB : o * 4;                                                                     \
-        extra[buf][r][0] = __builtin_amdgcn_raw_buffer_load_b128(res_rs, rb, 0, 0);                                     \
-        if (CPL == 8) extra[buf][r][EXW - 1] = __builtin_amdgcn_raw_buffer_load_b128(res_rs, full ? rb + 16 : OOB, 0, 0); \
+        extra[buf][r][0] = __builtin_amdgcn_raw_buffer_load_b128(res_rs, rb, 0, TAD_EPI_LOAD_AUX);                                     \
+        if (CPL == 8) extra[buf][r][EXW - 1] = __builtin_amdgcn_raw_buffer_load_b128(res_rs, full ? rb + 16 : OOB, 0, TAD_EPI_LOAD_AUX); \
       } else {                                                                                                          \
         const uint32_t hb = o == OOB ? OOB : o * 2;                                                                     \
         if (CPL == 8) {                                                                                                 \
-          if (n8) extra[buf][r][0] = __builtin_amdgcn_raw_buffer_load_b128(h_rs, hb, 0, 0);                             \
+          if (n8) extra[buf][r][0] = __builtin_amdgcn_raw_buffer_load_b128(h_rs, hb, 0, TAD_EPI_LOAD_AUX);                             \
           else {                                                                                                        \
-            const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(h_rs, hb, 0, 0);                                      \
-            const u32x2 hi = __builtin_amdgcn_raw_buffer_load_b64(h_rs, full ? hb + 8 : OOB, 0, 0);                     \
+            const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(h_rs, hb, 0, TAD_EPI_LOAD_AUX);                                      \
+            const u32x2 hi = __builtin_amdgcn_raw_buffer_load_b64(h_rs, full ? hb + 8 : OOB, 0, TAD_EPI_LOAD_AUX);                     \
             extra[buf][r][0] = u32x4{lo[0], lo[1], hi[0], hi[1]};                                                       \
           }                                                                                                             \
         } else {                                                                                                        \
-          const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(h_rs, hb, 0, 0);                                        \
+          const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(h_rs, hb, 0, TAD_EPI_LOAD_AUX);                                        \
           extra[buf][r][0] = u32x4{lo[0], lo[1], 0u, 0u};                                                               \
         }                                                                                                               \
       }                                                                                                                 \
@@ -597,13 +605,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
             const u32x2 lo = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
             if (CPL == 8) {
               const u32x2 hi = u32x2{pack_bf16x2(v[CPL - 4], v[CPL - 3]), pack_bf16x2(v[CPL - 2], v[CPL - 1])};
-              if (n8) __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[0], lo[1], hi[0], hi[1]}, pre_rs, pb, 0, 0);
+              if (n8) __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[0], lo[1], hi[0], hi[1]}, pre_rs, pb, 0, TAD_STORE_AUX);
               else {
-                __builtin_amdgcn_raw_buffer_store_b64(lo, pre_rs, pb, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(hi, pre_rs, fulld ? pb + 8 : OOB, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(lo, pre_rs, pb, 0, TAD_STORE_AUX);
+                __builtin_amdgcn_raw_buffer_store_b64(hi, pre_rs, fulld ? pb + 8 : OOB, 0, TAD_STORE_AUX);
               }
             } else {
-              __builtin_amdgcn_raw_buffer_store_b64(lo, pre_rs, pb, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b64(lo, pre_rs, pb, 0, TAD_STORE_AUX);
             }
           }
           gelu_fast_row<CPL / 2>(v);
@@ -630,13 +638,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
         if (OUT_BF16) {
           const u32x2 lo = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
           const u32x2 hi = u32x2{pack_bf16x2(v[CPL - 4], v[CPL - 3]), pack_bf16x2(v[CPL - 2], v[CPL - 1])};
-          if (n8) __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[0], lo[1], hi[0], hi[1]}, c_rs, ob, 0, 0);
+          if (n8) __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[0], lo[1], hi[0], hi[1]}, c_rs, ob, 0, TAD_STORE_AUX);
           else {
-            __builtin_amdgcn_raw_buffer_store_b64(lo, c_rs, ob, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b64(hi, c_rs, fulld ? ob + 8 : OOB, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(lo, c_rs, ob, 0, TAD_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b64(hi, c_rs, fulld ? ob + 8 : OOB, 0, TAD_STORE_AUX);
           }
         } else {
-          __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, c_rs, ob, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, c_rs, ob, 0, TAD_STORE_AUX);
         }
       }
     }
@@ -685,13 +693,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
             const u32x2 lo = u32x2{pack_bf16x2(v[b][0], v[b][1]), pack_bf16x2(v[b][2], v[b][3])};
             if (CPL == 8) {
               const u32x2 hi = u32x2{pack_bf16x2(v[b][CPL - 4], v[b][CPL - 3]), pack_bf16x2(v[b][CPL - 2], v[b][CPL - 1])};
-              if (n8) __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[0], lo[1], hi[0], hi[1]}, pre_rs, pb, 0, 0);
+              if (n8) __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[0], lo[1], hi[0], hi[1]}, pre_rs, pb, 0, TAD_STORE_AUX);
               else {
-                __builtin_amdgcn_raw_buffer_store_b64(lo, pre_rs, pb, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(hi, pre_rs, full ? pb + 8 : OOB, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(lo, pre_rs, pb, 0, TAD_STORE_AUX);
+                __builtin_amdgcn_raw_buffer_store_b64(hi, pre_rs, full ? pb + 8 : OOB, 0, TAD_STORE_AUX);
               }
             } else {
-              __builtin_amdgcn_raw_buffer_store_b64(lo, pre_rs, pb, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b64(lo, pre_rs, pb, 0, TAD_STORE_AUX);
             }
           }
           gelu_fast_row<CPL / 2>(v[b]);
@@ -721,14 +729,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
         if (OUT_BF16) {
           const u32x2 lo = u32x2{pack_bf16x2(v[b][0], v[b][1]), pack_bf16x2(v[b][2], v[b][3])};
           const u32x2 hi = u32x2{pack_bf16x2(v[b][CPL - 4], v[b][CPL - 3]), pack_bf16x2(v[b][CPL - 2], v[b][CPL - 1])};
-          if (n8) __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[0], lo[1], hi[0], hi[1]}, c_rs, ob, 0, 0);
+          if (n8) __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[0], lo[1], hi[0], hi[1]}, c_rs, ob, 0, TAD_STORE_AUX);
           else {
-            __builtin_amdgcn_raw_buffer_store_b64(lo, c_rs, ob, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b64(hi, c_rs, full ? ob + 8 : OOB, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(lo, c_rs, ob, 0, TAD_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b64(hi, c_rs, full ? ob + 8 : OOB, 0, TAD_STORE_AUX);
           }
         } else {
           __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[b][0]), __float_as_uint(v[b][1]), __float_as_uint(v[b][2]), __float_as_uint(v[b][3])},
-                                                 c_rs, ob, 0, 0);
+                                                 c_rs, ob, 0, TAD_STORE_AUX);
         }
       }
     }

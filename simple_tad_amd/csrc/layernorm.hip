@@ -6,6 +6,18 @@
 
 namespace tad {
 
+#ifndef TAD_LN_FWD_LOAD_NT
+#define TAD_LN_FWD_LOAD_NT 0
+#endif
+#ifndef TAD_LN_FWD_STORE_NT
+#define TAD_LN_FWD_STORE_NT 0
+#endif
+#ifndef TAD_LN_BWD_LOAD_NT
+#define TAD_LN_BWD_LOAD_NT 0
+#endif
+#ifndef TAD_LN_BWD_STORE_NT
+#define TAD_LN_BWD_STORE_NT 0
+#endif
 constexpr int LN_MAX_V = 8;  // float4 per lane -> D <= 64*4*8 = 2048
 
 int launch_reduce_partials(const float* partial, float* out, int splits, int64_t n, int accumulate, hipStream_t st);
@@ -27,7 +39,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = lane + 64 * i;
-    v[i] = (c < D4) ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    v[i] = (c < D4) ? ldg_f4<TAD_LN_FWD_LOAD_NT>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
   }
   const float mu = wave_sum(s) / (float)D;
@@ -60,9 +72,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
         uint2 p;
         p.x = pack_bf16x2(o.x, o.y);
         p.y = pack_bf16x2(o.z, o.w);
-        reinterpret_cast<uint2*>((uint16_t*)y + row * D)[c] = p;
+        stg_u2<TAD_LN_FWD_STORE_NT>(reinterpret_cast<uint2*>((uint16_t*)y + row * D) + c, p);
       } else {
-        reinterpret_cast<float4*>((float*)y + row * D)[c] = o;
+        stg_f4<TAD_LN_FWD_STORE_NT>(reinterpret_cast<float4*>((float*)y + row * D) + c, o);
       }
     }
   }
@@ -117,10 +129,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
     for (int i = 0; i < NV; ++i) {
       const int c = lane + 64 * i;
       if (FULL || c < D4) {
-        xv[i] = reinterpret_cast<const float4*>(x + row * D)[c];
-        if (DY_BF16) dyp[i] = reinterpret_cast<const uint2*>((const uint16_t*)dy + row * D)[c];
-        else dyv[i] = reinterpret_cast<const float4*>((const float*)dy + row * D)[c];
-        rv[i] = reinterpret_cast<const float4*>(rsrc + row * D)[c];
+        xv[i] = ldg_f4<TAD_LN_BWD_LOAD_NT>(reinterpret_cast<const float4*>(x + row * D) + c);
+        if (DY_BF16) dyp[i] = ldg_u2<TAD_LN_BWD_LOAD_NT>(reinterpret_cast<const uint2*>((const uint16_t*)dy + row * D) + c);
+        else dyv[i] = ldg_f4<TAD_LN_BWD_LOAD_NT>(reinterpret_cast<const float4*>((const float*)dy + row * D) + c);
+        rv[i] = ldg_f4<TAD_LN_BWD_LOAD_NT>(reinterpret_cast<const float4*>(rsrc + row * D) + c);
       }
     }
     const float mu = mean[row], rs = rstd[row];
@@ -163,7 +175,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = lane + 64 * i;
-      if (FULL || c < D4) reinterpret_cast<float4*>(dx + row * D)[c] = o[i];
+      if (FULL || c < D4) stg_f4<TAD_LN_BWD_STORE_NT>(reinterpret_cast<float4*>(dx + row * D) + c, o[i]);
       // the bf16 copy and the column sums feed the branch Linear, whose output was scaled per sample (drop-path)
       o[i].x *= sc; o[i].y *= sc; o[i].z *= sc; o[i].w *= sc;
       if (FULL || c < D4) { cs[i].x += o[i].x; cs[i].y += o[i].y; cs[i].z += o[i].z; cs[i].w += o[i].w; }
@@ -176,7 +188,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
           uint2 p;
           p.x = pack_bf16x2(o[i].x, o[i].y);
           p.y = pack_bf16x2(o[i].z, o[i].w);
-          reinterpret_cast<uint2*>(dxb + row * D)[c] = p;
+          stg_u2<TAD_LN_BWD_STORE_NT>(reinterpret_cast<uint2*>(dxb + row * D) + c, p);
         }
       }
     }
