@@ -105,6 +105,9 @@ __device__ __forceinline__ void stage_tile(const void* gbase, int gbytes, char* 
                          // other workgroups of the XCD are re-reading; measured 691.3 -> 695.8 clips/s over four alternating pairs of runs; 0 = default,
                          // 16 = sc1 measured neutral)
 #endif
+#ifndef TAD_STORE_AUX_RES
+#define TAD_STORE_AUX_RES TAD_STORE_AUX  // the same for the f32 residual-stream outputs (build-time experiment: a different policy for them)
+#endif
 #ifndef TAD_EPI_LOAD_AUX
 #define TAD_EPI_LOAD_AUX 0  // cache policy of what the epilogue reads once (f32 residual rows, bf16 pre-activation rows): build-time experiment
 #endif
@@ -366,6 +369,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
   // 0, stores are dropped), columns >= N get an out-of-range offset explicitly.  No per-lane branches, and the barriers of the
   // epilogue wait for LDS traffic only (lgkmcnt) -- a __syncthreads() would also drain every store issued so far (vmcnt(0)).
   constexpr uint32_t OOB = 0x80000000u;  // >= any descriptor size accepted by the launcher
+  constexpr int ST_AUX = IS_RES ? TAD_STORE_AUX_RES : TAD_STORE_AUX;  // cache policy of the output stores
   constexpr int ESZ = OUT_BF16 ? 2 : 4;
   const uint32_t mn_elems = (uint32_t)p.M * (uint32_t)p.N;
   const auto c_rs = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)(mn_elems * ESZ), 0x00020000);
@@ -605,13 +609,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
             const u32x2 lo = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
             if (CPL == 8) {
               const u32x2 hi = u32x2{pack_bf16x2(v[CPL - 4], v[CPL - 3]), pack_bf16x2(v[CPL - 2], v[CPL - 1])};
-              if (n8) __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[0], lo[1], hi[0], hi[1]}, pre_rs, pb, 0, TAD_STORE_AUX);
+              if (n8) __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[0], lo[1], hi[0], hi[1]}, pre_rs, pb, 0, ST_AUX);
               else {
-                __builtin_amdgcn_raw_buffer_store_b64(lo, pre_rs, pb, 0, TAD_STORE_AUX);
-                __builtin_amdgcn_raw_buffer_store_b64(hi, pre_rs, fulld ? pb + 8 : OOB, 0, TAD_STORE_AUX);
+                __builtin_amdgcn_raw_buffer_store_b64(lo, pre_rs, pb, 0, ST_AUX);
+                __builtin_amdgcn_raw_buffer_store_b64(hi, pre_rs, fulld ? pb + 8 : OOB, 0, ST_AUX);
               }
             } else {
-              __builtin_amdgcn_raw_buffer_store_b64(lo, pre_rs, pb, 0, TAD_STORE_AUX);
+              __builtin_amdgcn_raw_buffer_store_b64(lo, pre_rs, pb, 0, ST_AUX);
             }
           }
           gelu_fast_row<CPL / 2>(v);
@@ -638,13 +642,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
         if (OUT_BF16) {
           const u32x2 lo = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
           const u32x2 hi = u32x2{pack_bf16x2(v[CPL - 4], v[CPL - 3]), pack_bf16x2(v[CPL - 2], v[CPL - 1])};
-          if (n8) __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[0], lo[1], hi[0], hi[1]}, c_rs, ob, 0, TAD_STORE_AUX);
+          if (n8) __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[0], lo[1], hi[0], hi[1]}, c_rs, ob, 0, ST_AUX);
           else {
-            __builtin_amdgcn_raw_buffer_store_b64(lo, c_rs, ob, 0, TAD_STORE_AUX);
-            __builtin_amdgcn_raw_buffer_store_b64(hi, c_rs, fulld ? ob + 8 : OOB, 0, TAD_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b64(lo, c_rs, ob, 0, ST_AUX);
+            __builtin_amdgcn_raw_buffer_store_b64(hi, c_rs, fulld ? ob + 8 : OOB, 0, ST_AUX);
           }
         } else {
-          __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, c_rs, ob, 0, TAD_STORE_AUX);
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, c_rs, ob, 0, ST_AUX);
         }
       }
     }
@@ -693,13 +697,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
             const u32x2 lo = u32x2{pack_bf16x2(v[b][0], v[b][1]), pack_bf16x2(v[b][2], v[b][3])};
             if (CPL == 8) {
               const u32x2 hi = u32x2{pack_bf16x2(v[b][CPL - 4], v[b][CPL - 3]), pack_bf16x2(v[b][CPL - 2], v[b][CPL - 1])};
-              if (n8) __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[0], lo[1], hi[0], hi[1]}, pre_rs, pb, 0, TAD_STORE_AUX);
+              if (n8) __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[0], lo[1], hi[0], hi[1]}, pre_rs, pb, 0, ST_AUX);
               else {
-                __builtin_amdgcn_raw_buffer_store_b64(lo, pre_rs, pb, 0, TAD_STORE_AUX);
-                __builtin_amdgcn_raw_buffer_store_b64(hi, pre_rs, full ? pb + 8 : OOB, 0, TAD_STORE_AUX);
+                __builtin_amdgcn_raw_buffer_store_b64(lo, pre_rs, pb, 0, ST_AUX);
+                __builtin_amdgcn_raw_buffer_store_b64(hi, pre_rs, full ? pb + 8 : OOB, 0, ST_AUX);
               }
             } else {
-              __builtin_amdgcn_raw_buffer_store_b64(lo, pre_rs, pb, 0, TAD_STORE_AUX);
+              __builtin_amdgcn_raw_buffer_store_b64(lo, pre_rs, pb, 0, ST_AUX);
             }
           }
           gelu_fast_row<CPL / 2>(v[b]);
@@ -729,14 +733,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kern
         if (OUT_BF16) {
           const u32x2 lo = u32x2{pack_bf16x2(v[b][0], v[b][1]), pack_bf16x2(v[b][2], v[b][3])};
           const u32x2 hi = u32x2{pack_bf16x2(v[b][CPL - 4], v[b][CPL - 3]), pack_bf16x2(v[b][CPL - 2], v[b][CPL - 1])};
-          if (n8) __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[0], lo[1], hi[0], hi[1]}, c_rs, ob, 0, TAD_STORE_AUX);
+          if (n8) __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[0], lo[1], hi[0], hi[1]}, c_rs, ob, 0, ST_AUX);
           else {
-            __builtin_amdgcn_raw_buffer_store_b64(lo, c_rs, ob, 0, TAD_STORE_AUX);
-            __builtin_amdgcn_raw_buffer_store_b64(hi, c_rs, full ? ob + 8 : OOB, 0, TAD_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b64(lo, c_rs, ob, 0, ST_AUX);
+            __builtin_amdgcn_raw_buffer_store_b64(hi, c_rs, full ? ob + 8 : OOB, 0, ST_AUX);
           }
         } else {
           __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[b][0]), __float_as_uint(v[b][1]), __float_as_uint(v[b][2]), __float_as_uint(v[b][3])},
-                                                 c_rs, ob, 0, TAD_STORE_AUX);
+                                                 c_rs, ob, 0, ST_AUX);
         }
       }
     }

@@ -18,6 +18,9 @@ namespace tad {
 #ifndef TAD_LN_BWD_STORE_NT
 #define TAD_LN_BWD_STORE_NT 0
 #endif
+#ifndef TAD_LN_BWD_STORE_DX_NT
+#define TAD_LN_BWD_STORE_DX_NT TAD_LN_BWD_STORE_NT  // the f32 dx alone (read again only by the NEXT LayerNorm backward, a whole branch later)
+#endif
 constexpr int LN_MAX_V = 8;  // float4 per lane -> D <= 64*4*8 = 2048
 
 int launch_reduce_partials(const float* partial, float* out, int splits, int64_t n, int accumulate, hipStream_t st);
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = lane + 64 * i;
-      if (FULL || c < D4) stg_f4<TAD_LN_BWD_STORE_NT>(reinterpret_cast<float4*>(dx + row * D) + c, o[i]);
+      if (FULL || c < D4) stg_f4<TAD_LN_BWD_STORE_DX_NT>(reinterpret_cast<float4*>(dx + row * D) + c, o[i]);
       // the bf16 copy and the column sums feed the branch Linear, whose output was scaled per sample (drop-path)
       o[i].x *= sc; o[i].y *= sc; o[i].z *= sc; o[i].w *= sc;
       if (FULL || c < D4) { cs[i].x += o[i].x; cs[i].y += o[i].y; cs[i].z += o[i].z; cs[i].w += o[i].w; }
