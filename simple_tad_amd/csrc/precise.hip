@@ -375,7 +375,7 @@ __global__ void gelu_bwd_f32_kernel(const float* __restrict__ dy, const float* _
   }
 }
 __global__ void colsum_f32_kernel(const float* __restrict__ a, float* __restrict__ out, int64_t M, int N) {
-  // one block per 64 columns; 4 waves over rows, f64 accumulation (verification path)
+  // any N: one block per 64 columns; 4 waves over rows, f64 accumulation (verification path)
   __shared__ double red[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
@@ -385,6 +385,42 @@ __global__ void colsum_f32_kernel(const float* __restrict__ a, float* __restrict
   red[wave][lane] = s;
   __syncthreads();
   if (wave == 0 && c < N) out[c] = (float)(red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+}
+// N % 4 == 0 (every Linear of the model): one 1024-thread block per 16 columns -- four lanes read one row's 64-byte segment as float4, a
+// wave covers 16 rows per instruction, the 16 waves 256 rows per step, four row-steps in flight per lane -- so N / 16 = 48 .. 192 blocks
+// stream the matrix instead of N / 64 = 12 .. 48 with one 4-byte load in flight per lane (5.1 ms per call at M = 50176, N = 3072: a third of
+// the precise mode's step).  f64 accumulation per lane, then a fixed-order f64 tree over the 256 row lanes: deterministic.
+__global__ __launch_bounds__(1024) void colsum_f32_wide_kernel(const float* __restrict__ a, float* __restrict__ out, int64_t M, int N) {
+  __shared__ double red[256][17];  // [row lane][column of the block] (+1: no bank conflicts in the tree)
+  const int quad = threadIdx.x & 3, rl = threadIdx.x >> 2;
+  const int c = blockIdx.x * 16 + quad * 4;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (c < N) {
+    const float* p = a + c;
+    int64_t m = rl;
+    for (; m + 768 < M; m += 1024) {
+      const float4 v0 = *reinterpret_cast<const float4*>(p + m * N);
+      const float4 v1 = *reinterpret_cast<const float4*>(p + (m + 256) * N);
+      const float4 v2 = *reinterpret_cast<const float4*>(p + (m + 512) * N);
+      const float4 v3 = *reinterpret_cast<const float4*>(p + (m + 768) * N);
+      s0 += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+      s1 += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+      s2 += ((double)v0.z + (double)v1.z) + ((double)v2.z + (double)v3.z);
+      s3 += ((double)v0.w + (double)v1.w) + ((double)v2.w + (double)v3.w);
+    }
+    for (; m < M; m += 256) {
+      const float4 v = *reinterpret_cast<const float4*>(p + m * N);
+      s0 += (double)v.x; s1 += (double)v.y; s2 += (double)v.z; s3 += (double)v.w;
+    }
+  }
+  red[rl][quad * 4 + 0] = s0; red[rl][quad * 4 + 1] = s1; red[rl][quad * 4 + 2] = s2; red[rl][quad * 4 + 3] = s3;
+  __syncthreads();
+  for (int half = 128; half >= 1; half >>= 1) {  // 256 row lanes x 16 columns -> 16 sums; thread (r, col) folds row r + half into row r
+    const int col = threadIdx.x & 15;
+    for (int r = threadIdx.x >> 4; r < half; r += 64) red[r][col] += red[r + half][col];
+    __syncthreads();
+  }
+  if (threadIdx.x < 16 && blockIdx.x * 16 + (int)threadIdx.x < N) out[blockIdx.x * 16 + threadIdx.x] = (float)red[0][threadIdx.x];
 }
 
 static inline int grid_for(int64_t items) {
@@ -461,7 +497,8 @@ int tad_gelu_bwd_f32(const float* dy, const float* h, float* dh, int64_t n, tad_
 
 int tad_colsum_f32(const float* a, float* out, int64_t M, int N, tad_stream_t stream) {
   TAD_REQUIRE(a && out && M > 0 && N > 0, "colsum_f32: bad args");
-  hipLaunchKernelGGL(colsum_f32_kernel, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, a, out, M, N);
+  if (N % 4 == 0) hipLaunchKernelGGL(colsum_f32_wide_kernel, dim3((N + 15) / 16), dim3(1024), 0, (hipStream_t)stream, a, out, M, N);
+  else hipLaunchKernelGGL(colsum_f32_kernel, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, a, out, M, N);
   return check_launch("colsum_f32");
 }
 

@@ -297,6 +297,16 @@ def test_linear_reduction_off_the_k_tile_is_zero_padded(K):
         check(dx, dy.double() @ wT.double().t(), tol=2e-5, what=f"linear dX N={Kd}")
 
 
+@pytest.mark.parametrize("M,N", [(1, 4), (255, 16), (1027, 20), (5000, 772), (50176, 3072), (300, 37), (2049, 1)])
+def test_colsum_f32_shapes(K, M, N):
+    """column sums of an f32 matrix (bias gradients of the precise mode): wide kernel for N % 4 == 0, narrow one otherwise; f64 accumulation"""
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, N, generator=g) + 0.25
+    got = K.colsum_f32(dev(a))
+    check(got, a.double().sum(0), tol=2e-6, what=f"colsum f32 {M}x{N}")
+    assert torch.equal(got, K.colsum_f32(dev(a)))  # fixed summation order
+
+
 # ------------------------------------------------------------------ precise-mode kernels (parity gate): 1e-3 is met with margin
 def test_split_bf16x3_linear_matches_f32_product(K):
     M, N, Kd = 300, 256, 128
