@@ -996,9 +996,12 @@ static int g_nt_group_m = getenv("TAD_GEMM_GROUP_M") ? env_int("TAD_GEMM_GROUP_M
 // tile ids, so at any time they touch GROUP_M A-panels and ~32 / GROUP_M W-panels; each panel streams K-tile by K-tile, and a
 // panel's K-tile is fetched from beyond L2 once per group of tiles that share it while they run together.  Per group of
 // GROUP_M x tiles_n tiles that is GROUP_M A-panel loads (algorithmic) + tiles_n W-panel loads (overhead, amortised over GROUP_M).
-static int nt_group_m(int tiles_m, int tiles_n) {
+// Measured (tools/exp_gemm_knobs.py --knob group_m, the eight Linear shapes of a ViT-B block, with the non-temporal output stores in): 2 / 4 / 8 are
+// within 0.5 % of each other in sum; the long reductions (K = 2304 / 3072: an A panel of 256 rows is 1.2 - 1.5 MB) are 1 - 4 % faster with 4 (fc2 241
+// vs 246 us, dX(fc1) 220 vs 222), the K = 768 shapes with 8 (qkv 166 vs 169).
+static int nt_group_m(int tiles_m, int tiles_n, int K) {
   if (g_nt_group_m > 0) return g_nt_group_m;
-  return 8;
+  return K >= 2048 ? 4 : 8;
 }
 
 static unsigned long long* g_nt_stamps = nullptr;
@@ -1044,7 +1047,7 @@ static void launch_nt_variant(int v, GemmNT& p, hipStream_t st) {
   const int bn = v == 1 ? 256 : 128;
   const bool persist = !no_persist && (v == 1 || v == 3 || v == 6) && grid_p >= 8 && tiles(256, bn) > (v == 6 ? 3 : 1) * grid_p + grid_p / 2;
   if (v == 6 && (!persist || !TAD_NT_TWO_WG)) v = 3;
-  p.group_m = nt_group_m((p.M + 255) / 256, (p.N + bn - 1) / bn);
+  p.group_m = nt_group_m((p.M + 255) / 256, (p.N + bn - 1) / bn, p.K);
   p.sched = p.sched_clear = nullptr;
   if (persist && g_nt_dynamic) {
     if (int* ring = sched_ring(st)) {
