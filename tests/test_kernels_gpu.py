@@ -352,7 +352,9 @@ def test_attention_f32_fwd_bwd(K, B, N, H, d):
 # for the persistent path (>= 2 tiles per CU) and include ragged M / N edges.
 @pytest.mark.parametrize("M,N,Kd,mode", [
     (12544 + 77, 3072, 768, "gelu"), (25088 + 130, 768, 768, "res"), (25088, 768, 3072, "res"), (25088 + 5, 2304, 768, "plain"),
-    (12544 + 200, 3072, 768, "dgelu"), (25088, 768 + 4, 128, "plain_f32")])
+    (12544 + 200, 3072, 768, "dgelu"), (25088, 768 + 4, 128, "plain_f32"),
+    # the peeled last K-tile of the persistent bias-only bf16 kernel: odd number of K-tiles (falls back), two K-tiles, N off the 8-column store width
+    (25088 + 5, 2300, 192, "plain"), (20000 + 3, 1028, 128, "plain"), (30000, 1024, 3072, "plain")])
 def test_linear_persistent_schedule_is_bit_identical(K, M, N, Kd, mode):
     from simple_tad_amd import _lib
     lib = _lib.load()
