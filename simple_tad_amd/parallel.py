@@ -128,7 +128,7 @@ class DataParallel(nn.Module):
             # The persistent Linear kernels expect one workgroup per CU with a fixed tile list each (132-147 KB of LDS, every VGPR).
             # While an RCCL collective runs beside the backward pass it holds some CUs, the workgroups meant for them start a
             # whole kernel late and their tile lists double that kernel's time; the per-tile grid lets the dispatcher balance
-            # instead.  (Costs the next-tile prefetch, ~1.5 % of a single-GPU step.)
+            # instead.  (Costs the next-tile prefetch and the peeled last K-tile: 0.2 % of a single-GPU step on the round-2 build.)
             from . import kernels as _K
             _K.linear_tuning(persistent=0)
         # flat gradient buffer (layout shared with the fused optimizer: flat.FlatSpace)
