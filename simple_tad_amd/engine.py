@@ -62,28 +62,28 @@ class LayerDecayValueAssigner:
 
 
 def get_parameter_groups(model, weight_decay=1e-5, skip_list=(), get_num_layer=None, get_layer_scale=None, verbose=False):
-    """optim_factory.get_parameter_groups (optim_factory.py:49-88): 1-D / .bias / skip-listed -> no decay; optional
-    per-layer groups carrying ``lr_scale``."""
-    names, groups = {}, {}
-    for name, param in model.named_parameters():
-        if not param.requires_grad:
-            continue
-        if len(param.shape) == 1 or name.endswith(".bias") or name in skip_list:
-            group_name, wd = "no_decay", 0.
-        else:
-            group_name, wd = "decay", weight_decay
-        layer_id = None
-        if get_num_layer is not None:
-            layer_id = get_num_layer(name)
-            group_name = "layer_%d_%s" % (layer_id, group_name)
-        if group_name not in groups:
-            scale = get_layer_scale(layer_id) if get_layer_scale is not None else 1.
-            names[group_name] = {"weight_decay": wd, "params": [], "lr_scale": scale}
-            groups[group_name] = {"weight_decay": wd, "params": [], "lr_scale": scale}
-        groups[group_name]["params"].append(param)
-        names[group_name]["params"].append(name)
+    """The grouping rule of optim_factory.get_parameter_groups (optim_factory.py:49-88): a parameter is undecayed when it is 1-D,
+    a ``.bias`` or skip-listed; with layer-wise lr decay every (layer, decayed?) pair is a group of its own carrying ``lr_scale``.
+    Groups come out in order of first appearance in ``model.named_parameters()`` -- the order the reference hands to AdamW, and what
+    golden G12 pins (group names, member order, weight decay, lr_scale)."""
+    skip = frozenset(skip_list)
+    trainable = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    # key of a parameter = (layer id | None, decayed?)
+    keys = [(None if get_num_layer is None else get_num_layer(n), not (p.dim() == 1 or n.endswith(".bias") or n in skip)) for n, p in trainable]
+    groups, members = {}, {}
+    for key, (name, param) in zip(keys, trainable):
+        if key not in groups:
+            layer, decayed = key
+            groups[key] = {"weight_decay": weight_decay if decayed else 0., "params": [],
+                           "lr_scale": 1. if get_layer_scale is None else get_layer_scale(layer)}
+            members[key] = []
+        groups[key]["params"].append(param)
+        members[key].append(name)
     if verbose:
-        print("Param groups = %s" % json.dumps(names, indent=2))
+        def label(key):
+            kind = "decay" if key[1] else "no_decay"
+            return kind if key[0] is None else "layer_%d_%s" % (key[0], kind)
+        print("Param groups = %s" % json.dumps({label(k): dict(groups[k], params=members[k]) for k in groups}, indent=2))
     return list(groups.values())
 
 
@@ -174,22 +174,30 @@ class NativeScalerWithGradNormCount:
         pass
 
 
-def synchronize_meters(stats: dict, device=None) -> dict:
+METER_NAMES = ("loss", "class_acc", "grad_norm", "lr", "min_lr", "loss_scale")
+
+
+def synchronize_meters(stats: dict, device=None, group=None, names=None) -> dict:
     """C4 of SURVEY 2.3 -- ``MetricLogger.synchronize_between_processes`` (utils.py:71-82, called at engine_for_finetuning.py:138):
     every meter's (count, total) summed over the ranks, returned as ``{name: global_avg}`` (engine_for_finetuning.py:140), so every
     rank logs the same epoch averages.  The reference issues one barrier + one fp64 all-reduce PER meter; here all meters travel in
-    ONE fp64 all-reduce of a [n_meters, 2] tensor.  Single process: the local averages.  ``None`` entries are skipped as
-    MetricLogger.update does (utils.py:121-122)."""
+    ONE fp64 all-reduce of a [n_meters, 2] tensor over ``group`` (the process group of the gradient exchange; default group if
+    None).  ``names`` fixes the meter list: every rank must pack the same rows in the same order, so the engines pass their full
+    list and a meter a rank never updated travels as (0, 0) -- a per-rank list derived from the dict would make the collective's
+    shape differ across ranks and hang.  Single process: the local averages.  ``None`` entries are skipped as MetricLogger.update
+    does (utils.py:121-122)."""
     import torch.distributed as dist
-    names = sorted(k for k, v in stats.items() if isinstance(v, list))
+    if names is None:
+        names = sorted(k for k, v in stats.items() if isinstance(v, list))
+    names = list(names)
     packed = torch.zeros((len(names), 2), dtype=torch.float64)
     for i, k in enumerate(names):
-        vals = [float(v) for v in stats[k] if v is not None]
+        vals = [float(v) for v in stats.get(k, ()) if v is not None]
         packed[i, 0], packed[i, 1] = len(vals), sum(vals)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        if dist.get_backend() == "nccl":
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if dist.get_backend(group) == "nccl":
             packed = packed.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
-        dist.all_reduce(packed)
+        dist.all_reduce(packed, group=group)
         packed = packed.cpu()
     return {k: (packed[i, 1] / packed[i, 0]).item() for i, k in enumerate(names) if packed[i, 0] > 0}
 
@@ -211,7 +219,7 @@ def train_one_epoch(model: torch.nn.Module, criterion, data_loader: Iterable, op
     dp = model if isinstance(model, DataParallel) else None
     zero = (dp.zero_grad if dp is not None else lambda: optimizer.zero_grad(set_to_none=False))
     zero()
-    stats = {"loss": [], "class_acc": [], "grad_norm": [], "lr": [], "min_lr": [], "loss_scale": []}
+    stats = {k: [] for k in METER_NAMES}
     params = [p for p in model.parameters() if p.requires_grad]
     for data_iter_step, batch in enumerate(data_loader):
         samples, targets = batch[0], batch[1]
@@ -248,7 +256,7 @@ def train_one_epoch(model: torch.nn.Module, criterion, data_loader: Iterable, op
         if log is not None:
             log(epoch, data_iter_step, stats)
     # gather the stats from all processes (engine_for_finetuning.py:137-140): per-step lists stay per rank, "averaged" is global
-    stats["averaged"] = synchronize_meters(stats, device)
+    stats["averaged"] = synchronize_meters(stats, device, group=dp.pg if dp is not None else None, names=METER_NAMES)
     return stats
 
 

@@ -36,7 +36,8 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, optimizer, de
     inner = dp.module if dp is not None else model
     zero = dp.zero_grad if dp is not None else (lambda: optimizer.zero_grad(set_to_none=False))
     params = [p for p in model.parameters() if p.requires_grad]
-    stats = {"loss": [], "grad_norm": [], "lr": [], "min_lr": [], "loss_scale": [], "weight_decay": []}
+    names = ("loss", "grad_norm", "lr", "min_lr", "loss_scale", "weight_decay")  # fixed list: every rank packs the same rows
+    stats = {k: [] for k in names}
     for step, batch in enumerate(data_loader):
         it = start_steps + step
         if lr_schedule_values is not None or wd_schedule_values is not None:
@@ -71,5 +72,5 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, optimizer, de
             log(epoch, step, stats)
     # engine_for_pretraining.py:149-152: metric_logger.synchronize_between_processes() -> {k: meter.global_avg}
     from .engine import synchronize_meters
-    stats["averaged"] = synchronize_meters(stats, device)
+    stats["averaged"] = synchronize_meters(stats, device, group=dp.pg if dp is not None else None, names=names)
     return stats

@@ -42,6 +42,22 @@ class SlidingWindow:
         self._pool = None
         self._params = list(model.parameters())
         self._sig = None
+        self._cap_stream = None
+
+    def _drop_graphs(self) -> None:
+        """forget every captured graph together with what only they needed: their memory pool (the allocator retires a pool with its
+        last graph; a new generation gets a new one) and the scratch buffers of the capture stream"""
+        self._graphs.clear()
+        self._pool = None
+        if self._cap_stream is not None:
+            from . import kernels as K
+            K.release_workspace(self.device, self._cap_stream)
+
+    def __del__(self):
+        try:
+            self._drop_graphs()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
 
     @property
     def full(self) -> bool:
@@ -72,26 +88,32 @@ class SlidingWindow:
                 return self.model(self.ring)
             # A captured graph reads the bf16 weight copies (ops._wcache) and scratch buffers by raw pointer: the graphs are dropped
             # whenever the weights may have changed (a new weight epoch, a parameter re-assigned or modified in place), and each
-            # graph entry keeps the copies it was captured with alive (kernels.workspace never frees a buffer either).
+            # graph entry keeps the copies and the scratch buffers it was captured with alive.
             from . import ops
             sig = (ops.weight_epoch(), tuple(p._version for p in self._params), tuple(p.data_ptr() for p in self._params[:4]))
             if sig != self._sig:
-                self._graphs.clear()
-                self._pool = None   # (the allocator retires a graph memory pool with its last graph: a new generation gets a new pool)
+                self._drop_graphs()
                 self._sig = sig
             ent = self._graphs.get(self.start)
             if ent is None:
-                side = torch.cuda.Stream()
+                from . import kernels as K
+                # Warm-up AND capture run on one stream of this object's own: kernels.workspace is keyed by (device, stream), so the
+                # warm-up allocates exactly the scratch buffer the capture then bakes into the graph (allocated inside the capture
+                # it would come from the graph's private pool and be pinned for good).  The buffers of that stream are held next to
+                # the graphs and released together with them (_drop_graphs).
+                if self._cap_stream is None:
+                    self._cap_stream = torch.cuda.Stream(self.device)
+                side = self._cap_stream
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):  # warm-up outside the capture (weight copies, workspaces, lazy init)
                     self.model(self.ring)
-                torch.cuda.current_stream().wait_stream(side)
+                side.synchronize()
                 g = torch.cuda.CUDAGraph()
                 if self._pool is None:
                     self._pool = torch.cuda.graph_pool_handle()
-                with torch.cuda.graph(g, pool=self._pool):
+                with torch.cuda.graph(g, pool=self._pool, stream=side):
                     out = self.model(self.ring)
-                ent = self._graphs[self.start] = (g, out, ops.cached_weight_tensors())
+                ent = self._graphs[self.start] = (g, out, ops.cached_weight_tensors(), K.workspace_refs(self.device, side))
             ent[0].replay()
             return ent[1].clone()
         finally:

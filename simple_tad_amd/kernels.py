@@ -109,22 +109,40 @@ def _dt(t: torch.Tensor) -> int:
     raise _lib.TadError(f"unsupported dtype {t.dtype}")
 
 
-_retired = []  # outgrown scratch buffers: kept alive because a captured HIP graph may have baked their addresses in
+def _ws_key(device, stream=None):
+    dev = device.index if device.index is not None else torch.cuda.current_device()
+    return (dev, (torch.cuda.current_stream(device) if stream is None else stream).cuda_stream)
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:
     """Grow-only scratch buffer per (device, stream): kernels on one stream run in issue order, so consecutive ops share it; another
-    stream (a side-stream warm-up, a capture stream) gets its own and never aliases it.  A buffer that is outgrown is retired, not
-    freed -- HIP graphs captured earlier (inference.SlidingWindow, bench --graph) hold raw pointers into it.  Growth is geometric, so
-    the retired buffers together stay below the size of the live one."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
-    ws = _workspaces.get(key)
+    stream (a capture stream) gets its own and never aliases it.  A buffer that is outgrown is retired, not freed, for as long as
+    its (device, stream) entry lives -- HIP graphs captured on that stream hold raw pointers into it.  Growth is geometric, so the
+    retired buffers together stay below the size of the live one.  Holders of captured graphs warm up ON THE CAPTURE STREAM (so the
+    buffer the capture uses exists before the capture starts), keep `workspace_refs` of that stream next to their graphs and call
+    `release_workspace` when the stream goes away (inference.SlidingWindow, bench --graph)."""
+    key = _ws_key(device)
+    ent = _workspaces.get(key)
+    if ent is None:
+        ent = _workspaces[key] = {"ws": None, "retired": []}
+    ws = ent["ws"]
     if ws is None or ws.numel() < nbytes:
         if ws is not None:
-            _retired.append(ws)
+            ent["retired"].append(ws)
         ws = torch.empty(max(int(nbytes), 2 * (ws.numel() if ws is not None else 0), 1 << 20), dtype=torch.uint8, device=device)
-        _workspaces[key] = ws
+        ent["ws"] = ws
     return ws
+
+
+def workspace_refs(device, stream=None):
+    """every scratch buffer (live and retired) of one (device, stream): what a graph captured on that stream may point into"""
+    ent = _workspaces.get(_ws_key(device, stream))
+    return [] if ent is None else [t for t in [ent["ws"], *ent["retired"]] if t is not None]
+
+
+def release_workspace(device, stream=None) -> None:
+    """forget the scratch buffers of one (device, stream); they are freed once the last holder of `workspace_refs` lets go"""
+    _workspaces.pop(_ws_key(device, stream), None)
 
 
 # ----------------------------------------------------------------------------- casts

@@ -284,6 +284,10 @@ class VisionTransformer(nn.Module):
         self.use_checkpoint = use_checkpoint
         if use_learnable_pos_emb:
             self.pos_embed = nn.Parameter(torch.zeros(1, num_patches, embed_dim))
+            # the forward adds a DETACHED copy (as the reference does, :312-313): the table stays a trainable-looking Parameter that
+            # provably never receives a gradient.  The marker keeps it out of the all-reduce bucket counts (parallel.DataParallel)
+            # and makes the fused optimizer skip it the way torch.optim skips a ``None`` gradient (optim.FusedAdamW).
+            self.pos_embed._tad_never_grad = True
         else:
             # plain tensor attribute, absent from the state dict -- as in the reference (:249-253)
             self.pos_embed = get_sinusoid_encoding_table(num_patches, embed_dim)

@@ -71,6 +71,7 @@ class PretrainVisionTransformerEncoder(nn.Module):
         self.use_checkpoint = use_checkpoint
         if use_learnable_pos_emb:
             self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, embed_dim))
+            self.pos_embed._tad_never_grad = True  # added detached (:96 of the reference): see modeling_finetune.VisionTransformer
         else:
             self.pos_embed = get_sinusoid_encoding_table(num_patches, embed_dim)
         dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]

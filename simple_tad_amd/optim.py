@@ -41,8 +41,13 @@ class FusedAdamW(torch.optim.Optimizer):
         self.exp_avg, self.exp_avg_sq = self.space.zeros(), self.space.zeros()
         chunks = self.space.total // ADAMW_CHUNK
         cg = torch.full((chunks,), 255, dtype=torch.uint8)
+        # parameters that provably never receive a gradient (``_tad_never_grad``: a learnable pos_embed added detached) are skipped
+        # like torch.optim skips a ``None`` gradient: no decay, no moment update, no step count -- their chunks stay unmapped (255)
+        self._never = {id(p) for p in plist if getattr(p, "_tad_never_grad", False)}
         for gi, g in enumerate(self.param_groups):
             for p in g["params"]:
+                if id(p) in self._never:
+                    continue
                 o = self.space.offset[id(p)] // ADAMW_CHUNK
                 cg[o:o + FlatSpace.padded(p) // ADAMW_CHUNK] = gi
         self.chunk_group = cg.to(self.space.device)
@@ -97,6 +102,8 @@ class FusedAdamW(torch.optim.Optimizer):
         # chunk map is used.  Otherwise a slot is a (group, count) pair and the chunk map is rebuilt for this step.
         missing = False
         for p in self.space.params:
+            if id(p) in self._never:
+                continue
             if p.grad is None:
                 missing = True
             else:
@@ -105,14 +112,14 @@ class FusedAdamW(torch.optim.Optimizer):
         if not missing and not self._ragged:
             self.steps += 1
             chunk_group, slot_lr, slot_wd, slot_step = self.chunk_group, lrs, wds, [self.steps] * len(lrs)
-            updated = self.space.params
+            updated = [p for p in self.space.params if id(p) not in self._never] if self._never else self.space.params
         else:
             self._ragged = True
             chunk_group = torch.full((self.chunk_group.numel(),), 255, dtype=torch.uint8)
             slots, slot_lr, slot_wd, slot_step, updated = {}, [], [], [], []
             for gi, g in enumerate(self.param_groups):
                 for p in g["params"]:
-                    if p.grad is None:
+                    if p.grad is None or id(p) in self._never:
                         continue
                     t = int(self.state[p]["step"]) + 1
                     si = slots.get((gi, t))
@@ -164,4 +171,4 @@ class FusedAdamW(torch.optim.Optimizer):
             st["step"] = torch.as_tensor(float(st["step"]))
             steps = max(steps, int(st["step"]))
         self.steps = steps
-        self._ragged = len({int(self.state[p]["step"]) for p in self.space.params if self.state.get(p)}) > 1
+        self._ragged = len({int(self.state[p]["step"]) for p in self.space.params if self.state.get(p) and id(p) not in self._never}) > 1

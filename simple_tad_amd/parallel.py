@@ -103,7 +103,8 @@ class ShardSampler:
 class DataParallel(nn.Module):
     """Replicated-model data parallelism with bucketed, overlapped gradient all-reduce."""
 
-    def __init__(self, module: nn.Module, bucket_mb: float = 64.0, process_group=None, broadcast: bool = True, overlap: bool = True):
+    def __init__(self, module: nn.Module, bucket_mb: float = 64.0, process_group=None, broadcast: bool = True, overlap: bool = True,
+                 reduce_avg: Optional[bool] = None):
         """``overlap=False``: exchange every bucket in ``finish()`` after backward instead of as soon as its last gradient lands --
         required for models that use a parameter more than once per backward (weight tying, a module called twice per forward):
         the overlapped exchange announces a parameter after its FIRST gradient write and raises if it sees a second one."""
@@ -142,7 +143,9 @@ class DataParallel(nn.Module):
         start, count = 0, 0
         for i, (p, o) in enumerate(zip(order, offs)):
             end = o + FlatSpace.padded(p)
-            count += 1
+            # a parameter marked as never receiving a gradient (a learnable pos_embed that is added detached) stays in the flat
+            # layout with a zero gradient but is not waited for: its bucket is announced by the others
+            count += 0 if getattr(p, "_tad_never_grad", False) else 1
             if end - start >= limit or i == len(order) - 1:
                 self.buckets.append({"lo": start, "hi": end, "n": count, "ready": 0})
                 start, count = end, 0
@@ -156,17 +159,23 @@ class DataParallel(nn.Module):
         # read the bucket before the kernels queued on the current stream had written it: drain the stream first.  RCCL ("nccl")
         # orders its kernels after the current stream itself.
         self._drain_first = bool(dist.is_initialized() and dist.get_backend(self.pg) == "gloo" and self.flat_grad.is_cuda)
-        # RCCL averages inside the collective (ncclAvg): no separate pass over the bucket; gloo has no AVG, so there the bucket is
-        # divided by the world size first (which also keeps the sum in range)
+        # Mean over the ranks.  Default on every backend: divide the bucket by the world size, then all-reduce(SUM) -- the path the
+        # world-size-2 / 4 tests execute.  ``reduce_avg=True`` (or TAD_DP_AVG=1) takes the mean inside the collective instead
+        # (ncclAvg: one pass over each bucket less); it is opt-in until a multi-GPU RCCL run has exercised it, and the one-element
+        # probe below is a collective every rank must pass: a failure RAISES on every rank instead of being swallowed (a collective
+        # that fails on one rank leaves the communicator aborted or out of step, which would only surface later as a hang).
+        if reduce_avg is None:
+            reduce_avg = os.environ.get("TAD_DP_AVG", "0") == "1"
         self._avg_in_collective = False
-        if dist.is_initialized() and dist.get_backend(self.pg) == "nccl" and self.flat_grad.is_cuda:
-            try:  # probed once on every rank (a collective): an RCCL / torch build without AVG falls back to divide-then-sum
-                probe = torch.ones(1, dtype=torch.float32, device=self.flat_grad.device)
-                dist.all_reduce(probe, op=dist.ReduceOp.AVG, group=self.pg)
-                self._avg_in_collective = abs(float(probe.item()) - 1.0) < 1e-6
-            except Exception:  # noqa: BLE001
-                self._avg_in_collective = False
-        self._announced = set()
+        if reduce_avg and self.world > 1:
+            if not (dist.get_backend(self.pg) == "nccl" and self.flat_grad.is_cuda):
+                raise ValueError("DataParallel(reduce_avg=True) needs the nccl (RCCL) backend with GPU gradients; gloo has no AVG")
+            probe = torch.ones(1, dtype=torch.float32, device=self.flat_grad.device)
+            dist.all_reduce(probe, op=dist.ReduceOp.AVG, group=self.pg)
+            if abs(float(probe.item()) - 1.0) > 1e-6:
+                raise RuntimeError(f"DataParallel: ReduceOp.AVG of ones returned {float(probe.item())!r}")
+            self._avg_in_collective = True
+        self._announced = {}  # id(param) -> version of p.grad when it was announced
         self._sunk = set()
         self._works = []
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in order]
@@ -192,9 +201,17 @@ class DataParallel(nn.Module):
         # layernorm_bwd_sunk, right after the in-place write) and again by autograd's post-accumulate hook, which torch also runs
         # for inputs whose Function.backward returned None.  Count it once, or a bucket would be exchanged before its last
         # gradient has been written.
-        if id(p) in self._announced:
+        ver = p.grad._version if p.grad is not None else -1
+        seen = self._announced.get(id(p))
+        if seen is not None:
+            # Kernel-side sink writes go through raw pointers and leave the version counter alone; an autograd accumulation
+            # (``p.grad += dW``: a tied weight whose second use took the non-sink route) bumps it.  If that happens after the bucket
+            # has been handed to the collective, the addition would be lost silently: refuse.
+            if ver != seen:
+                raise RuntimeError("DataParallel: a parameter's gradient was accumulated again after its bucket had been announced "
+                                   "(weight tying / a module used twice per forward); build DataParallel with overlap=False")
             return
-        self._announced.add(id(p))
+        self._announced[id(p)] = ver
         b = self.buckets[self._bucket_of[id(p)]]
         b["ready"] += 1
         if b["ready"] == b["n"]:
@@ -224,6 +241,8 @@ class DataParallel(nn.Module):
         if self.world == 1 or not self.require_sync:
             return
         for b in self.buckets:  # a parameter that received no gradient this step leaves its bucket incomplete
+            if b["n"] == 0 and self.overlap:
+                continue  # only never-grad parameters: zeros on every rank
             if b["ready"] or not self.overlap:
                 b["ready"] = 0
                 self._exchange(self.flat_grad[b["lo"]:b["hi"]], async_op=False)

@@ -432,9 +432,19 @@ def _pretrain_engine(mf):
     um.MetricLogger = _Logger
     # diagnostics only (per-head gradient norms for plots); the engine asserts that they are non-zero after the loop
     um.collect_grad_norms_pretrain = lambda *a, **k: (np.ones((12, 6, 5)), np.ones((12, 6)), np.ones((2,)))
+    # The mock stands in for `utils` only while the two reference modules below bind their module-level imports; afterwards the
+    # previous entry (the REAL utils when G12 / G13 imported it first, or nothing) is put back, so that a later
+    # `import utils as ref_utils` in the same process gets the real module and a full run reaches G12 / G13.
+    prev_utils = sys.modules.get("utils")
     sys.modules["utils"] = um
-    import modeling_pretrain as mp
-    import engine_for_pretraining as efp
+    try:
+        import modeling_pretrain as mp
+        import engine_for_pretraining as efp
+    finally:
+        if prev_utils is None:
+            sys.modules.pop("utils", None)
+        else:
+            sys.modules["utils"] = prev_utils
 
     def run(model, x, mask, normlize_target=True):
         captured = {}
