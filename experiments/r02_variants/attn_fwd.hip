@@ -12,7 +12,7 @@
 // images are XOR-swizzled so all reads are bank-conflict free (tools/lds_bank_sim.py).
 #include "common.h"
 
-TAD_NAMESPACE_BEGIN
+namespace tad {
 
 constexpr int HD = 64;      // head dim
 constexpr int KV_TILE = 64; // keys per LDS tile
@@ -35,11 +35,11 @@ __device__ __forceinline__ float half_swap_sum(float x) {
 
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 
-// DMA_MODE: see attn_bwd.hip (0: next tile's LDS-DMA pieces at the top of the tile; 2: timing-only ablation, ablation builds)
+// DMA_MODE: see attn_bwd.hip (0: next tile's LDS-DMA pieces at the top of the tile; 1: K pieces behind the score products, V pieces
+// behind the exponentials; 2: timing-only ablation)
 template <bool OUT_BF16, int DMA_MODE>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, void* __restrict__ out,
-                                                       uint16_t* __restrict__ out_lo, float* __restrict__ lse, int N, int H, int B,
-                                                       float scale) {
+                                                       float* __restrict__ lse, int N, int H, int B, float scale) {
   __shared__ __attribute__((aligned(1024))) char lds[2 * 2 * KV_TILE * HD * 2];  // [buf][K|V][64 keys][128 B]
   constexpr int TILE_BYTES = KV_TILE * HD * 2;                                  // 8 KiB
   const int tid = threadIdx.x, lane = tid & 63;
@@ -61,13 +61,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
   const float c = scale * 1.44269504088896340736f;  // scale * log2(e)
 
   // Q^T fragments (B operand): lane (q, h5) holds Q[q][16ks + 8h5 .. +7]
-  op16x8 qf[4];
+  bf16x8 qf[4];
   {
     int qrow = q0 + ql;
     if (qrow > N - 1) qrow = N - 1;  // clamped rows are computed but never stored
     const uint16_t* qp = base + (int64_t)qrow * tok_stride + 8 * h5;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const op16x8*>(qp + 16 * ks);
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
   }
 
   // staging: K/V tiles go global -> LDS by LDS-DMA (no staging registers, no ds_write): a 1-KiB piece = 8 keys x 128 B; wave w
@@ -129,12 +129,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
   // The selector A has ones in rows 0 and 8 over kg {0, 2} and in rows 4 and 12 over kg {1, 3}; output register 0 of lane l is
   // D[4 (l>>4)][l & 15]: lanes 0-15 and 32-47 get the sum of query l & 15, lanes 16-31 and 48-63 that of query 16 + (l & 15) -- each
   // lane its own query (lane & 31), no cross-lane step.
-  op16x8 sel;
+  bf16x8 sel;
   {
     const int m = lane & 15, kg = lane >> 4;
     const bool on = ((m & 7) == 0 && (kg & 1) == 0) || ((m & 7) == 4 && (kg & 1) == 1);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) sel[e] = (op16_t)(on ? 1.0f : 0.0f);
+    for (int e = 0; e < 8; ++e) sel[e] = (__bf16)(on ? 1.0f : 0.0f);
   }
 
   // One K/V tile of 64 keys out of LDS buffer BUF (a literal: every LDS address below is then lane-constant + immediate).
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
   {                                                                                                                       \
     const int kv0 = (T) * KV_TILE;                                                                                        \
     const bool more_ = (T) + 1 < nt;                                                                                      \
-    if (more_ && DMA_MODE == 0) DMA_TILE((BUF) ^ 1, kv0 + KV_TILE);                                                        \
+    if (more_ && (DMA_MODE == 0 || (DMA_MODE == 1 && !wave_live))) DMA_TILE((BUF) ^ 1, kv0 + KV_TILE);                     \
     const char* kl = lds + (BUF) * 2 * TILE_BYTES;                                                                        \
     const char* vl = kl + TILE_BYTES;                                                                                     \
     if (wave_live) { /* waves whose 32 query rows all lie past the sequence only help staging the tiles */               \
@@ -151,8 +151,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
       _Pragma("unroll") for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;                                                      \
       const int key = kt * 32 + ql;                                                                                       \
       _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                                  \
-        const op16x8 kf = *reinterpret_cast<const op16x8*>(kl + key * 128 + (((2 * ks + h5) ^ swk(key)) << 4));           \
-        s[kt] = TAD_MFMA_32x32x16(kf, qf[ks], s[kt]);                                      \
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kl + key * 128 + (((2 * ks + h5) ^ swk(key)) << 4));           \
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kt], 0, 0, 0);                                      \
       }                                                                                                                   \
     }                                                                                                                     \
     if (kv0 + KV_TILE > N) { /* ragged last tile: mask keys >= N */                                                       \
@@ -162,6 +162,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
         if (key >= N) s[kt][r] = -1e30f;                                                                                  \
       }                                                                                                                   \
     }                                                                                                                     \
+    if (DMA_MODE == 1 && more_) DMA_K_((BUF) ^ 1, kv0 + KV_TILE);                                                          \
     float mloc = s[0][0];                                                                                                 \
     _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                                      \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[kt][r]);                                      \
@@ -178,11 +179,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
           _Pragma("unroll") for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;                                               \
     }                                                                                                                     \
     const float mc = m_run * c;                                                                                           \
-    op16x8 pf[2][2];                                                                                                      \
+    bf16x8 pf[2][2];                                                                                                      \
     _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                                      \
         _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2)                                                                  \
             _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                                 \
-                pf[kt][s2][j] = (op16_t)fast_exp2(s[kt][8 * s2 + j] * c - mc);                                            \
+                pf[kt][s2][j] = (__bf16)fast_exp2(s[kt][8 * s2 + j] * c - mc);                                            \
+    if (DMA_MODE == 1 && more_) DMA_V_((BUF) ^ 1, kv0 + KV_TILE);                                                          \
     f32x4 rs = {0.f, 0.f, 0.f, 0.f};                                                                                      \
     /* V^T fragments through the asm reads of common.h (the builtin made the compiler drain the DMA of the next tile here):  \
        group g = 2 kt + s2 covers keys 16g .. 16g+15; the reads of group g+1 are issued before the MFMAs of group g */     \
@@ -199,10 +201,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
           vhi[par ^ 1][dt] = lds_tr16_b64<(BUF) * 2 * TILE_BYTES + TILE_BYTES + (g_ + 1) * 16 * 128 + 8 * 128>(v_rd[dt]); \
         }                                                                                                                 \
       }                                                                                                                   \
-      rs = TAD_MFMA_16x16x32(sel, pf[g_ >> 1][g_ & 1], rs);                                \
+      rs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sel, pf[g_ >> 1][g_ & 1], rs, 0, 0, 0);                                \
       lds_wait<(g_ < 3 ? 4 : 0)>(vlo[par][0], vhi[par][0], vlo[par][1], vhi[par][1]);                                     \
       _Pragma("unroll") for (int dt = 0; dt < 2; ++dt)                                                                    \
-        o[dt] = TAD_MFMA_32x32x16(join_tr(vlo[par][dt], vhi[par][dt]), pf[g_ >> 1][g_ & 1], o[dt]); \
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_tr(vlo[par][dt], vhi[par][dt]), pf[g_ >> 1][g_ & 1], o[dt], 0, 0, 0); \
     });                                                                                                                   \
     l_run += rs[0]; /* the lane's own query: see `sel` */                                                                 \
     }                                                                                                                     \
@@ -234,15 +236,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
                     v3 = o[dt][4 * r4 + 3] * inv;
         if (OUT_BF16) {
           uint2 pk;
-          pk.x = pack_op16x2(v0, v1);
-          pk.y = pack_op16x2(v2, v3);
+          pk.x = pack_bf16x2(v0, v1);
+          pk.y = pack_bf16x2(v2, v3);
           *reinterpret_cast<uint2*>((uint16_t*)out + obase + d) = pk;
-          if (out_lo) {  // what the 16-bit rounding dropped (see tad_attn_fwd: the backward's delta is taken of out + out_lo)
-            uint2 lo;
-            lo.x = pack_op16x2(v0 - op16_lo_f32(pk.x), v1 - op16_hi_f32(pk.x));
-            lo.y = pack_op16x2(v2 - op16_lo_f32(pk.y), v3 - op16_hi_f32(pk.y));
-            *reinterpret_cast<uint2*>(out_lo + obase + d) = lo;
-          }
         } else {
           *reinterpret_cast<float4*>((float*)out + obase + d) = make_float4(v0, v1, v2, v3);
         }
@@ -251,19 +247,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
   }
 }
 
-TAD_NAMESPACE_END
+}  // namespace tad
 
 using namespace tad;
 
-namespace tad { namespace knobs { extern int attn_dma_mode; } }  // attn_bwd.hip (tad_attn_tuning)
+extern int g_attn_dma_mode;  // attn_bwd.hip (tad_attn_tuning)
 
-extern "C" int tad_attn_fwd(const uint16_t* qkv, void* out, int out_dtype, uint16_t* out_lo, float* lse, int B, int N, int H, int d,
-                            float scale, tad_stream_t stream) {
+extern "C" int tad_attn_fwd(const uint16_t* qkv, void* out, int out_dtype, float* lse, int B, int N, int H, int d, float scale,
+                            tad_stream_t stream) {
   TAD_REQUIRE(qkv && out, "attn_fwd: null pointer");
-  TAD_REQUIRE(!out_lo || out_dtype == TAD_OP16, "attn_fwd: out_lo (the rounding residual) goes with a 16-bit output");
   TAD_REQUIRE(d == HD, "attn_fwd: head_dim must be 64 (got %d)", d);
   TAD_REQUIRE(B > 0 && N > 0 && H > 0 && H <= 65535 && B <= 65535, "attn_fwd: bad shape B=%d N=%d H=%d", B, N, H);
-  TAD_REQUIRE(out_dtype == TAD_F32 || out_dtype == TAD_OP16, "attn_fwd: bad out_dtype %d", out_dtype);
+  TAD_REQUIRE(out_dtype == TAD_F32 || out_dtype == TAD_BF16, "attn_fwd: bad out_dtype %d", out_dtype);
   TAD_REQUIRE(scale > 0.f, "attn_fwd: scale must be positive");
   // the kernel addresses qkv through ONE buffer descriptor with 32-bit byte offsets (K/V staging by LDS-DMA)
   TAD_REQUIRE((int64_t)B * N * 3 * H * HD * 2 < (1ll << 32), "attn_fwd: qkv of %lld bytes exceeds the 4 GiB buffer descriptor (B=%d N=%d H=%d)",
@@ -272,14 +267,15 @@ extern "C" int tad_attn_fwd(const uint16_t* qkv, void* out, int out_dtype, uint1
   const dim3 grid((unsigned)(((N + Q_BLOCK - 1) / Q_BLOCK) * H * B)), block(256);
 #define LAUNCH_FWD(M_)                                                                                                      \
   {                                                                                                                         \
-    if (out_dtype == TAD_OP16)                                                                                              \
-      hipLaunchKernelGGL((attn_fwd_kernel<true, M_>), grid, block, 0, (hipStream_t)stream, qkv, out, out_lo, lse, N, H, B, scale);  \
+    if (out_dtype == TAD_BF16)                                                                                              \
+      hipLaunchKernelGGL((attn_fwd_kernel<true, M_>), grid, block, 0, (hipStream_t)stream, qkv, out, lse, N, H, B, scale);  \
     else                                                                                                                    \
-      hipLaunchKernelGGL((attn_fwd_kernel<false, M_>), grid, block, 0, (hipStream_t)stream, qkv, out, out_lo, lse, N, H, B, scale); \
+      hipLaunchKernelGGL((attn_fwd_kernel<false, M_>), grid, block, 0, (hipStream_t)stream, qkv, out, lse, N, H, B, scale); \
     return check_launch("attn_fwd");                                                                                        \
   }
+  if (g_attn_dma_mode == 1) LAUNCH_FWD(1)
 #ifdef TAD_GEMM_ABLATION
-  if (tad::knobs::attn_dma_mode == 2) LAUNCH_FWD(2)
+  if (g_attn_dma_mode == 2) LAUNCH_FWD(2)
 #endif
   LAUNCH_FWD(0)
 #undef LAUNCH_FWD

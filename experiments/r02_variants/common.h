@@ -1,48 +1,16 @@
 // Shared device helpers for the gfx950 (CDNA4, wave64) kernels of libtad_mi355x.so.
 #pragma once
-// 16-bit operand format of this compilation pass.  Every source that touches 16-bit GEMM / attention operands is compiled twice
-// (simple_tad_amd/build.py): once for bfloat16 (the default: entry points tad_*) and once with -DTAD_OPND_F16 for IEEE half
-// (entry points tad_*_f16, see opnd_f16_names.h).  Same kernels, same schedules, same MFMA rate; only the conversion instructions
-// (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32, shift / v_cvt_f32_f16) and the MFMA opcode differ.  Device code lives in an inline
-// namespace per pass so that equally named template instantiations of the two passes never meet at link time.
-#ifdef TAD_OPND_F16
-#include "opnd_f16_names.h"
-#define TAD_NS op_f16
-#else
-#define TAD_NS op_bf16
-#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <type_traits>
 #include "../../include/tad_mi355x.h"
 
-#define TAD_NAMESPACE_BEGIN namespace tad { inline namespace TAD_NS {
-#define TAD_NAMESPACE_END }}
-
 namespace tad {
-// shared by both passes (defined once, capi.hip)
-void set_error(const char* fmt, ...);
-int check_launch(const char* what);
-}  // namespace tad
 
-TAD_NAMESPACE_BEGIN
-
-#ifdef TAD_OPND_F16
-typedef _Float16 op16_t;
-#define TAD_OP16 TAD_F16
-#define TAD_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
-#define TAD_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
-#else
-typedef __bf16 op16_t;
-#define TAD_OP16 TAD_BF16
-#define TAD_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
-#define TAD_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
-#endif
-
-typedef __attribute__((ext_vector_type(8))) op16_t op16x8;
-typedef __attribute__((ext_vector_type(4))) op16_t op16x4;
-typedef __attribute__((ext_vector_type(2))) op16_t op16x2;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -53,6 +21,9 @@ typedef __attribute__((ext_vector_type(2))) int i32x2;
 
 constexpr int WAVE = 64;
 
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
 #define TAD_REQUIRE(cond, ...)                \
   do {                                        \
     if (!(cond)) {                            \
@@ -61,38 +32,17 @@ constexpr int WAVE = 64;
     }                                         \
   } while (0)
 
-// 16-bit operand <-> f32.  bf16: the upper half of the f32 pattern; f16: v_cvt_f32_f16.  Round-to-nearest-even on the way down;
-// the plain casts lower to v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 on gfx950 and keep a NaN a NaN.
-__device__ __forceinline__ float op16_to_f32(uint16_t v) {
-#ifdef TAD_OPND_F16
-  return (float)__builtin_bit_cast(_Float16, v);
-#else
-  return __uint_as_float(((uint32_t)v) << 16);
-#endif
-}
-// low / high element of a packed pair
-__device__ __forceinline__ float op16_lo_f32(uint32_t w) {
-#ifdef TAD_OPND_F16
-  return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu));
-#else
-  return __uint_as_float(w << 16);
-#endif
-}
-__device__ __forceinline__ float op16_hi_f32(uint32_t w) {
-#ifdef TAD_OPND_F16
-  return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16));
-#else
-  return __uint_as_float(w & 0xffff0000u);
-#endif
-}
-__device__ __forceinline__ uint16_t f32_to_op16(float f) {
-  op16_t b = (op16_t)f;
+__device__ __forceinline__ float bf16_to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even; plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 and keeps NaN a NaN
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+  __bf16 b = (__bf16)f;
   return __builtin_bit_cast(uint16_t, b);
 }
-__device__ __forceinline__ uint32_t pack_op16x2(float lo, float hi) {
-  op16x2 v;
-  v[0] = (op16_t)lo;
-  v[1] = (op16_t)hi;
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  bf16x2 v;
+  v[0] = (__bf16)lo;
+  v[1] = (__bf16)hi;
   return __builtin_bit_cast(uint32_t, v);
 }
 
@@ -146,7 +96,7 @@ __device__ __forceinline__ s16x4 lds_tr16_b64(uint32_t addr) {
   return r;
 }
 template <typename T, int OFF>
-__device__ __forceinline__ T lds_read_b128(uint32_t addr) {  // plain 16-byte read (T = op16x8, f32x4 ...), same contract as lds_tr16_b64
+__device__ __forceinline__ T lds_read_b128(uint32_t addr) {  // plain 16-byte read (T = bf16x8, f32x4 ...), same contract as lds_tr16_b64
   static_assert(OFF >= 0 && OFF < 65536 && sizeof(T) == 16, "ds offset field is 16 bits; 16-byte result");
   T r;
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
@@ -173,10 +123,10 @@ template <int N, typename A, typename B, typename C, typename D, typename E, typ
 __device__ __forceinline__ void lds_wait(A& a, B& b, C& c, D& d, E& e, F& f, G& g, H& h) {
   asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : TAD_LGKM(N));
 }
-__device__ __forceinline__ op16x8 join_tr(const s16x4& lo, const s16x4& hi) {
+__device__ __forceinline__ bf16x8 join_tr(const s16x4& lo, const s16x4& hi) {
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return __builtin_bit_cast(op16x8, v);
+  return __builtin_bit_cast(bf16x8, v);
 }
 // compile-time loop: f(std::integral_constant<int, I>) for I in [BEGIN, END)
 template <int BEGIN, int END, typename F>
@@ -261,12 +211,12 @@ __device__ __forceinline__ void gelu_fast_row(float* v) {
     v[2 * i + 1] = y[1];
   }
 }
-// v[0..2W) *= gelu'(h), h given as W packed 16-bit operand pairs
+// v[0..2W) *= gelu'(h), h given as W packed bf16 pairs
 template <int W>
 __device__ __forceinline__ void gelu_grad_fast_row(float* v, const uint32_t* hw) {
   f32x2 x[W], g[W];
 #pragma unroll
-  for (int i = 0; i < W; ++i) x[i] = f32x2{op16_lo_f32(hw[i]), op16_hi_f32(hw[i])};
+  for (int i = 0; i < W; ++i) x[i] = f32x2{__uint_as_float(hw[i] << 16), __uint_as_float(hw[i] & 0xffff0000u)};
   half_plus_x_poly2(x, g, DGELU_C, DGELU_XMAX);
 #pragma unroll
   for (int i = 0; i < W; ++i) {
@@ -324,4 +274,4 @@ __device__ __forceinline__ void stg_u2(uint2* p, const uint2& v) {
   else *reinterpret_cast<v2*>(p) = t;
 }
 
-TAD_NAMESPACE_END
+}  // namespace tad

@@ -1,11 +1,11 @@
-// 16-bit-operand (bf16 / f16, see common.h) MFMA GEMMs for the Linear layers of the Video-ViT path (gfx950, wave64).
+// bf16 MFMA GEMMs for the Linear layers of the Video-ViT path (gfx950, wave64).
 //
 //  gemm_nt : C[M,N] = A[M,K] * B[N,K]^T (+ fused epilogue)      forward Linear and input-gradient (with W^T)
 //  gemm_tn : C[N,K] = P[Mr,N]^T * Q[Mr,K]  (split over Mr)        weight gradient
 //
 // Both stage 64-deep K-tiles global -> LDS with 16-byte LDS-DMA loads (buffer_load ... lds; out-of-range rows
 // read as zero through the buffer descriptor's bounds check), double-buffered, one barrier per K-tile, and use
-// v_mfma_f32_16x16x32_{bf16,f16}.  The LDS images are XOR-swizzled on the 16-byte chunk index (the swizzle is applied
+// v_mfma_f32_16x16x32_bf16.  The LDS images are XOR-swizzled on the 16-byte chunk index (the swizzle is applied
 // to the per-lane *source* address because the DMA destination is lane-linear) so that every ds_read_b128 /
 // ds_read_b64_tr_b16 below is bank-conflict free (tools/lds_bank_sim.py).
 //
@@ -22,7 +22,7 @@
 #include <string>
 #include "common.h"
 
-TAD_NAMESPACE_BEGIN
+namespace tad {
 
 int launch_reduce_partials(const float* partial, float* out, int splits, int64_t n, int accumulate, hipStream_t st);
 int launch_reduce_col_ranges(const float* partial, int N, int splits, int c0, float* out0, int c1, float* out1, int n, int accumulate,
@@ -63,6 +63,10 @@ struct GemmNT {
   int debug;  // ablation (TAD_GEMM_DEBUG, timing only, wrong results): 1 = no DMA inside the K loop, 2 = no MFMA, 4 = no epilogue,
               // 8 = (gemm_tn) no fragment reads and no MFMA: staging and barriers only, 16 = (gemm_tn) unswizzled DMA source
   int group_m;        // tile raster: row panels swept per column panel before moving to the next column panel (L2 reuse)
+  int stagger_ticks;  // persistent kernel: span (10 ns ticks of s_memrealtime) over which the workgroups of an XCD spread their start
+  int stagger_group;  // workgroups of an XCD start in groups of this many (power of two)
+  int* sched;        // persistent kernel: 8 tile counters (one per XCD) of this launch, or null = fixed tile lists
+  int* sched_clear;  // 8 counters of another slot of the ring to reset (see launch_nt_variant)
   unsigned long long* stamps;  // debug timeline (tad_linear_debug_stamps): per workgroup 64 slots of 4 x s_memrealtime, or null
 };
 
@@ -90,14 +94,37 @@ __device__ __forceinline__ void stage_tile(const void* gbase, int gbytes, char* 
   }
 }
 
+#ifndef TAD_DMA_SPREAD
+#define TAD_DMA_SPREAD 0
+#endif
+#ifndef TAD_NT_PIPE
+#define TAD_NT_PIPE 0
+#endif
 #ifndef TAD_STORE_AUX
 #define TAD_STORE_AUX 2  // cache policy of the gemm_nt output stores: 2 = nt (streamed: the 77-308 MB outputs do not displace the operand panels the
                          // other workgroups of the XCD are re-reading; measured 691.3 -> 695.8 clips/s over four alternating pairs of runs; 0 = default,
                          // 16 = sc1 measured neutral)
 #endif
-#ifndef TAD_NT_PEEL
-#define TAD_NT_PEEL 1  // last K-tile of the persistent bias-only 16-bit kernel peeled (see PEEL in gemm_nt_kernel); 0 = the round-1 schedule
+#ifndef TAD_STORE_AUX_RES
+#define TAD_STORE_AUX_RES TAD_STORE_AUX  // the same for the f32 residual-stream outputs (build-time experiment: a different policy for them)
 #endif
+#ifndef TAD_NT_PEEL
+#define TAD_NT_PEEL 1  // last K-tile of the persistent bias-only bf16 kernel peeled (see PEEL in gemm_nt_kernel); 0 = the round-1 schedule
+#endif
+#ifndef TAD_EPI_LOAD_AUX
+#define TAD_EPI_LOAD_AUX 0  // cache policy of what the epilogue reads once (f32 residual rows, bf16 pre-activation rows): build-time experiment
+#endif
+#ifndef TAD_NT_TWO_WG
+#define TAD_NT_TWO_WG 0  // build-time variant: tile configuration 6 (two independent 4-wave workgroups per CU), see launch_nt_variant
+#endif
+// piece I of a stage only (stage_tile issues all PIECES at once): for the build-time variant that spreads a stage's pieces between the
+// MFMA groups of a k-step (-DTAD_DMA_SPREAD=1)
+template <int NW, bool SCALAR_ADD = false>
+__device__ __forceinline__ void stage_piece(const void* gbase, int gbytes, char* tile, uint32_t off_i, uint32_t add, int wave, int i) {
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(gbase), 0, gbytes, 0x00020000);
+  if (SCALAR_ADD) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(tile + (i * NW + wave) * 1024), 16, off_i, add, 0, 0);
+  else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(tile + (i * NW + wave) * 1024), 16, off_i + add, 0, 0, 0);
+}
 
 // wait until at most `stages_in_flight` later stages (LOADS DMA instructions each, per wave) plus EXTRA younger vector-memory
 // instructions are still outstanding
@@ -124,12 +151,16 @@ __device__ __forceinline__ void lds_barrier() {
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
+// swizzle of the 16-byte chunk index for 64-byte LDS rows (K-tile depth 32): conflict-free for the same fragment reads
+__device__ __forceinline__ int sw_nt32(int row) { return ((row >> 3) & 1) << 1; }
+template <int BKT>
+__device__ __forceinline__ int sw_rows(int row) { return BKT == 64 ? sw_nt(row) : sw_nt32(row); }
+
 // PERSIST: one workgroup per CU walks a strided list of tiles (see the comment at the tile loop).
 // DIRECT: the epilogue runs on the accumulator registers and stores straight from the MFMA layout (16 rows x 64 contiguous bytes
 // per store instruction); otherwise the accumulators are transposed through the LDS first (whole rows per instruction).
-template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int EPI, bool OUT_BF16, bool PERSIST, bool DIRECT>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const GemmNT p) {
-  constexpr int BKT = BK;
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int BKT, int MIN_WAVES, int EPI, bool OUT_BF16, bool PERSIST, bool DIRECT, bool DYN = false>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES) void gemm_nt_kernel(const GemmNT p) {
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr bool IS_RES = (EPI == EPI_RESIDUAL || EPI == EPI_RESMOD);
   constexpr int ROWB = BKT * 2;               // bytes per LDS row
@@ -164,11 +195,20 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
   // ids first + j, first + j + step, ... of its XCD's range, so at any time the XCD works on ~step consecutive ids as above.
   // What is gained over one launch-scheduled workgroup per tile: the first K-tile of the next tile (with the register-layout
   // epilogue: its whole prologue) is fetched under the epilogue, and no workgroup launch sits between two tiles.
+  // Optional staggered starts (stagger_ticks > 0: workgroup j of an XCD waits j / step of a K-loop time before its first tile, so the
+  // store bursts of the epilogues spread over the K loops of the other CUs) were measured NOT to shorten the epilogues -- their own
+  // LDS / VALU time, not HBM contention, is what is left -- and default to off (profiles/README.md).
   const int GROUP_M = p.group_m;  // row panels per column-panel group (launch_nt_variant; tad_linear_tuning("group_m"))
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
   const int per_group = GROUP_M * tiles_n;
-  int t_cur, t_end, t_step, t_first = 0;
+  // Dynamic lists (p.sched): only the first tile of a workgroup is fixed (first + j); every further one is pulled from its XCD's
+  // counter (one returning atomic per tile, issued right after a K loop -- never inside it -- and consumed after the next one, so a
+  // workgroup always holds one tile in reserve).  A
+  // workgroup that starts late -- its CU was busy with another stream's kernel, e.g. an RCCL collective beside the backward pass --
+  // then simply finds fewer tiles left, instead of doubling the launch's time with a full list of its own.
+  __shared__ int next_idx_lds[1];
+  int t_cur, t_end, t_step, t_first = 0, fetched = 0;
   const int xcd = blockIdx.x & 7;
   if (PERSIST) {
     const int j = blockIdx.x >> 3;
@@ -176,6 +216,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
     t_cur = t_first + j;
     t_end = t_first + (tiles_m * tiles_n >> 3) + ((xcd < ((tiles_m * tiles_n) & 7)) ? 1 : 0);
     t_step = gridDim.x >> 3;
+    if (DYN && p.sched_clear && blockIdx.x == 0 && tid < 8) p.sched_clear[tid] = 0;
+    if (DYN && tid == 0) fetched = __hip_atomic_fetch_add(p.sched + xcd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (p.stagger_ticks > 0) {
+      const int ph = j & ~(p.stagger_group - 1);
+      const uint64_t wait = (uint64_t)p.stagger_ticks * ph / t_step;
+      const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+      while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+    }
   } else {
     t_cur = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     t_end = t_cur + 1;
@@ -201,11 +249,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
   {                                                                                                                    \
     _Pragma("unroll") for (int i = 0; i < BM / (RPP * NW); ++i) {                                                      \
       const int row = (i * NW + wave) * RPP + drow;                                                                    \
-      a_off[i] = (uint32_t)(m0 + row) * (uint32_t)(p.K * 2) + (uint32_t)((dchunk ^ sw_nt(row)) * 16);           \
+      a_off[i] = (uint32_t)(m0 + row) * (uint32_t)(p.K * 2) + (uint32_t)((dchunk ^ sw_rows<BKT>(row)) * 16);           \
     }                                                                                                                  \
     _Pragma("unroll") for (int i = 0; i < BN / (RPP * NW); ++i) {                                                      \
       const int row = (i * NW + wave) * RPP + drow;                                                                    \
-      b_off[i] = (uint32_t)(n0 + row) * (uint32_t)(p.K * 2) + (uint32_t)((dchunk ^ sw_nt(row)) * 16);           \
+      b_off[i] = (uint32_t)(n0 + row) * (uint32_t)(p.K * 2) + (uint32_t)((dchunk ^ sw_rows<BKT>(row)) * 16);           \
     }                                                                                                                  \
   }
 #define STAGE_NT(buf, kt) \
@@ -221,7 +269,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
   for (int i = 0; i < MREP; ++i) {
     const int row = wm * WTM + i * 16 + c;
     a_rd[i] = row * ROWB;
-    a_sw[i] = sw_nt(row);
+    a_sw[i] = sw_rows<BKT>(row);
   }
   // B-operand rows (output cols n), permuted so that the 4 lanes (kq = 0..3) that share an output row write one contiguous
   // 64-byte segment per store instruction:
@@ -235,26 +283,58 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
     const int rl = OUT_BF16 ? (32 * (j >> 1) + 8 * (c >> 2) + 4 * (j & 1) + (c & 3)) : (16 * j + 4 * (c >> 2) + (c & 3));
     const int row = wn * WTN + rl;
     b_rd[j] = row * ROWB;
-    b_sw[j] = sw_nt(row);
+    b_sw[j] = sw_rows<BKT>(row);
   }
 
   const int nk = p.K / BKT;
 #define FRAG_A(dst, base, ks) \
   _Pragma("unroll") for (int i = 0; i < MREP; ++i)  \
-      dst[i] = *reinterpret_cast<const op16x8*>((base) + a_rd[i] + ((((KSTEPS > 1 ? 4 * (ks) : 0) + kq) ^ a_sw[i]) << 4))
+      dst[i] = *reinterpret_cast<const bf16x8*>((base) + a_rd[i] + ((((KSTEPS > 1 ? 4 * (ks) : 0) + kq) ^ a_sw[i]) << 4))
 #define FRAG_B(dst, base, ks) \
   _Pragma("unroll") for (int j = 0; j < NREP; ++j)  \
-      dst[j] = *reinterpret_cast<const op16x8*>((base) + b_rd[j] + ((((KSTEPS > 1 ? 4 * (ks) : 0) + kq) ^ b_sw[j]) << 4))
+      dst[j] = *reinterpret_cast<const bf16x8*>((base) + b_rd[j] + ((((KSTEPS > 1 ? 4 * (ks) : 0) + kq) ^ b_sw[j]) << 4))
 #define MFMA_BLOCK(afr, bfr_)                                                                            \
   if (!(DBG_BITS(p) & 2)) {                                                                                  \
     _Pragma("unroll") for (int i = 0; i < MREP; ++i)                                                     \
         _Pragma("unroll") for (int j = 0; j < NREP; ++j)                                                 \
-            acc[i][j] = TAD_MFMA_16x16x32(bfr_[j], afr[i], acc[i][j]);    \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr_[j], afr[i], acc[i][j], 0, 0, 0);    \
   } else {                                                                                               \
     _Pragma("unroll") for (int i = 0; i < MREP; ++i) asm volatile("" ::"v"(afr[i]));                     \
     _Pragma("unroll") for (int j = 0; j < NREP; ++j) asm volatile("" ::"v"(bfr_[j]));                    \
   }
+  // Build-time variant -DTAD_DMA_SPREAD=1 (TAD_BUILD_DEFINES, tools/exp_build_ab.sh): the DMA pieces of the next stage go out one per
+  // m-row of MFMAs instead of all in front of the k-step (an LDS-DMA piece blocks the issuing wave for 60-185 cycles depending on what
+  // the phase carries)
+  constexpr int APIECES = BM / (RPP * NW), BPIECES = BN / (RPP * NW);
+#define MFMA_BLOCK_DMA(afr, bfr_, buf, kt_, cond_)                                                                           \
+  {                                                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < MREP; ++i) {                                                                       \
+      _Pragma("unroll") for (int j = 0; j < NREP; ++j)                                                                       \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr_[j], afr[i], acc[i][j], 0, 0, 0);                           \
+      if (!(cond_)) continue; /* wave-uniform: a scalar branch around one buffer_load; the MFMAs are unconditional */        \
+      if (i < APIECES) stage_piece<NW, true>(p.A, a_bytes, lds + (buf) * STAGE_BYTES, a_off[i < APIECES ? i : 0], (uint32_t)(kt_) * ROWB, wave, i); \
+      else if (i - APIECES < BPIECES)                                                                                        \
+        stage_piece<NW, true>(p.B, b_bytes, lds + (buf) * STAGE_BYTES + A_BYTES, b_off[(i - APIECES) < BPIECES ? (i - APIECES) : 0], (uint32_t)(kt_) * ROWB, wave, i - APIECES); \
+    }                                                                                                                        \
+  }
   const bool late = wave >= NW / 2;  // wave-uniform (scalar branches); the MFMA code is shared by both halves
+  // Build-time variant -DTAD_NT_PIPE=1 (256 x 256 tile): fragment reads as inline asm in a fixed software pipeline.  hipcc streams the A
+  // fragments just in time (2 ds_read_b128, s_waitcnt lgkmcnt(1), 4 MFMAs ...: each group of four MFMAs waits for a read issued right in
+  // front of it).  Here the 12 reads of k-step 0 go out back to back, row i's A register is refilled with its k-step-1 fragment as soon
+  // as row i's four MFMAs are issued (in place: no second A set), the four B fragments of k-step 1 go into a second B set behind rows
+  // 0..3, and every wait is a counted lgkmcnt that leaves the younger reads in flight: one exposed LDS latency per K-tile (behind the
+  // barrier; the next tile's data may not be read earlier) instead of one per MFMA group.
+  constexpr bool PIPE = TAD_NT_PIPE && BM == 256 && BN == 256 && KSTEPS == 2 && MREP == 8 && NREP == 4 && STAGES == 2 &&
+                        (EPI == EPI_PLAIN || EPI == EPI_GELU);  // (the residual / GELU-backward variants have no registers left: they spill)
+  uint32_t pa[PIPE ? MREP : 1], pb[PIPE ? NREP : 1];  // lane-constant LDS byte addresses (stage 0, k-step 0); k-step 1 = address ^ 64
+  if constexpr (PIPE) {
+    const uint32_t l0 = lds_addr(lds);
+#pragma unroll
+    for (int i = 0; i < MREP; ++i) pa[i] = l0 + a_rd[i] + (uint32_t)((kq ^ a_sw[i]) << 4);
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) pb[j] = l0 + b_rd[j] + (uint32_t)((kq ^ b_sw[j]) << 4);
+  }
+
   // epilogue geometry (see the epilogue below)
   constexpr int MREP_C = CROWS / (16 * WAVES_M);     // m-fragments each wave contributes to a chunk
   constexpr int NCHUNK = MREP / MREP_C;
@@ -293,7 +373,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
   // 0, stores are dropped), columns >= N get an out-of-range offset explicitly.  No per-lane branches, and the barriers of the
   // epilogue wait for LDS traffic only (lgkmcnt) -- a __syncthreads() would also drain every store issued so far (vmcnt(0)).
   constexpr uint32_t OOB = 0x80000000u;  // >= any descriptor size accepted by the launcher
-  constexpr int ST_AUX = TAD_STORE_AUX;  // cache policy of the output stores
+  constexpr int ST_AUX = IS_RES ? TAD_STORE_AUX_RES : TAD_STORE_AUX;  // cache policy of the output stores
   constexpr int ESZ = OUT_BF16 ? 2 : 4;
   const uint32_t mn_elems = (uint32_t)p.M * (uint32_t)p.N;
   const auto c_rs = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)(mn_elems * ESZ), 0x00020000);
@@ -324,19 +404,19 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
       if (IS_RES) {                                                                                        \
         if (EPI == EPI_RESMOD) o = (nn < p.N && m < p.M) ? (uint32_t)((m + p.row_base) % p.res_mod) * (uint32_t)p.N + (uint32_t)nn : OOB;  \
         const uint32_t rb = o == OOB ? OOB : o * 4;                                                                     \
-        extra[buf][jj][0] = __builtin_amdgcn_raw_buffer_load_b128(res_rs, rb, 0, 0);                                    \
-        if (CPL == 8) extra[buf][jj][EXW - 1] = __builtin_amdgcn_raw_buffer_load_b128(res_rs, fulld ? rb + 16 : OOB, 0, 0); \
+        extra[buf][jj][0] = __builtin_amdgcn_raw_buffer_load_b128(res_rs, rb, 0, TAD_EPI_LOAD_AUX);                                    \
+        if (CPL == 8) extra[buf][jj][EXW - 1] = __builtin_amdgcn_raw_buffer_load_b128(res_rs, fulld ? rb + 16 : OOB, 0, TAD_EPI_LOAD_AUX); \
       } else {                                                                                                          \
         const uint32_t hb = o == OOB ? OOB : o * 2;                                                                     \
         if (CPL == 8) {                                                                                                 \
-          if (n8) extra[buf][jj][0] = __builtin_amdgcn_raw_buffer_load_b128(h_rs, hb, 0, 0);                            \
+          if (n8) extra[buf][jj][0] = __builtin_amdgcn_raw_buffer_load_b128(h_rs, hb, 0, TAD_EPI_LOAD_AUX);                            \
           else {                                                                                                        \
-            const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(h_rs, hb, 0, 0);                                      \
-            const u32x2 hi = __builtin_amdgcn_raw_buffer_load_b64(h_rs, fulld ? hb + 8 : OOB, 0, 0);                    \
+            const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(h_rs, hb, 0, TAD_EPI_LOAD_AUX);                                      \
+            const u32x2 hi = __builtin_amdgcn_raw_buffer_load_b64(h_rs, fulld ? hb + 8 : OOB, 0, TAD_EPI_LOAD_AUX);                    \
             extra[buf][jj][0] = u32x4{lo[0], lo[1], hi[0], hi[1]};                                                      \
           }                                                                                                             \
         } else {                                                                                                        \
-          const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(h_rs, hb, 0, 0);                                        \
+          const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(h_rs, hb, 0, TAD_EPI_LOAD_AUX);                                        \
           extra[buf][jj][0] = u32x4{lo[0], lo[1], 0u, 0u};                                                              \
         }                                                                                                               \
       }                                                                                                                 \
@@ -351,19 +431,19 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
       if (IS_RES) {                                                                                        \
         if (EPI == EPI_RESMOD) o = (nvalid && m < p.M) ? (uint32_t)((m + p.row_base) % p.res_mod) * (uint32_t)p.N + (uint32_t)n : OOB;     \
         const uint32_t rb = o == OOB ? OOB : o * 4;                                                                     \
-        extra[buf][r][0] = __builtin_amdgcn_raw_buffer_load_b128(res_rs, rb, 0, 0);                                     \
-        if (CPL == 8) extra[buf][r][EXW - 1] = __builtin_amdgcn_raw_buffer_load_b128(res_rs, full ? rb + 16 : OOB, 0, 0); \
+        extra[buf][r][0] = __builtin_amdgcn_raw_buffer_load_b128(res_rs, rb, 0, TAD_EPI_LOAD_AUX);                                     \
+        if (CPL == 8) extra[buf][r][EXW - 1] = __builtin_amdgcn_raw_buffer_load_b128(res_rs, full ? rb + 16 : OOB, 0, TAD_EPI_LOAD_AUX); \
       } else {                                                                                                          \
         const uint32_t hb = o == OOB ? OOB : o * 2;                                                                     \
         if (CPL == 8) {                                                                                                 \
-          if (n8) extra[buf][r][0] = __builtin_amdgcn_raw_buffer_load_b128(h_rs, hb, 0, 0);                             \
+          if (n8) extra[buf][r][0] = __builtin_amdgcn_raw_buffer_load_b128(h_rs, hb, 0, TAD_EPI_LOAD_AUX);                             \
           else {                                                                                                        \
-            const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(h_rs, hb, 0, 0);                                      \
-            const u32x2 hi = __builtin_amdgcn_raw_buffer_load_b64(h_rs, full ? hb + 8 : OOB, 0, 0);                     \
+            const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(h_rs, hb, 0, TAD_EPI_LOAD_AUX);                                      \
+            const u32x2 hi = __builtin_amdgcn_raw_buffer_load_b64(h_rs, full ? hb + 8 : OOB, 0, TAD_EPI_LOAD_AUX);                     \
             extra[buf][r][0] = u32x4{lo[0], lo[1], hi[0], hi[1]};                                                       \
           }                                                                                                             \
         } else {                                                                                                        \
-          const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(h_rs, hb, 0, 0);                                        \
+          const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(h_rs, hb, 0, TAD_EPI_LOAD_AUX);                                        \
           extra[buf][r][0] = u32x4{lo[0], lo[1], 0u, 0u};                                                               \
         }                                                                                                               \
       }                                                                                                                 \
@@ -406,7 +486,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
     // the barrier that opens this K-tile proves it), and the barrier behind the K loop disappears (the next tile's first barrier orders its DMA
     // into slot 1 behind this tile's last reads).  Measured against the unpeeled build (bit-identical results): qkv forward 202 -> 192 us, the four
     // bias-only shapes of a block 677 -> 660 us, the training step 684.4 -> 686.7 clips/s over three alternating pairs.
-    constexpr bool PEEL_OK = TAD_NT_PEEL && PERSIST && DIRECT && EPI == EPI_PLAIN && OUT_BF16 && BM == 256 && BN == 256 && KSTEPS == 2 &&
+    constexpr bool PEEL_OK = TAD_NT_PEEL && PERSIST && !DYN && DIRECT && EPI == EPI_PLAIN && OUT_BF16 && BM == 256 && BN == 256 && KSTEPS == 2 &&
                              STAGES == 2;
     const bool peel = PEEL_OK && nk >= 2 && (nk & 1) == 0 && !(DBG_BITS(p) & 7);
     peeled = peel;
@@ -429,15 +509,51 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
       // (wave w and w + NW/2) therefore issue them at different times: the older half before its first k-step, the younger
       // half between its two k-steps, so the SIMD's matrix pipe always has one wave feeding it.
       const bool dma = more && !(DBG_BITS(p) & 1);
-      op16x8 af[MREP], bfr[NREP];
-      if (dma && !late) { STAGE_NT(wr_now, kt_next); }
+      constexpr bool spread = TAD_DMA_SPREAD && MREP >= APIECES + BPIECES && KSTEPS == 2;
+      if constexpr (PIPE) {
+        const uint32_t so = (uint32_t)((sa - lds));  // byte offset of this K-tile's stage (0 or STAGE_BYTES)
+        bf16x8 a[MREP], b[NREP], b2[NREP];
+        if (dma && !late) { STAGE_NT(wr_now, kt_next); }
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) b[j] = lds_read_b128<bf16x8, A_BYTES>(pb[j] + so);
+#pragma unroll
+        for (int i = 0; i < MREP; ++i) a[i] = lds_read_b128<bf16x8, 0>(pa[i] + so);
+        // k-step 0.  Reads still in flight in front of row i: a[i+1 .. 7] and the 2 i (i <= 4; 8 + (i - 4) beyond) refills issued so far
+        static_for<0, MREP>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          constexpr int inflight = (MREP - 1 - i) + (i <= NREP ? 2 * i : 2 * NREP + (i - NREP));
+          if constexpr (i == 0) lds_wait<inflight>(b[0], b[1], b[2], b[3], a[0]);
+          else lds_wait<inflight>(a[i]);
+#pragma unroll
+          for (int j = 0; j < NREP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          a[i] = lds_read_b128<bf16x8, 0>((pa[i] ^ 64u) + so);
+          if constexpr (i < NREP) b2[i] = lds_read_b128<bf16x8, A_BYTES>((pb[i] ^ 64u) + so);
+        });
+        if (dma && late) { STAGE_NT(wr_now, kt_next); }
+        // k-step 1: issue order of its reads was a'0 b'0 a'1 b'1 a'2 b'2 a'3 b'3 a'4 a'5 a'6 a'7
+        static_for<0, MREP>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          constexpr int inflight = i < NREP ? MREP - NREP : MREP - 1 - i;
+          if constexpr (i == 0) lds_wait<inflight>(b2[0], b2[1], b2[2], b2[3], a[0], a[1], a[2], a[3]);
+          else lds_wait<inflight>(a[i]);
+#pragma unroll
+          for (int j = 0; j < NREP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b2[j], a[i], acc[i][j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        continue;
+      }
+      bf16x8 af[MREP], bfr[NREP];
+      if (dma && !spread && (!late || KSTEPS == 1)) { STAGE_NT(wr_now, kt_next); }
       FRAG_B(bfr, sb, 0);
       FRAG_A(af, sa, 0);
-      MFMA_BLOCK(af, bfr);
-      if (dma && late) { STAGE_NT(wr_now, kt_next); }
-      FRAG_B(bfr, sb, 1);
-      FRAG_A(af, sa, 1);
-      MFMA_BLOCK(af, bfr);
+      if constexpr (spread) { MFMA_BLOCK_DMA(af, bfr, wr_now, kt_next, dma && !late); } else { MFMA_BLOCK(af, bfr); }
+      if (KSTEPS == 2) {
+        if (dma && !spread && late) { STAGE_NT(wr_now, kt_next); }
+        FRAG_B(bfr, sb, 1);
+        FRAG_A(af, sa, 1);
+        if constexpr (spread) { MFMA_BLOCK_DMA(af, bfr, wr_now, kt_next, dma && late); } else { MFMA_BLOCK(af, bfr); }
+      }
     }
     if constexpr (PEEL_OK) {
       if (peel) {
@@ -450,7 +566,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
           TILE_OFFSETS();
           STAGE_NT(0, 0);
         }
-        op16x8 b0[NREP], b1[NREP];
+        bf16x8 b0[NREP], b1[NREP];
         FRAG_B(b0, sb, 0);
         FRAG_B(b1, sb, 1);
         const bool n8p = (p.N & 7) == 0;
@@ -463,8 +579,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
             const bool fulld = nn + 8 <= p.N;
             const uint32_t o = nn < p.N ? (uint32_t)m * (uint32_t)p.N + (uint32_t)nn : OOB;
             const uint32_t ob = o == OOB ? OOB : o * 2;
-            const u32x2 lo = u32x2{pack_op16x2(acc[i][2 * jj][0], acc[i][2 * jj][1]), pack_op16x2(acc[i][2 * jj][2], acc[i][2 * jj][3])};
-            const u32x2 hi = u32x2{pack_op16x2(acc[i][2 * jj + 1][0], acc[i][2 * jj + 1][1]), pack_op16x2(acc[i][2 * jj + 1][2], acc[i][2 * jj + 1][3])};
+            const u32x2 lo = u32x2{pack_bf16x2(acc[i][2 * jj][0], acc[i][2 * jj][1]), pack_bf16x2(acc[i][2 * jj][2], acc[i][2 * jj][3])};
+            const u32x2 hi = u32x2{pack_bf16x2(acc[i][2 * jj + 1][0], acc[i][2 * jj + 1][1]), pack_bf16x2(acc[i][2 * jj + 1][2], acc[i][2 * jj + 1][3])};
             if (n8p) __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[0], lo[1], hi[0], hi[1]}, c_rs, ob, 0, ST_AUX);
             else {
               __builtin_amdgcn_raw_buffer_store_b64(lo, c_rs, ob, 0, ST_AUX);
@@ -474,12 +590,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
         };
         static_for<0, MREP>([&](auto ic) {
           constexpr int i = decltype(ic)::value;
-          const op16x8 a0 = *reinterpret_cast<const op16x8*>(sa + a_rd[i] + (((0 + kq) ^ a_sw[i]) << 4));
-          const op16x8 a1 = *reinterpret_cast<const op16x8*>(sa + a_rd[i] + (((4 + kq) ^ a_sw[i]) << 4));
+          const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(sa + a_rd[i] + (((0 + kq) ^ a_sw[i]) << 4));
+          const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(sa + a_rd[i] + (((4 + kq) ^ a_sw[i]) << 4));
 #pragma unroll
-          for (int j = 0; j < NREP; ++j) acc[i][j] = TAD_MFMA_16x16x32(b0[j], a0, acc[i][j]);
+          for (int j = 0; j < NREP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j], a0, acc[i][j], 0, 0, 0);
 #pragma unroll
-          for (int j = 0; j < NREP; ++j) acc[i][j] = TAD_MFMA_16x16x32(b1[j], a1, acc[i][j]);
+          for (int j = 0; j < NREP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], a1, acc[i][j], 0, 0, 0);
           if constexpr (i >= 1) {
             store_row(std::integral_constant<int, i - 1>{});
             __builtin_amdgcn_sched_barrier(0);
@@ -495,8 +611,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
   // transposed through the LDS in chunks of CROWS rows and every global load / store of a wave covers whole contiguous rows
   // (512 B - 1 KiB runs).  The variant (EPI, OUT_BF16) is a template parameter, offsets are 32-bit buffer offsets, the rows read
   // besides the accumulators come one chunk ahead (ISSUE_EXTRA), and the LDS reads of a chunk are batched BATCH rows at a time.
-  t_cur += t_step;
-  if (!peeled) block_barrier();  // every wave is done with the ring
+  if (PERSIST && DYN) {
+    if (tid == 0) {
+      next_idx_lds[0] = fetched;  // (the compiler waits for the atomic issued one tile ago -- or at kernel start -- here)
+      fetched = __hip_atomic_fetch_add(p.sched + xcd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the tile after next
+    }
+    lds_barrier();  // every wave is done with the ring (its LDS reads were consumed by the MFMAs above); next_idx_lds is published
+    t_cur = t_first + t_step + __builtin_amdgcn_readfirstlane(next_idx_lds[0]);
+  } else {
+    t_cur += t_step;
+    if (!peeled) block_barrier();  // every wave is done with the ring
+  }
   const bool has_next = PERSIST && t_cur < t_end;
   STAMP(1);
   if (has_next && !peeled) {
@@ -546,9 +671,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
         if (EPI == EPI_GELU) {
           if (p.preact) {
             const uint32_t pb = o == OOB ? OOB : o * 2;
-            const u32x2 lo = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
+            const u32x2 lo = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
             if (CPL == 8) {
-              const u32x2 hi = u32x2{pack_op16x2(v[CPL - 4], v[CPL - 3]), pack_op16x2(v[CPL - 2], v[CPL - 1])};
+              const u32x2 hi = u32x2{pack_bf16x2(v[CPL - 4], v[CPL - 3]), pack_bf16x2(v[CPL - 2], v[CPL - 1])};
               if (n8) __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[0], lo[1], hi[0], hi[1]}, pre_rs, pb, 0, ST_AUX);
               else {
                 __builtin_amdgcn_raw_buffer_store_b64(lo, pre_rs, pb, 0, ST_AUX);
@@ -580,8 +705,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
           }
         }
         if (OUT_BF16) {
-          const u32x2 lo = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
-          const u32x2 hi = u32x2{pack_op16x2(v[CPL - 4], v[CPL - 3]), pack_op16x2(v[CPL - 2], v[CPL - 1])};
+          const u32x2 lo = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          const u32x2 hi = u32x2{pack_bf16x2(v[CPL - 4], v[CPL - 3]), pack_bf16x2(v[CPL - 2], v[CPL - 1])};
           if (n8) __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[0], lo[1], hi[0], hi[1]}, c_rs, ob, 0, ST_AUX);
           else {
             __builtin_amdgcn_raw_buffer_store_b64(lo, c_rs, ob, 0, ST_AUX);
@@ -634,9 +759,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
         if (EPI == EPI_GELU) {
           if (p.preact) {
             const uint32_t pb = off[b] == OOB ? OOB : off[b] * 2;
-            const u32x2 lo = u32x2{pack_op16x2(v[b][0], v[b][1]), pack_op16x2(v[b][2], v[b][3])};
+            const u32x2 lo = u32x2{pack_bf16x2(v[b][0], v[b][1]), pack_bf16x2(v[b][2], v[b][3])};
             if (CPL == 8) {
-              const u32x2 hi = u32x2{pack_op16x2(v[b][CPL - 4], v[b][CPL - 3]), pack_op16x2(v[b][CPL - 2], v[b][CPL - 1])};
+              const u32x2 hi = u32x2{pack_bf16x2(v[b][CPL - 4], v[b][CPL - 3]), pack_bf16x2(v[b][CPL - 2], v[b][CPL - 1])};
               if (n8) __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[0], lo[1], hi[0], hi[1]}, pre_rs, pb, 0, ST_AUX);
               else {
                 __builtin_amdgcn_raw_buffer_store_b64(lo, pre_rs, pb, 0, ST_AUX);
@@ -671,8 +796,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
           }
         }
         if (OUT_BF16) {
-          const u32x2 lo = u32x2{pack_op16x2(v[b][0], v[b][1]), pack_op16x2(v[b][2], v[b][3])};
-          const u32x2 hi = u32x2{pack_op16x2(v[b][CPL - 4], v[b][CPL - 3]), pack_op16x2(v[b][CPL - 2], v[b][CPL - 1])};
+          const u32x2 lo = u32x2{pack_bf16x2(v[b][0], v[b][1]), pack_bf16x2(v[b][2], v[b][3])};
+          const u32x2 hi = u32x2{pack_bf16x2(v[b][CPL - 4], v[b][CPL - 3]), pack_bf16x2(v[b][CPL - 2], v[b][CPL - 1])};
           if (n8) __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[0], lo[1], hi[0], hi[1]}, c_rs, ob, 0, ST_AUX);
           else {
             __builtin_amdgcn_raw_buffer_store_b64(lo, c_rs, ob, 0, ST_AUX);
@@ -719,9 +844,8 @@ __device__ __forceinline__ int sw_tn(int row) { return ((row & 3) | ((row >> 1) 
 // Transposed 16x16x32 fragments from a [64 reduction rows][row bytes] tile: lane (g = lane>>4, li = lane&15) supplies rows
 // 32ks + 8g + (li>>2) (+4 for the second read), columns col0 + 4*(li&3); it receives column col0 + li, reduction rows 32ks + 8g + 0..7.
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int BKT = 64>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(const GemmTN p) {
-  constexpr int BKT = BK;
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   constexpr int MREP = WTM / 16, NREP = WTN / 16;
@@ -790,9 +914,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(const Ge
   const bool bias_on = (p.bias_slab != nullptr);
   static_assert(MREP % WAVES_N == 0, "bias fragments split across the waves of a row");
   constexpr int BREP = MREP / WAVES_N;
-  op16x8 ones;
+  bf16x8 ones;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) ones[e] = (op16_t)1.0f;
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
   f32x4 bacc[BREP];
 #pragma unroll
   for (int i = 0; i < BREP; ++i) bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -836,7 +960,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(const Ge
     const int wr_now = wr, t_next = t + STAGES - 1;
     rd = (rd + 1 == STAGES) ? 0 : rd + 1;
     wr = (wr + 1 == STAGES) ? 0 : wr + 1;
-#define KSTEP_TN(ks) \
+#define KSTEP_TN(ks) KSTEP_TN_(ks, false)
+#define KSTEP_TN_(ks, SPREAD_) /* SPREAD_: wave-uniform runtime condition (false: a literal, the branch folds away) */ \
   if (!(DBG_BITS(p) & 8)) {                                                                                   \
     s16x4 ql_[NREP], qh_[NREP], pl_[MREP], ph_[MREP];                                                         \
     _Pragma("unroll") for (int j = 0; j < NREP; ++j) {                                                        \
@@ -849,30 +974,42 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(const Ge
     }                                                                                                         \
     /* the four column fragments (8 reads), then one row fragment (2 reads) at a time as its MFMAs come up */ \
     lds_wait<2 * MREP>(ql_[0], qh_[0], ql_[1], qh_[1], ql_[2], qh_[2], ql_[3], qh_[3]);                       \
-    op16x8 qf[NREP];                                                                                          \
+    bf16x8 qf[NREP];                                                                                          \
     _Pragma("unroll") for (int j = 0; j < NREP; ++j) qf[j] = join_tr(ql_[j], qh_[j]);                         \
     static_for<0, MREP>([&](auto ic) {                                                                        \
       constexpr int i = decltype(ic)::value;                                                                  \
       lds_wait<2 * (MREP - 1 - i)>(pl_[i], ph_[i]);                                                           \
-      const op16x8 pf = join_tr(pl_[i], ph_[i]);                                                              \
+      const bf16x8 pf = join_tr(pl_[i], ph_[i]);                                                              \
       if (!(DBG_BITS(p) & 2)) {                                                                               \
         _Pragma("unroll") for (int j = 0; j < NREP; ++j)                                                      \
-            acc[i][j] = TAD_MFMA_16x16x32(qf[j], pf, acc[i][j]);               \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], pf, acc[i][j], 0, 0, 0);               \
       } else {                                                                                                \
         asm volatile("" ::"v"(pf));                                                                           \
         _Pragma("unroll") for (int j = 0; j < NREP; ++j) asm volatile("" ::"v"(qf[j]));                       \
       }                                                                                                       \
       if (bias_now && (i % WAVES_N) == wn)                                                                    \
-        bacc[i / WAVES_N] = TAD_MFMA_16x16x32(pf, ones, bacc[i / WAVES_N]);    \
+        bacc[i / WAVES_N] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, ones, bacc[i / WAVES_N], 0, 0, 0);    \
+      if (SPREAD_) { /* experiment: piece i of the next stage behind row fragment i's MFMAs */                \
+        if (i < P_PIECES) stage_piece<NW>(p.P, p_bytes, lds + wr_now * STAGE_BYTES, p_off[i < P_PIECES ? i : 0], (uint32_t)(t_next) * BKT * (uint32_t)(p.N * 2), wave, i); \
+        else if (i - P_PIECES < Q_PIECES) stage_piece<NW>(p.Q, q_bytes, lds + wr_now * STAGE_BYTES + P_BYTES, q_off[(i - P_PIECES) < Q_PIECES ? (i - P_PIECES) : 0], (uint32_t)(t_next) * BKT * (uint32_t)(p.K * 2), wave, i - P_PIECES); \
+      }                                                                                                       \
     });                                                                                                       \
   }
     const bool late = wave >= NW / 2;  // stagger the DMA issue of the two waves that share a SIMD (see gemm_nt_kernel)
     const bool dma = more && !(DBG_BITS(p) & 1);
-    static_assert(KSTEPS == 2, "two 32-deep k-steps per stage");
-    if (dma && !late) { STAGE_TN(wr_now, t_next); }
-    KSTEP_TN(0);
-    if (dma && late) { STAGE_TN(wr_now, t_next); }
-    KSTEP_TN(1);
+    constexpr bool spread = TAD_DMA_SPREAD && MREP >= P_PIECES + Q_PIECES;
+    if constexpr (KSTEPS == 2 && spread) {
+      KSTEP_TN_(0, dma && !late);
+      KSTEP_TN_(1, dma && late);
+    } else if (KSTEPS == 2) {
+      if (dma && !late) { STAGE_TN(wr_now, t_next); }
+      KSTEP_TN(0);
+      if (dma && late) { STAGE_TN(wr_now, t_next); }
+      KSTEP_TN(1);
+    } else {
+      if (dma) { STAGE_TN(wr_now, t_next); }
+      KSTEP_TN(0);
+    }
   }
 
   if (bias_on && li == 0) {
@@ -903,34 +1040,22 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(const Ge
 
 // ------------------------------------------------------------------------------------------------------------
 
-static int cu_count();
-
-TAD_NAMESPACE_END
-// Scheduling knobs and counters of the Linear GEMMs (tad_linear_tuning; initial values from the environment).  One copy for the whole
-// library: defined by the bf16 compilation pass, shared by the half pass.
-namespace tad { namespace knobs {
-#ifndef TAD_OPND_F16
 static int env_int(const char* name) {
   const char* v = getenv(name);
   return v ? atoi(v) : 0;
 }
-int gemm_debug = env_int("TAD_GEMM_DEBUG");  // ablation bits (GemmNT::debug); only ablation builds look at them
-int nt_persist = !env_int("TAD_GEMM_NO_PERSIST");
-int nt_direct = getenv("TAD_GEMM_DIRECT_EPI") ? env_int("TAD_GEMM_DIRECT_EPI") : 1;
-int nt_split = getenv("TAD_GEMM_SPLIT_TAIL") ? env_int("TAD_GEMM_SPLIT_TAIL") : 1;
-int nt_variant = env_int("TAD_GEMM_NT_VARIANT");  // 0 = planned per shape (launch_gemm_nt), else the tile configuration for every launch
-int nt_group_m_knob = getenv("TAD_GEMM_GROUP_M") ? env_int("TAD_GEMM_GROUP_M") : 0;  // 0 = per-shape choice (nt_group_m)
-int tn_variant = env_int("TAD_GEMM_TN_VARIANT");
-unsigned long long* nt_stamps = nullptr;
-long long nt_launches = 0;  // gemm_nt kernel launches so far (tad_linear_kernel_launches)
-#else
-extern int gemm_debug, nt_persist, nt_direct, nt_split, nt_variant, nt_group_m_knob, tn_variant;
-extern unsigned long long* nt_stamps;
-extern long long nt_launches;
-#endif
-}}  // namespace tad::knobs
-TAD_NAMESPACE_BEGIN
-using namespace knobs;
+static int cu_count();
+
+// scheduling knobs (tad_linear_tuning; initial values from TAD_GEMM_NO_PERSIST / TAD_GEMM_STAGGER / TAD_GEMM_STAGGER_GROUP)
+static int g_gemm_debug = env_int("TAD_GEMM_DEBUG");  // ablation bits (GemmNT::debug); only ablation builds look at them
+static int g_nt_persist = !env_int("TAD_GEMM_NO_PERSIST");
+static int g_nt_stagger_pct = getenv("TAD_GEMM_STAGGER") ? env_int("TAD_GEMM_STAGGER") : 0;  // % of one tile's K-loop time
+static int g_nt_stagger_group = getenv("TAD_GEMM_STAGGER_GROUP") ? env_int("TAD_GEMM_STAGGER_GROUP") : 1;
+static int g_nt_direct = getenv("TAD_GEMM_DIRECT_EPI") ? env_int("TAD_GEMM_DIRECT_EPI") : 1;
+static int g_nt_split = getenv("TAD_GEMM_SPLIT_TAIL") ? env_int("TAD_GEMM_SPLIT_TAIL") : 1;
+static int g_nt_dynamic = getenv("TAD_GEMM_DYNAMIC") ? env_int("TAD_GEMM_DYNAMIC") : 0;  // measured: +7 % gemm_nt time in the full step
+static int g_nt_variant = env_int("TAD_GEMM_NT_VARIANT");  // 0 = planned per shape (launch_gemm_nt), else the tile configuration for every launch
+static int g_nt_group_m = getenv("TAD_GEMM_GROUP_M") ? env_int("TAD_GEMM_GROUP_M") : 0;  // 0 = per-shape choice (nt_group_m)
 
 // Row panels per column-panel group of the tile raster.  The ~32 workgroups resident on an XCD (private 4 MiB L2) walk consecutive
 // tile ids, so at any time they touch GROUP_M A-panels and ~32 / GROUP_M W-panels; each panel streams K-tile by K-tile, and a
@@ -940,29 +1065,78 @@ using namespace knobs;
 // within 0.5 % of each other in sum; the long reductions (K = 2304 / 3072: an A panel of 256 rows is 1.2 - 1.5 MB) are 1 - 4 % faster with 4 (fc2 241
 // vs 246 us, dX(fc1) 220 vs 222), the K = 768 shapes with 8 (qkv 166 vs 169).
 static int nt_group_m(int tiles_m, int tiles_n, int K) {
-  if (nt_group_m_knob > 0) return nt_group_m_knob;
+  if (g_nt_group_m > 0) return g_nt_group_m;
   return K >= 2048 ? 4 : 8;
 }
 
+static unsigned long long* g_nt_stamps = nullptr;
+
+// Tile counters of the persistent kernels with dynamic lists: a ring of SCHED_SLOTS slots of 8 ints (one counter per XCD), one slot
+// per launch in rotation.  A launch resets the slot half a ring ahead of its own (used long ago, needed again only half a ring
+// later), so no memset launch is needed and launches on different streams never share a slot.  The ring is the library's only
+// device allocation (16 KiB per device, made on the first persistent launch); a launch that is being captured into a HIP graph
+// takes fixed lists instead (a replayed node would find its slot used up).
+constexpr int SCHED_SLOTS = 512;
+static int* g_sched_ring[64] = {};
+static unsigned g_sched_seq = 0;
+static int* sched_ring(hipStream_t st) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!g_sched_ring[dev]) {
+    int* ptr = nullptr;
+    if (hipMalloc(&ptr, SCHED_SLOTS * 8 * sizeof(int)) != hipSuccess || hipMemset(ptr, 0, SCHED_SLOTS * 8 * sizeof(int)) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    g_sched_ring[dev] = ptr;
+  }
+  return g_sched_ring[dev];
+}
+static long long g_nt_launches = 0;  // gemm_nt kernel launches so far (tad_linear_kernel_launches)
 
 // Tile configurations.  NT: 1 = 256x256 (2x4 waves) 2 stages; 2 = 128x128 (2x2) 2 stages, 2 workgroups/CU;
 // 3 = 256x128 (4x2) 3 stages; 4 = 128x64, 5 = 64x64 (2x2 waves, 2 stages: small problems).  0 = auto.  The epilogue kind and output type are compile-time (the epilogue is VALU-bound).
 // Variants 1 and 3 run as persistent kernels (one workgroup per CU walks a tile list) once there are more than 1.5 tiles per CU.
+// 6 (only with -DTAD_NT_TWO_WG=1) = 256x128 with FOUR waves (2x2, 128x64 per wave as in variant 1), K-tile 32, 3 stages, 72 KiB of LDS
+// and 256 registers: TWO independent persistent workgroups per CU, one wave of each per SIMD, so that the epilogue of one runs beside the
+// K loop of the other.  Bit-identical results; measured 13-30 % SLOWER than the planned variants at all eight ViT-B shapes.
 template <int EPI, bool OUT_BF16>
 static void launch_nt_variant(int v, GemmNT& p, hipStream_t st) {
   auto tiles = [&](int bm, int bn) { return ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
-  const int no_persist = !nt_persist;
+  const int no_persist = !g_nt_persist, stagger_pct = g_nt_stagger_pct, stagger_group = g_nt_stagger_group;
   if (((EPI == EPI_RESIDUAL && OUT_BF16) || EPI == EPI_RESMOD) && v == 1) v = 3;  // (not instantiated: no registers / never needed)
   if (v != 2 && v != 4 && v != 5 && p.rowscale && p.rows_per_scale < 256) v = 2;  // the 256-row tiles take at most two row-scale groups per tile
   const int grid_p = cu_count() & ~7;
   const int bn = v == 1 ? 256 : 128;
-  const bool persist = !no_persist && (v == 1 || v == 3) && grid_p >= 8 && tiles(256, bn) > grid_p + grid_p / 2;
+  const bool persist = !no_persist && (v == 1 || v == 3 || v == 6) && grid_p >= 8 && tiles(256, bn) > (v == 6 ? 3 : 1) * grid_p + grid_p / 2;
+  if (v == 6 && (!persist || !TAD_NT_TWO_WG)) v = 3;
   p.group_m = nt_group_m((p.M + 255) / 256, (p.N + bn - 1) / bn, p.K);
+  p.sched = p.sched_clear = nullptr;
+  if (persist && g_nt_dynamic) {
+    if (int* ring = sched_ring(st)) {
+      const unsigned seq = g_sched_seq++;
+      p.sched = ring + (seq % SCHED_SLOTS) * 8;
+      p.sched_clear = ring + ((seq + SCHED_SLOTS / 2) % SCHED_SLOTS) * 8;
+    }
+  }
+  if (persist) {
+    // one K-tile (64 deep) of a 256 x bn tile at ~1.15 PFLOP/s chip-wide: 1.87 us for bn = 256
+    const double ktile_us = 2.0 * 256.0 * bn * 64.0 / (1.15e15 / cu_count()) * 1e6;
+    p.stagger_ticks = (int)(ktile_us * (p.K / 64) * 100.0 * stagger_pct / 100.0);
+    p.stagger_group = stagger_group > 0 ? stagger_group : 1;
+  }
 #define NT_LAUNCH(BM_, BN_, WM_, WN_, ST_, PER_, DIR_, GRID_, THREADS_)                                                              \
-  hipLaunchKernelGGL((gemm_nt_kernel<BM_, BN_, WM_, WN_, ST_, EPI, OUT_BF16, PER_, DIR_>), dim3(GRID_), dim3(THREADS_), 0, st, p)
+  do {                                                                                                                             \
+    if (PER_ && p.sched)                                                                                                           \
+      hipLaunchKernelGGL((gemm_nt_kernel<BM_, BN_, WM_, WN_, ST_, 64, 1, EPI, OUT_BF16, PER_, DIR_, PER_>), dim3(GRID_), dim3(THREADS_), 0, st, p); \
+    else                                                                                                                           \
+      hipLaunchKernelGGL((gemm_nt_kernel<BM_, BN_, WM_, WN_, ST_, 64, 1, EPI, OUT_BF16, PER_, DIR_, false>), dim3(GRID_), dim3(THREADS_), 0, st, p); \
+  } while (0)
   // measured per shape (tools/exp_epilogue.py): storing straight from the MFMA layout wins only for the bias-only bf16 epilogue
-  // (nothing to fetch, no arithmetic); the others keep the LDS transposition.  nt_direct: 0 = never, 1 = auto, 2 = always.
-  const bool direct = nt_direct == 2 || (nt_direct == 1 && EPI == EPI_PLAIN && OUT_BF16);
+  // (nothing to fetch, no arithmetic); the others keep the LDS transposition.  g_nt_direct: 0 = never, 1 = auto, 2 = always.
+  const bool direct = g_nt_direct == 2 || (g_nt_direct == 1 && EPI == EPI_PLAIN && OUT_BF16);
   switch (v) {
     case 1:
       if constexpr (!(EPI == EPI_RESIDUAL && OUT_BF16) && EPI != EPI_RESMOD) {
@@ -974,6 +1148,12 @@ static void launch_nt_variant(int v, GemmNT& p, hipStream_t st) {
       if (persist) { if (direct) NT_LAUNCH(256, 128, 4, 2, 3, true, true, grid_p, 512); else NT_LAUNCH(256, 128, 4, 2, 3, true, false, grid_p, 512); }
       else { if (direct) NT_LAUNCH(256, 128, 4, 2, 3, false, true, tiles(256, 128), 512); else NT_LAUNCH(256, 128, 4, 2, 3, false, false, tiles(256, 128), 512); }
       break;
+#if TAD_NT_TWO_WG
+    case 6:
+      if (direct) hipLaunchKernelGGL((gemm_nt_kernel<256, 128, 2, 2, 3, 32, 2, EPI, OUT_BF16, true, true, false>), dim3(2 * grid_p), dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((gemm_nt_kernel<256, 128, 2, 2, 3, 32, 2, EPI, OUT_BF16, true, false, false>), dim3(2 * grid_p), dim3(256), 0, st, p);
+      break;
+#endif
     case 4:
       if (direct) NT_LAUNCH(128, 64, 2, 2, 2, false, true, tiles(128, 64), 256); else NT_LAUNCH(128, 64, 2, 2, 2, false, false, tiles(128, 64), 256);
       break;
@@ -988,7 +1168,7 @@ static void launch_nt_variant(int v, GemmNT& p, hipStream_t st) {
 }
 
 static int launch_gemm_nt_one(GemmNT p, int v, hipStream_t st) {
-  ++nt_launches;
+  ++g_nt_launches;
   if (p.epi == EPI_RESIDUAL && p.residual && p.res_mod > 0) p.epi = EPI_RESMOD;
 #define NT_CASE(E)                                                       \
   case E:                                                                \
@@ -1068,9 +1248,9 @@ int launch_gemm_nt(const GemmNT& p_in, hipStream_t st) {
       return TAD_OK;
     }
   }
-  const int forced = nt_variant;
-  p.debug = gemm_debug;
-  p.stamps = nt_stamps;
+  const int forced = g_nt_variant;
+  p.debug = g_gemm_debug;
+  p.stamps = g_nt_stamps;
   if (forced) return launch_gemm_nt_one(p, forced, st);
   if (p.M < 2048 || p.N < 128) {
     // small problems (batch-1 inference: 1568 or 784 rows): 128 x 128 tiles, or 128 x 64 when those would leave more than half of the
@@ -1088,7 +1268,7 @@ int launch_gemm_nt(const GemmNT& p_in, hipStream_t st) {
   const double cost_b = v1_ok ? nt_cost(1, p.epi, p.c_bf16, p.M, p.N, p.K) : 1e300;
   double cost_c = 1e300;
   int main_rows = 0;
-  if (v1_ok && nt_split) {
+  if (v1_ok && g_nt_split) {
     const int tiles_n = (p.N + 255) / 256, tiles_m = (p.M + 255) / 256;
     const int grid = cu_count() & ~7;
     const int rounds = (int)((int64_t)tiles_m * tiles_n / grid);
@@ -1101,7 +1281,7 @@ int launch_gemm_nt(const GemmNT& p_in, hipStream_t st) {
       cost_c = nt_cost(1, p.epi, p.c_bf16, main_rows, p.N, p.K) + tail_cost;
     }
   }
-  if (nt_split == 2 && main_rows > 0) cost_c = 0.0;  // forced (experiments)
+  if (g_nt_split == 2 && main_rows > 0) cost_c = 0.0;  // forced (experiments)
   if (cost_c < cost_a && cost_c < cost_b) {
     int rc = launch_gemm_nt_one(row_range(p, 0, main_rows), 1, st);
     if (rc) return rc;
@@ -1113,7 +1293,10 @@ int launch_gemm_nt(const GemmNT& p_in, hipStream_t st) {
 }
 
 // TN: 1 = 256x256 (2x4) 2 stages; 3 = 256x128 (4x2) 3 stages.  Splits over the reduction dim target ~1 workgroup per CU.
-static int tn_variant() { return knobs::tn_variant ? knobs::tn_variant : 1; }
+static int tn_variant() {
+  static const int forced = env_int("TAD_GEMM_TN_VARIANT");
+  return forced ? forced : 1;
+}
 static int cu_count() {
   static const int n = [] {
     int dev = 0, v = 0;
@@ -1164,7 +1347,7 @@ int launch_gemm_tn(const uint16_t* P, const uint16_t* Q, float* out, float* bias
   if (Mr * (int64_t)N * 2 >= (1ll << 32) || Mr * (int64_t)K * 2 >= (1ll << 32)) { set_error("gemm_tn: operand exceeds 4 GiB"); return TAD_EINVAL; }
   GemmTN p;
   p.P = P; p.Q = Q; p.slab = (float*)ws; p.Mr = (int)Mr; p.N = N; p.K = K;
-  p.debug = gemm_debug;
+  p.debug = g_gemm_debug;
   int splits;
   const int tiles = tn_plan(Mr, N, K, &splits, &p.rows_per_split);
   const int tiles_k = (K + (tn_variant() != 3 ? 256 : 128) - 1) / (tn_variant() != 3 ? 256 : 128);
@@ -1182,7 +1365,7 @@ int launch_gemm_tn(const uint16_t* P, const uint16_t* Q, float* out, float* bias
   return launch_reduce_dw(p.slab, out, splits, (int64_t)N * K, accumulate, p.bias_slab, splits * tiles_k, N, bias_out, nullptr, N, 0, st);
 }
 
-TAD_NAMESPACE_END
+}  // namespace tad
 
 using namespace tad;
 
@@ -1192,12 +1375,12 @@ int tad_linear_fwd(const uint16_t* x, const uint16_t* w, const float* bias, void
                    const float* residual, const float* gamma, const float* rowscale, int rows_per_scale, int64_t M, int N, int K,
                    tad_stream_t stream) {
   TAD_REQUIRE(x && w && y, "linear_fwd: null pointer");
-  TAD_REQUIRE(y_dtype == TAD_F32 || y_dtype == TAD_OP16, "linear_fwd: bad y_dtype %d", y_dtype);
+  TAD_REQUIRE(y_dtype == TAD_F32 || y_dtype == TAD_BF16, "linear_fwd: bad y_dtype %d", y_dtype);
   TAD_REQUIRE(epilogue >= TAD_EPI_BIAS && epilogue <= TAD_EPI_BIAS_RESIDUAL, "linear_fwd: bad epilogue %d", epilogue);
   TAD_REQUIRE(!rowscale || rows_per_scale > 0, "linear_fwd: rows_per_scale must be positive");
   TAD_REQUIRE(M > 0 && M < (1ll << 31), "linear_fwd: bad M");
   GemmNT p{};
-  p.A = x; p.B = w; p.C = y; p.bias = bias; p.c_bf16 = (y_dtype == TAD_OP16);
+  p.A = x; p.B = w; p.C = y; p.bias = bias; p.c_bf16 = (y_dtype == TAD_BF16);
   p.M = (int)M; p.N = N; p.K = K;
   p.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
   if (epilogue == TAD_EPI_BIAS_GELU) { p.epi = EPI_GELU; p.preact = preact; }
@@ -1210,11 +1393,11 @@ int tad_linear_fwd_qkv(const uint16_t* x, const uint16_t* w, const float* q_bias
                        int K, tad_stream_t stream) {
   TAD_REQUIRE(x && w && y, "linear_fwd_qkv: null pointer");
   TAD_REQUIRE((q_bias == nullptr) == (v_bias == nullptr), "linear_fwd_qkv: q_bias and v_bias come together");
-  TAD_REQUIRE(y_dtype == TAD_F32 || y_dtype == TAD_OP16, "linear_fwd_qkv: bad y_dtype %d", y_dtype);
+  TAD_REQUIRE(y_dtype == TAD_F32 || y_dtype == TAD_BF16, "linear_fwd_qkv: bad y_dtype %d", y_dtype);
   TAD_REQUIRE(N > 0 && N % 12 == 0, "linear_fwd_qkv: N=%d must be 3 x a multiple of 4", N);
   TAD_REQUIRE(M > 0 && M < (1ll << 31), "linear_fwd_qkv: bad M");
   GemmNT p{};
-  p.A = x; p.B = w; p.C = y; p.c_bf16 = (y_dtype == TAD_OP16);
+  p.A = x; p.B = w; p.C = y; p.c_bf16 = (y_dtype == TAD_BF16);
   p.bias = q_bias; p.bias2 = v_bias; p.bias_seg = q_bias ? N / 3 : 0;
   p.M = (int)M; p.N = N; p.K = K;
   p.rows_per_scale = 1;
@@ -1229,38 +1412,42 @@ int tad_linear_bwd_weight_qkv(const uint16_t* dy, const uint16_t* x, float* dW, 
   return launch_gemm_tn(dy, x, dW, dq_bias, dv_bias, accumulate, ws, ws_bytes, M, N, K, (hipStream_t)stream);
 }
 
-#ifndef TAD_OPND_F16  // process-wide knobs / counters: one copy for the library (bf16 pass)
 int tad_linear_tuning(const char* key, int value) {
   TAD_REQUIRE(key, "linear_tuning: null key");
   const std::string k(key);
-  if (k == "persistent") nt_persist = value != 0;
-  else if (k == "direct_epilogue") { TAD_REQUIRE(value >= 0 && value <= 2, "linear_tuning: direct_epilogue=%d not in 0..2", value); nt_direct = value; }
-  else if (k == "debug") gemm_debug = value;  // ablation bits (timing experiments; ignored by production builds)
-  else if (k == "group_m") { TAD_REQUIRE(value >= 0 && value <= 1024, "linear_tuning: group_m=%d out of range", value); nt_group_m_knob = value; }
-  else if (k == "variant") { TAD_REQUIRE(value >= 0 && value <= 5, "linear_tuning: variant=%d not in 0..5", value); nt_variant = value; }
-  else if (k == "split_tail") { TAD_REQUIRE(value >= 0 && value <= 2, "linear_tuning: split_tail=%d not in 0..2", value); nt_split = value; }
+  if (k == "persistent") g_nt_persist = value != 0;
+  else if (k == "stagger_pct") { TAD_REQUIRE(value >= 0 && value <= 400, "linear_tuning: stagger_pct=%d out of range", value); g_nt_stagger_pct = value; }
+  else if (k == "stagger_group") {
+    TAD_REQUIRE(value >= 1 && value <= 32 && (value & (value - 1)) == 0, "linear_tuning: stagger_group=%d must be a power of two in 1..32", value);
+    g_nt_stagger_group = value;
+  }
+  else if (k == "direct_epilogue") { TAD_REQUIRE(value >= 0 && value <= 2, "linear_tuning: direct_epilogue=%d not in 0..2", value); g_nt_direct = value; }
+  else if (k == "dynamic_tiles") g_nt_dynamic = value != 0;
+  else if (k == "debug") g_gemm_debug = value;  // ablation bits (timing experiments; ignored by production builds)
+  else if (k == "group_m") { TAD_REQUIRE(value >= 0 && value <= 1024, "linear_tuning: group_m=%d out of range", value); g_nt_group_m = value; }
+  else if (k == "variant") { TAD_REQUIRE(value >= 0 && value <= 6, "linear_tuning: variant=%d not in 0..6", value); g_nt_variant = value; }
+  else if (k == "split_tail") { TAD_REQUIRE(value >= 0 && value <= 2, "linear_tuning: split_tail=%d not in 0..2", value); g_nt_split = value; }
   else { set_error("linear_tuning: unknown key '%s'", key); return TAD_EINVAL; }
   return TAD_OK;
 }
 
-long long tad_linear_kernel_launches(void) { return nt_launches; }
+long long tad_linear_kernel_launches(void) { return g_nt_launches; }
 
 int tad_linear_debug_stamps(void* buf) {
 #ifndef TAD_GEMM_ABLATION
   if (buf) { set_error("linear_debug_stamps: timeline stamps need an ablation build (TAD_BUILD_ABLATION=1 python -m simple_tad_amd.build --force)"); return TAD_EINVAL; }
 #endif
-  nt_stamps = (unsigned long long*)buf;
+  g_nt_stamps = (unsigned long long*)buf;
   return TAD_OK;
 }
-#endif
 
 int tad_linear_bwd_input(const uint16_t* dy, const uint16_t* wT, void* dx, int dx_dtype, const uint16_t* gelu_preact, int64_t M, int N,
                          int K, tad_stream_t stream) {
   TAD_REQUIRE(dy && wT && dx, "linear_bwd_input: null pointer");
-  TAD_REQUIRE(dx_dtype == TAD_F32 || dx_dtype == TAD_OP16, "linear_bwd_input: bad dx_dtype %d", dx_dtype);
+  TAD_REQUIRE(dx_dtype == TAD_F32 || dx_dtype == TAD_BF16, "linear_bwd_input: bad dx_dtype %d", dx_dtype);
   TAD_REQUIRE(M > 0 && M < (1ll << 31), "linear_bwd_input: bad M");
   GemmNT p{};
-  p.A = dy; p.B = wT; p.C = dx; p.c_bf16 = (dx_dtype == TAD_OP16);
+  p.A = dy; p.B = wT; p.C = dx; p.c_bf16 = (dx_dtype == TAD_BF16);
   p.M = (int)M; p.N = K; p.K = N;  // dx[M,K] = dy[M,N] * (wT[K,N])^T
   p.rows_per_scale = 1;
   p.epi = gelu_preact ? EPI_DGELU : EPI_PLAIN;
@@ -1268,11 +1455,9 @@ int tad_linear_bwd_input(const uint16_t* dy, const uint16_t* wT, void* dx, int d
   return launch_gemm_nt(p, (hipStream_t)stream);
 }
 
-#ifndef TAD_OPND_F16
 size_t tad_linear_bwd_weight_workspace_bytes(int64_t M, int N, int K) {
   return gemm_tn_workspace_bytes(M, N, K);
 }
-#endif
 
 int tad_linear_bwd_weight(const uint16_t* dy, const uint16_t* x, float* dW, float* db, int accumulate, void* ws, size_t ws_bytes,
                           int64_t M, int N, int K, tad_stream_t stream) {
@@ -1312,9 +1497,7 @@ int tad_patch_embed_gemm(const uint16_t* cols, const uint16_t* w_bf16, const flo
   return launch_gemm_nt(p, (hipStream_t)stream);
 }
 
-#ifndef TAD_OPND_F16
 size_t tad_patch_embed_bwd_workspace_bytes(int64_t M, int D, int K) { return tad_linear_bwd_weight_workspace_bytes(M, D, K); }
-#endif
 
 int tad_patch_embed_bwd(const uint16_t* dy_bf16, const uint16_t* cols, float* dW, float* db, void* ws, size_t ws_bytes, int64_t M, int D,
                         int K, tad_stream_t stream) {

@@ -4,8 +4,23 @@
 // wave reductions by cross-lane shuffles -- no LDS on the forward path.
 #include "common.h"
 
-TAD_NAMESPACE_BEGIN
+namespace tad {
 
+#ifndef TAD_LN_FWD_LOAD_NT
+#define TAD_LN_FWD_LOAD_NT 0
+#endif
+#ifndef TAD_LN_FWD_STORE_NT
+#define TAD_LN_FWD_STORE_NT 0
+#endif
+#ifndef TAD_LN_BWD_LOAD_NT
+#define TAD_LN_BWD_LOAD_NT 0
+#endif
+#ifndef TAD_LN_BWD_STORE_NT
+#define TAD_LN_BWD_STORE_NT 0
+#endif
+#ifndef TAD_LN_BWD_STORE_DX_NT
+#define TAD_LN_BWD_STORE_DX_NT TAD_LN_BWD_STORE_NT  // the f32 dx alone (read again only by the NEXT LayerNorm backward, a whole branch later)
+#endif
 constexpr int LN_MAX_V = 8;  // float4 per lane -> D <= 64*4*8 = 2048
 
 int launch_reduce_partials(const float* partial, float* out, int splits, int64_t n, int accumulate, hipStream_t st);
@@ -27,7 +42,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = lane + 64 * i;
-    v[i] = (c < D4) ? ldg_f4<false>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    v[i] = (c < D4) ? ldg_f4<TAD_LN_FWD_LOAD_NT>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
   }
   const float mu = wave_sum(s) / (float)D;
@@ -58,11 +73,11 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
       o.w = (v[i].w - mu) * rs * g.w + b.w;
       if (OUT_BF16) {
         uint2 p;
-        p.x = pack_op16x2(o.x, o.y);
-        p.y = pack_op16x2(o.z, o.w);
-        stg_u2<false>(reinterpret_cast<uint2*>((uint16_t*)y + row * D) + c, p);
+        p.x = pack_bf16x2(o.x, o.y);
+        p.y = pack_bf16x2(o.z, o.w);
+        stg_u2<TAD_LN_FWD_STORE_NT>(reinterpret_cast<uint2*>((uint16_t*)y + row * D) + c, p);
       } else {
-        stg_f4<false>(reinterpret_cast<float4*>((float*)y + row * D) + c, o);
+        stg_f4<TAD_LN_FWD_STORE_NT>(reinterpret_cast<float4*>((float*)y + row * D) + c, o);
       }
     }
   }
@@ -117,10 +132,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
     for (int i = 0; i < NV; ++i) {
       const int c = lane + 64 * i;
       if (FULL || c < D4) {
-        xv[i] = ldg_f4<false>(reinterpret_cast<const float4*>(x + row * D) + c);
-        if (DY_BF16) dyp[i] = ldg_u2<false>(reinterpret_cast<const uint2*>((const uint16_t*)dy + row * D) + c);
-        else dyv[i] = ldg_f4<false>(reinterpret_cast<const float4*>((const float*)dy + row * D) + c);
-        rv[i] = ldg_f4<false>(reinterpret_cast<const float4*>(rsrc + row * D) + c);
+        xv[i] = ldg_f4<TAD_LN_BWD_LOAD_NT>(reinterpret_cast<const float4*>(x + row * D) + c);
+        if (DY_BF16) dyp[i] = ldg_u2<TAD_LN_BWD_LOAD_NT>(reinterpret_cast<const uint2*>((const uint16_t*)dy + row * D) + c);
+        else dyv[i] = ldg_f4<TAD_LN_BWD_LOAD_NT>(reinterpret_cast<const float4*>((const float*)dy + row * D) + c);
+        rv[i] = ldg_f4<TAD_LN_BWD_LOAD_NT>(reinterpret_cast<const float4*>(rsrc + row * D) + c);
       }
     }
     const float mu = mean[row], rs = rstd[row];
@@ -138,7 +153,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
       const int c = lane + 64 * i;
       if (FULL || c < D4) {
         if (DY_BF16)
-          dyv[i] = make_float4(op16_lo_f32(dyp[i].x), op16_hi_f32(dyp[i].x), op16_lo_f32(dyp[i].y), op16_hi_f32(dyp[i].y));
+          dyv[i] = make_float4(__uint_as_float(dyp[i].x << 16), __uint_as_float(dyp[i].x & 0xffff0000u), __uint_as_float(dyp[i].y << 16),
+                               __uint_as_float(dyp[i].y & 0xffff0000u));
         xh[i] = make_float4((xv[i].x - mu) * rs, (xv[i].y - mu) * rs, (xv[i].z - mu) * rs, (xv[i].w - mu) * rs);
         const float4 t = make_float4(dyv[i].x * g[i].x, dyv[i].y * g[i].y, dyv[i].z * g[i].z, dyv[i].w * g[i].w);
         s1 += (t.x + t.y) + (t.z + t.w);
@@ -162,7 +178,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = lane + 64 * i;
-      if (FULL || c < D4) stg_f4<false>(reinterpret_cast<float4*>(dx + row * D) + c, o[i]);
+      if (FULL || c < D4) stg_f4<TAD_LN_BWD_STORE_DX_NT>(reinterpret_cast<float4*>(dx + row * D) + c, o[i]);
       // the bf16 copy and the column sums feed the branch Linear, whose output was scaled per sample (drop-path)
       o[i].x *= sc; o[i].y *= sc; o[i].z *= sc; o[i].w *= sc;
       if (FULL || c < D4) { cs[i].x += o[i].x; cs[i].y += o[i].y; cs[i].z += o[i].z; cs[i].w += o[i].w; }
@@ -173,9 +189,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
         const int c = lane + 64 * i;
         if (FULL || c < D4) {
           uint2 p;
-          p.x = pack_op16x2(o[i].x, o[i].y);
-          p.y = pack_op16x2(o[i].z, o[i].w);
-          stg_u2<false>(reinterpret_cast<uint2*>(dxb + row * D) + c, p);
+          p.x = pack_bf16x2(o[i].x, o[i].y);
+          p.y = pack_bf16x2(o[i].z, o[i].w);
+          stg_u2<TAD_LN_BWD_STORE_NT>(reinterpret_cast<uint2*>(dxb + row * D) + c, p);
         }
       }
     }
@@ -213,7 +229,7 @@ static inline int ln_bwd_blocks(int64_t rows) {
   return (int)b;
 }
 
-TAD_NAMESPACE_END
+}  // namespace tad
 
 using namespace tad;
 
@@ -224,12 +240,12 @@ int tad_layernorm_fwd(const float* x, const float* gamma, const float* beta, voi
   TAD_REQUIRE(x && gamma && beta && y, "layernorm_fwd: null pointer");
   TAD_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * LN_MAX_V, "layernorm_fwd: D=%d must be a multiple of 4 and <= %d", D,
               64 * 4 * LN_MAX_V);
-  TAD_REQUIRE(y_dtype == TAD_F32 || y_dtype == TAD_OP16, "layernorm_fwd: bad y_dtype %d", y_dtype);
+  TAD_REQUIRE(y_dtype == TAD_F32 || y_dtype == TAD_BF16, "layernorm_fwd: bad y_dtype %d", y_dtype);
   const int nv = (D / 4 + 63) / 64;
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
 #define LN_FWD(NV)                                                                                                          \
-  if (y_dtype == TAD_OP16)                                                                                                  \
+  if (y_dtype == TAD_BF16)                                                                                                  \
     hipLaunchKernelGGL((layernorm_fwd_kernel<NV, true>), grid, block, 0, st, x, gamma, beta, y, mean, rstd, rows, D, eps); \
   else                                                                                                                      \
     hipLaunchKernelGGL((layernorm_fwd_kernel<NV, false>), grid, block, 0, st, x, gamma, beta, y, mean, rstd, rows, D, eps);
@@ -246,9 +262,7 @@ int tad_layernorm_fwd(const float* x, const float* gamma, const float* beta, voi
   return check_launch("layernorm_fwd");
 }
 
-#ifndef TAD_OPND_F16  // format-independent: one copy for the library (bf16 pass)
 size_t tad_layernorm_bwd_workspace_bytes(int64_t rows, int D) { return (size_t)3 * ln_bwd_blocks(rows) * (size_t)D * sizeof(float); }
-#endif
 
 int tad_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* mean, const float* rstd,
                       const float* dres, float* dx, uint16_t* dx_bf16, float* dgamma, float* dbeta, float* colsum_dx,
@@ -256,7 +270,7 @@ int tad_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float*
                       tad_stream_t stream) {
   TAD_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && ws, "layernorm_bwd: null pointer");
   TAD_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * LN_MAX_V, "layernorm_bwd: unsupported D=%d", D);
-  TAD_REQUIRE(dy_dtype == TAD_F32 || dy_dtype == TAD_OP16, "layernorm_bwd: bad dy_dtype %d", dy_dtype);
+  TAD_REQUIRE(dy_dtype == TAD_F32 || dy_dtype == TAD_BF16, "layernorm_bwd: bad dy_dtype %d", dy_dtype);
   TAD_REQUIRE(!rowscale || rows_per_scale > 0, "layernorm_bwd: rows_per_scale must be positive");
   const int blocks = ln_bwd_blocks(rows);
   if (ws_bytes < (size_t)3 * blocks * D * sizeof(float)) { set_error("layernorm_bwd: workspace too small"); return TAD_ENOSPACE; }
@@ -271,7 +285,7 @@ int tad_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float*
   hipLaunchKernelGGL((layernorm_bwd_kernel<NV, BF, FULL_>), dim3(blocks), dim3(256), smem, st, dy, x, gamma, mean, rstd, dres, dx, \
                      dx_bf16, partial, rows, D, rows_per_block, want_cs, rowscale, rows_per_scale)
 #define LN_BWD(NV)                                                                                                             \
-  if (dy_dtype == TAD_OP16) { if (full) LN_BWD_(NV, true, true); else LN_BWD_(NV, true, false); }                               \
+  if (dy_dtype == TAD_BF16) { if (full) LN_BWD_(NV, true, true); else LN_BWD_(NV, true, false); }                               \
   else { if (full) LN_BWD_(NV, false, true); else LN_BWD_(NV, false, false); }
   switch (nv) {
     case 1: LN_BWD(1); break;

@@ -18,7 +18,8 @@
  *   - never allocate device memory, never synchronise the device, re-entrant per stream.
  *     Scratch memory is passed in by the caller; sizes come from the *_workspace_bytes()
  *     queries.
- *   - "bf16" = bfloat16 stored as uint16_t; "f32" = IEEE float.
+ *   - "bf16" = bfloat16 stored as uint16_t; "f32" = IEEE float.  Every uint16_t operand below is bf16 in the tad_* entry points and
+ *     IEEE half in their tad_*_f16 twins (same kernels compiled for the other operand format; see the end of this header).
  *   - row-major everywhere; leading dimension == number of columns unless stated.
  */
 #ifndef TAD_MI355X_H
@@ -31,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TAD_ABI_VERSION 2
+#define TAD_ABI_VERSION 3
 
 enum tad_status {
   TAD_OK = 0,
@@ -40,7 +41,10 @@ enum tad_status {
   TAD_ENOSPACE = -3  /* workspace too small               */
 };
 
-enum tad_dtype { TAD_F32 = 0, TAD_BF16 = 1 };
+/* Element types.  TAD_BF16 / TAD_F16 name the 16-bit OPERAND FORMAT of a call: the entry points below take bfloat16 operands and accept
+ * TAD_F32 or TAD_BF16 where an output type is selectable; their IEEE-half twins (tad_*_f16, end of this header) take half operands
+ * and accept TAD_F32 or TAD_F16. */
+enum tad_dtype { TAD_F32 = 0, TAD_BF16 = 1, TAD_F16 = 2 };
 
 /* Linear-layer epilogues (tad_linear_fwd). */
 enum tad_epilogue {
@@ -133,14 +137,8 @@ int tad_linear_bwd_weight_qkv(const uint16_t* dy, const uint16_t* x, float* dW, 
                               tad_stream_t stream);
 /* Scheduling knobs of the Linear GEMMs (process-wide; results never depend on them, only timing): tad_linear_tuning(key, value).
  *   "persistent"      1 = one workgroup per CU walks the tile list (default), 0 = one workgroup per tile
- *   "stagger_pct"     span over which the workgroups of a persistent launch spread their start, in % of one tile's K-loop
- *                     time (default 0)
- *   "stagger_group"   workgroups of an XCD start in groups of this many (power of two, default 1)
  *   "direct_epilogue" 2 = epilogue on the accumulator registers, stores straight from the MFMA layout; 0 = accumulators
  *                     transposed through the LDS first (whole rows per store instruction); 1 = per epilogue kind (default)
- *   "dynamic_tiles"   1 = the workgroups of a persistent launch pull their tiles (after the first) from per-XCD counters (robust
- *                     when another stream's kernel holds some CUs; the counters live in a 16 KiB ring the library allocates once
- *                     per device on first use; measured 7 % slower per launch inside a training step), 0 = fixed lists (default)
  *   "split_tail"      1 = a Linear whose 256 x 256 tiles do not fill whole rounds of one workgroup per CU may run as two
  *                     launches (whole rounds + remaining rows) when the cost model says so (default); 0 = never; 2 = always */
 int tad_linear_tuning(const char* key, int value);
@@ -163,21 +161,26 @@ int tad_linear_bwd_weight(const uint16_t* dy, const uint16_t* x, float* dW, floa
  * FlashAttention.forward -> flash_attn_varlen_qkvpacked_func (flash_attention_class.py:47-50)
  * with equal-length sequences (cu_seqlens = arange(0,(B+1)N,N)).
  * qkv [B,N,3,H,d] bf16 packed (the qkv Linear's output, column order [3][H][d]); d must be 64.
- * out [B,N,H,d] in out_dtype; lse [B,H,N] f32 = log(sum_j exp(scale * q.k_j)) (natural log). */
-int tad_attn_fwd(const uint16_t* qkv, void* out, int out_dtype, float* lse, int B, int N, int H, int d,
+ * out [B,N,H,d] in out_dtype; lse [B,H,N] f32 = log(sum_j exp(scale * q.k_j)) (natural log).
+ * out_lo (nullable, 16-bit outputs only): [B,N,H,d] = what the rounding of out dropped (out + out_lo carries 16 / 22 significant
+ * bits), for tad_attn_bwd's delta. */
+int tad_attn_fwd(const uint16_t* qkv, void* out, int out_dtype, uint16_t* out_lo, float* lse, int B, int N, int H, int d,
                  float scale, tad_stream_t stream);
 /* dqkv [B,N,3,H,d] bf16 (fully overwritten).  delta: scratch of tad_attn_bwd_scratch_bytes(B, N, H) bytes = 2*B*H*N floats (the
  * first kernel leaves -rowsum(dout*out) in [0, BHN) and -lse/scale in [BHN, 2 BHN) for the second one, which takes them as the
  * initial values of its accumulators). */
-/* Scheduling knob of the three attention kernels; timing only, never results.  "dma_mode": 0 = the LDS-DMA pieces of the next K/V
- * (Q/dO) tile are issued at the top of a tile, 1 = spread behind the score products of the two half tiles. */
+/* Knob of the three attention kernels.  "dma_mode": 0 = production; 2 / 3 = timing-only ablations (wrong results) that only
+ * ablation builds (TAD_BUILD_ABLATION=1) accept. */
 int tad_attn_tuning(const char* key, int value);
 size_t tad_attn_bwd_scratch_bytes(int B, int N, int H);
 /* Diagnostic, ablation builds only (see tad_linear_debug_stamps): while buf (device memory, 32 bytes per workgroup of the dK/dV grid
  * = ceil(N/128)*H*B workgroups) is set, every dK/dV workgroup records {s_memrealtime, s_memtime} at the start and at the end of its
  * tile loop: (d memtime / d memrealtime) x 100 MHz = the clock held inside the loop.  NULL switches it off. */
 int tad_attn_debug_stamps(void* buf);
-int tad_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* lse,
+/* out_lo (nullable): the forward's rounding residual; with it delta = rowsum(dout * (out + out_lo)), i.e. of the unrounded output, which
+ * is what cancels against the dP the kernels recompute (without it the q / k gradients of near-uniform attention rows carry the
+ * rounding of out amplified by |delta| / |dP - delta|). */
+int tad_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* out_lo, const uint16_t* dout, const float* lse,
                  uint16_t* dqkv, float* delta, int B, int N, int H, int d, float scale,
                  tad_stream_t stream);
 
@@ -220,7 +223,9 @@ int tad_transpose_bf16_batched(const uint16_t* src, uint16_t* dst, const int32_t
  * group_lr / group_wd / group_step: HOST arrays [n_groups] (this step's lr and weight decay; the 1-based count of updates the
  * group's tensors will have received after this call -- torch keeps it per parameter).  Update rule = torch.optim.AdamW:
  *   p *= 1 - lr*wd;  m += (1-b1)(g-m);  v = b2 v + (1-b2) g^2;  p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
- * grad_scale (device scalar or NULL): g is multiplied by *grad_scale first (gradient clipping without a host sync).
+ * grad_scale (device scalar or NULL): g is multiplied by *grad_scale first (gradient clipping and loss-scale removal without a host
+ *   sync).  *grad_scale == 0 or not finite SKIPS the update (parameters, moments and the operand copy stay untouched; sumsq_partials
+ *   is still written): the device-side form of GradScaler's "found inf -> skip the step" (utils.py:386-412).
  * param_bf16 (or NULL): receives bf16(p_new) -- the operand copy the next forward's GEMMs read.
  * sumsq_partials (or NULL): [ceil(n / CHUNK)] per-chunk sums of the UNSCALED g^2 (deterministic order). */
 #define TAD_ADAMW_CHUNK 4096
@@ -297,6 +302,57 @@ int tad_rccl_world_size(tad_comm_t comm, int* nranks);
 int tad_rccl_allreduce(tad_comm_t comm, void* buf, size_t count, int dtype, int average, tad_stream_t stream);
 int tad_rccl_broadcast(tad_comm_t comm, void* buf, size_t count, int dtype, int root, tad_stream_t stream);
 int tad_rccl_destroy(tad_comm_t comm);
+
+/* ---- IEEE half operand twins ------------------------------------------------------------------------------------------------------
+ * The reference trains under torch.cuda.amp.autocast() -- float16 on CUDA -- with a GradScaler (engine_for_finetuning.py:67,
+ * utils.py:386-412).  Every entry point above that takes or produces 16-bit GEMM / attention operands therefore exists a second
+ * time with IEEE half in place of bfloat16: identical signature, semantics, kernels and schedules (the sources are compiled twice,
+ * csrc/common.h), TAD_F16 in place of TAD_BF16 wherever a dtype argument selects the 16-bit type.  Half carries 11 significant bits
+ * against bfloat16's 8 (operand rounding 2^-12 instead of 2^-9) at the same MFMA rate, and a narrower range (6e-8 .. 65504): the
+ * backward pass runs on loss-scaled gradients exactly as in the reference (engine.NativeScalerWithGradNormCount; the scale is removed,
+ * and an overflowed step skipped, inside tad_adamw_step_f16 through its grad_scale argument). */
+int tad_cast_f32_f16(const float* src, uint16_t* dst, int64_t n, tad_stream_t stream);
+int tad_transpose_cast_f32_f16(const float* src /*[R,C]*/, uint16_t* dst /*[C,R]*/, int R, int C, tad_stream_t stream);
+int tad_scale_cast_f16(const float* x, uint16_t* y, const float* gamma, const float* rowscale, int rows_per_scale, int64_t M, int N,
+                       tad_stream_t stream);
+int tad_colsum_f16(const uint16_t* a, float* out, int accumulate, void* ws, size_t ws_bytes, int64_t M, int N, tad_stream_t stream);
+int tad_split_f16x3(const float* x, uint16_t* out, int64_t M, int K, int role_b, int stack, tad_stream_t stream);
+int tad_im2col_tubelets_f16(const float* x, uint16_t* cols, int B, int C, int T, int H, int W, int tubelet, int patch,
+                            tad_stream_t stream);
+int tad_im2col_tubelets_u8_f16(const uint8_t* frames, uint16_t* cols, int B, int T, int H, int W, int tubelet, int patch,
+                               const float* mean3, const float* std3, int bgr, int t_offset, tad_stream_t stream);
+int tad_patch_embed_fwd_f16(const float* x, const uint16_t* w_f16, const float* bias, const float* pos, float* out, uint16_t* cols,
+                            int B, int C, int T, int H, int W, int tubelet, int patch, int D, tad_stream_t stream);
+int tad_patch_embed_gemm_f16(const uint16_t* cols, const uint16_t* w_f16, const float* bias, const float* pos, float* out, int64_t M,
+                             int ntok, int D, int K, tad_stream_t stream);
+int tad_patch_embed_bwd_f16(const uint16_t* dy_f16, const uint16_t* cols, float* dW, float* db, void* ws, size_t ws_bytes, int64_t M,
+                            int D, int K, tad_stream_t stream);
+int tad_layernorm_fwd_f16(const float* x, const float* gamma, const float* beta, void* y, int y_dtype, float* mean, float* rstd,
+                          int64_t rows, int D, float eps, tad_stream_t stream);
+int tad_layernorm_bwd_f16(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* mean, const float* rstd,
+                          const float* dres, float* dx, uint16_t* dx_f16, float* dgamma, float* dbeta, float* colsum_dx,
+                          const float* rowscale, int rows_per_scale, int accumulate, void* ws, size_t ws_bytes, int64_t rows, int D,
+                          tad_stream_t stream);
+int tad_linear_fwd_f16(const uint16_t* x, const uint16_t* w, const float* bias, void* y, int y_dtype, int epilogue, uint16_t* preact,
+                       const float* residual, const float* gamma, const float* rowscale, int rows_per_scale, int64_t M, int N, int K,
+                       tad_stream_t stream);
+int tad_linear_fwd_qkv_f16(const uint16_t* x, const uint16_t* w, const float* q_bias, const float* v_bias, void* y, int y_dtype,
+                           int64_t M, int N, int K, tad_stream_t stream);
+int tad_linear_bwd_input_f16(const uint16_t* dy, const uint16_t* wT, void* dx, int dx_dtype, const uint16_t* gelu_preact, int64_t M,
+                             int N, int K, tad_stream_t stream);
+int tad_linear_bwd_weight_f16(const uint16_t* dy, const uint16_t* x, float* dW, float* db, int accumulate, void* ws, size_t ws_bytes,
+                              int64_t M, int N, int K, tad_stream_t stream);
+int tad_linear_bwd_weight_qkv_f16(const uint16_t* dy, const uint16_t* x, float* dW, float* dq_bias, float* dv_bias, int accumulate,
+                                  void* ws, size_t ws_bytes, int64_t M, int N, int K, tad_stream_t stream);
+int tad_attn_fwd_f16(const uint16_t* qkv, void* out, int out_dtype, uint16_t* out_lo, float* lse, int B, int N, int H, int d,
+                     float scale, tad_stream_t stream);
+int tad_attn_bwd_f16(const uint16_t* qkv, const uint16_t* out, const uint16_t* out_lo, const uint16_t* dout, const float* lse,
+                     uint16_t* dqkv, float* delta, int B, int N, int H, int d, float scale, tad_stream_t stream);
+int tad_meanpool_bwd_f16(const float* dy, float* dx, uint16_t* dx_f16, int B, int N, int D, tad_stream_t stream);
+int tad_adamw_step_f16(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint16_t* param_f16,
+                       const uint8_t* chunk_group, int64_t n, const float* group_lr, const float* group_wd, int n_groups,
+                       const int32_t* group_step, float beta1, float beta2, float eps, const float* grad_scale,
+                       float* sumsq_partials, tad_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -38,11 +38,11 @@ SIGNATURES = {
     "tad_linear_bwd_input": (_i, [_vp, _vp, _vp, _i, _vp, _i64, _i, _i, _vp]),
     "tad_linear_bwd_weight_workspace_bytes": (_sz, [_i64, _i, _i]),
     "tad_linear_bwd_weight": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _sz, _i64, _i, _i, _vp]),
-    "tad_attn_fwd": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _vp]),
+    "tad_attn_fwd": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "tad_attn_tuning": (_i, [C.c_char_p, _i]),
     "tad_attn_bwd_scratch_bytes": (_sz, [_i, _i, _i]),
     "tad_attn_debug_stamps": (_i, [_vp]),
-    "tad_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "tad_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "tad_meanpool_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "tad_meanpool_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "tad_colsum_workspace_bytes": (_sz, [_i64, _i]),
@@ -76,9 +76,24 @@ SIGNATURES = {
     "tad_rccl_destroy": (_i, [_vp]),
 }
 
-TAD_F32, TAD_BF16 = 0, 1
+TAD_F32, TAD_BF16, TAD_F16 = 0, 1, 2
+
+# IEEE-half twins (include/tad_mi355x.h, "IEEE half operand twins"): same signature as the bf16 entry point they mirror
+F16_TWINS = {
+    "tad_cast_f32_bf16": "tad_cast_f32_f16", "tad_transpose_cast_f32_bf16": "tad_transpose_cast_f32_f16",
+    "tad_scale_cast_bf16": "tad_scale_cast_f16", "tad_colsum_bf16": "tad_colsum_f16", "tad_split_bf16x3": "tad_split_f16x3",
+    "tad_im2col_tubelets": "tad_im2col_tubelets_f16", "tad_im2col_tubelets_u8": "tad_im2col_tubelets_u8_f16",
+    "tad_patch_embed_fwd": "tad_patch_embed_fwd_f16", "tad_patch_embed_gemm": "tad_patch_embed_gemm_f16",
+    "tad_patch_embed_bwd": "tad_patch_embed_bwd_f16", "tad_layernorm_fwd": "tad_layernorm_fwd_f16",
+    "tad_layernorm_bwd": "tad_layernorm_bwd_f16", "tad_linear_fwd": "tad_linear_fwd_f16", "tad_linear_fwd_qkv": "tad_linear_fwd_qkv_f16",
+    "tad_linear_bwd_input": "tad_linear_bwd_input_f16", "tad_linear_bwd_weight": "tad_linear_bwd_weight_f16",
+    "tad_linear_bwd_weight_qkv": "tad_linear_bwd_weight_qkv_f16", "tad_attn_fwd": "tad_attn_fwd_f16", "tad_attn_bwd": "tad_attn_bwd_f16",
+    "tad_meanpool_bwd": "tad_meanpool_bwd_f16", "tad_adamw_step": "tad_adamw_step_f16",
+}
+for _bf, _h in F16_TWINS.items():
+    SIGNATURES[_h] = SIGNATURES[_bf]
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 ADAMW_CHUNK = 4096
 ADAMW_MAX_GROUPS = 128
 POOL_SPLIT = 8

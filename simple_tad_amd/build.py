@@ -11,6 +11,9 @@ CSRC = os.path.join(HERE, "csrc")
 # and TAD_LIB=<path> selects the library a process loads (_lib.py).
 LIB = os.path.join(HERE, os.environ.get("TAD_BUILD_LIB", "libtad_mi355x.so"))
 SOURCES = ["capi.hip", "elementwise.hip", "layernorm.hip", "gemm.hip", "attn_fwd.hip", "attn_bwd.hip", "precise.hip", "optim.hip", "mae.hip", "metrics.hip", "collective.hip"]
+# Sources that touch 16-bit GEMM / attention operands are compiled a second time with -DTAD_OPND_F16: the same kernels for IEEE half
+# operands, exported as tad_*_f16 (csrc/common.h, csrc/opnd_f16_names.h; include/tad_mi355x.h "IEEE half operand twins").
+F16_SOURCES = ["elementwise.hip", "layernorm.hip", "gemm.hip", "attn_fwd.hip", "attn_bwd.hip", "optim.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result",
          # keep MFMA accumulators in the (unified) VGPR file: without it the compiler parks them in AGPRs and pays a
          # v_accvgpr_read/write per element around every softmax / epilogue
@@ -39,21 +42,26 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
 
-    def compile_one(src):
-        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "opnd_f16_names.h"), os.path.join(os.path.dirname(HERE), "include", "tad_mi355x.h")]
+
+    def compile_one(job):
+        src, half = job
+        obj = os.path.join(objdir, src.replace(".hip", "_f16.o" if half else ".o"))
         srcp = os.path.join(CSRC, src)
-        if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(srcp), os.path.getmtime(os.path.join(CSRC, "common.h")),
-                                                                          os.path.getmtime(os.path.join(os.path.dirname(HERE), "include", "tad_mi355x.h")))):
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(p) for p in [srcp, *headers]):
             return obj
-        cmd = [hipcc, *FLAGS, *(["-DTAD_GEMM_ABLATION"] if os.environ.get("TAD_BUILD_ABLATION") == "1" else []),
+        cmd = [hipcc, *FLAGS, *(["-DTAD_OPND_F16"] if half else []), *(["-DTAD_GEMM_ABLATION"] if os.environ.get("TAD_BUILD_ABLATION") == "1" else []),
                *os.environ.get("TAD_BUILD_DEFINES", "").split(), "-c", srcp, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
         return obj
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
-        objs = list(ex.map(compile_one, SOURCES))
+    # longest jobs first (gemm.hip takes ~35 s per pass); TAD_BUILD_JOBS bounds the parallelism (default: the CPU count, at most 8)
+    jobs = sorted([(s, False) for s in SOURCES] + [(s, True) for s in F16_SOURCES], key=lambda j: -os.path.getsize(os.path.join(CSRC, j[0])))
+    workers = int(os.environ.get("TAD_BUILD_JOBS", 0)) or min(8, os.cpu_count() or 4)
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        objs = list(ex.map(compile_one, jobs))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)

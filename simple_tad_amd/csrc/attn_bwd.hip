@@ -21,7 +21,7 @@
 #include <type_traits>
 #include "common.h"
 
-namespace tad {
+TAD_NAMESPACE_BEGIN
 
 constexpr int BHD = 64;
 constexpr float LOG2E = 1.44269504088896340736f;
@@ -36,7 +36,7 @@ typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 
 // transposed fragment: lane (x = lane&31 within a 32-wide column tile, h = lane>>5) gets, for j = 0..7, element
 // tile[rbase + 8*(j>>2) + 4*h + (j&3)][col0 + x]   (the k-order of an accumulator tile used as the other operand)
-__device__ __forceinline__ bf16x8 tr_frag_dual(const char* tile, int rbase, int col0, int lane) {
+__device__ __forceinline__ op16x8 tr_frag_dual(const char* tile, int rbase, int col0, int lane) {
   const int G = lane >> 4, li = lane & 15;
   const int r0 = rbase + 4 * (G >> 1) + (li >> 2), r1 = r0 + 8;
   const int col = col0 + 16 * (G & 1) + 4 * (li & 3);
@@ -46,7 +46,7 @@ __device__ __forceinline__ bf16x8 tr_frag_dual(const char* tile, int rbase, int 
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(a0));
   const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(a1));
   const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return __builtin_bit_cast(bf16x8, v);
+  return __builtin_bit_cast(op16x8, v);
 }
 // The same fragment through the inline-asm reads of common.h (the builtin form above makes the compiler drain the LDS-DMA of the
 // next tile in front of it): tr_dual_addr gives the lane's two LDS addresses for rbase = 0 inside a tile at byte address `tile`
@@ -62,34 +62,32 @@ __device__ __forceinline__ void tr_dual_addr(uint32_t tile, int col0, int lane, 
   }
 }
 // row fragment: lane (row = lane&31, h = lane>>5) gets tile[row0 + row][16ks + 8h .. +7]
-__device__ __forceinline__ bf16x8 row_frag_dual(const char* tile, int row, int ks, int h5) {
-  return *reinterpret_cast<const bf16x8*>(tile + row * 128 + (((2 * ks + h5) ^ sw_dual(row)) << 4));
+__device__ __forceinline__ op16x8 row_frag_dual(const char* tile, int row, int ks, int h5) {
+  return *reinterpret_cast<const op16x8*>(tile + row * 128 + (((2 * ks + h5) ^ sw_dual(row)) << 4));
 }
 
-__device__ __forceinline__ bf16x8 pack8(const f32x16& a, int s2) {
+__device__ __forceinline__ op16x8 pack8(const f32x16& a, int s2) {
   // pairwise v_cvt_pk_bf16_f32 (one instruction per two elements)
   typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
   u32x4 r;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) r[j] = pack_bf16x2(a[8 * s2 + 2 * j], a[8 * s2 + 2 * j + 1]);
-  return __builtin_bit_cast(bf16x8, r);
+  for (int j = 0; j < 4; ++j) r[j] = pack_op16x2(a[8 * s2 + 2 * j], a[8 * s2 + 2 * j + 1]);
+  return __builtin_bit_cast(op16x8, r);
 }
 
 // ------------------------------------------------------------------------------------------------ dQ
-// DMA_MODE (tad_attn_tuning("dma_mode")): where the LDS-DMA pieces of the NEXT tile are issued.  0: all at the top of the tile (before the
-// first matrix instruction).  1: spread into the tile -- issuing a piece blocks the wave for 60-185 cycles depending on what else the
-// phase carries (MI355X_MICROARCH.md, 'LDS-DMA piece issue cost'), cheapest in VALU-only stretches.  2: ablation, no DMA inside the loop
-// (every tile reads the first one: wrong results, timing only; refused outside ablation builds).
-// NST (tad_attn_tuning("stages")): depth of the K/V (Q/dO) tile ring.  2: the next tile is requested at the top of a tile and the end of the
-// tile waits for ALL of it (s_waitcnt vmcnt(0)): whatever part of its latency the tile's arithmetic did not cover is exposed.  3: the
-// tile after next is requested instead and the end of the tile waits with a COUNTED vmcnt that leaves it in flight (raw s_barrier: a
-// __syncthreads() would drain the DMA), so a request has two tile times to land.
-template <int DMA_MODE, int NST>
+// DMA_MODE: 0 = production (the LDS-DMA pieces of the NEXT tile are issued at the top of a tile, before its first matrix instruction; the end of
+// the tile waits for all of it).  2 / 3 exist in ablation builds only (timing experiments, wrong results): 2 = no DMA inside the loop,
+// 3 = dK/dV kernel without its transposed LDS reads.  The variants round 2 measured and dropped (pieces spread into the tile, a
+// three-deep tile ring, 64 keys per wave at one wave per SIMD) are archived under experiments/r02_variants.
+template <int DMA_MODE>
 __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out,
+                                                          const uint16_t* __restrict__ out_lo,
                                                           const uint16_t* __restrict__ dout, const float* __restrict__ lse,
                                                           float* __restrict__ delta, uint16_t* __restrict__ dqkv, int N, int H, int B,
                                                           float scale) {
   constexpr int TILE_BYTES = 64 * 128;
+  constexpr int NST = 2;  // K/V (Q/dO) tile ring depth
   __shared__ __attribute__((aligned(1024))) char lds[NST * 2 * TILE_BYTES];  // [buf][K|V]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -108,27 +106,38 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
   const bool qvalid = qrow < N;
   const bool wave_live = q0 < N;  // wave-uniform
   if (!qvalid) qrow = N - 1;
-  bf16x8 qf[4], dof[4];
+  op16x8 qf[4], dof[4];
   {
     const uint16_t* qp = base + (int64_t)qrow * tok + 8 * h5;
     const uint16_t* dp = dout + (((int64_t)b * N + qrow) * H + head) * BHD + 8 * h5;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
-      dof[ks] = *reinterpret_cast<const bf16x8*>(dp + 16 * ks);
+      qf[ks] = *reinterpret_cast<const op16x8*>(qp + 16 * ks);
+      dof[ks] = *reinterpret_cast<const op16x8*>(dp + 16 * ks);
     }
   }
   const float lse2 = lse[((int64_t)b * H + head) * N + qrow] * LOG2E;
   // delta = rowsum(dO o O): this lane holds half of its query row (the 8-element groups 2ks + h5), lane ^ 32 the other half
   float dlt;
   {
-    const uint16_t* op = out + (((int64_t)b * N + qrow) * H + head) * BHD + 8 * h5;
+    // With out_lo (what the forward's 16-bit rounding of O dropped) delta is taken of the UNROUNDED output.  delta = sum_k P_k dP_k
+    // must cancel against the dP the kernels recompute exactly from V and dO; a delta computed from the rounded O is off by
+    // dO . (O - round(O)), an error in dS proportional to P that does not cancel -- for rows whose dP_k are nearly equal across the
+    // keys (dS small against delta: near-uniform attention, a common component in V) it dominated dQ / dK and the q / k gradients
+    // behind them (measured on ViT-B at the real shape: the worst q-row slice of a qkv weight gradient off by 12 % in bf16, 2 % in f16).
+    const int64_t orow = (((int64_t)b * N + qrow) * H + head) * BHD + 8 * h5;
     float part = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const bf16x8 of = *reinterpret_cast<const bf16x8*>(op + 16 * ks);
+      const op16x8 of = *reinterpret_cast<const op16x8*>(out + orow + 16 * ks);
+      if (out_lo) {
+        const op16x8 ol = *reinterpret_cast<const op16x8*>(out_lo + orow + 16 * ks);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) part = fmaf((float)of[e], (float)dof[ks][e], part);
+        for (int e = 0; e < 8; ++e) part = fmaf((float)of[e] + (float)ol[e], (float)dof[ks][e], part);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part = fmaf((float)of[e], (float)dof[ks][e], part);
+      }
     }
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(part), __float_as_uint(part), false, false);
     dlt = __uint_as_float(r[0]) + __uint_as_float(r[1]);
@@ -176,16 +185,11 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
 
   const int nt = (N + 63) / 64;
   DMA_KV(0, 0);
-  if (NST == 3 && nt > 1) {
-    DMA_KV(1, 64);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // tile 0 landed (this wave's 4 pieces of tile 1 may still be in flight)
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   asm volatile("" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  // the tile loop runs in pairs (triples with three stages) so that the LDS buffer index is a literal in each copy of the body: every LDS address is then a
+  // the tile loop runs in pairs so that the LDS buffer index is a literal in each copy of the body: every LDS address is then a
   // lane constant + immediate instead of a handful of v_add / v_or per fragment read
   uint32_t ktr[2][2];  // K^T fragment addresses (tile 0 of buffer 0), [d tile][first / second read]
   tr_dual_addr(lds_addr(lds), 0, lane, ktr[0]);
@@ -193,12 +197,10 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
   auto dq_tile = [&](auto BUFC, int t) {
     constexpr int BUF = decltype(BUFC)::value;
     const int kv0 = t * 64;
-    const bool more = NST == 3 ? (t + 2 < nt) : (t + 1 < nt);  // is there a tile to request during this one?
-    constexpr int NBUF = NST == 3 ? (BUF + 2) % 3 : (BUF ^ 1);  // its buffer ...
-    const int nkv0 = NST == 3 ? kv0 + 128 : kv0 + 64;           // ... and first key
-    // (the second half of a tile is skipped only in the LAST tile, where nothing is staged any more: a live wave that has to stage
-    // runs both halves, so DMA_MODE 1 may hang its pieces on them)
-    if (more && (DMA_MODE == 0 || (DMA_MODE == 1 && !wave_live))) DMA_KV(NBUF, nkv0);
+    const bool more = t + 1 < nt;  // is there a tile to request during this one?
+    constexpr int NBUF = BUF ^ 1;  // its buffer ...
+    const int nkv0 = kv0 + 64;     // ... and first key
+    if (more && DMA_MODE == 0) DMA_KV(NBUF, nkv0);
     const char* kl = lds + BUF * 2 * TILE_BYTES;
     const char* vl = kl + TILE_BYTES;
     // a wave whose 32 query rows all lie past the sequence (the last block of N = 1568 has one live wave of four) only helps
@@ -224,8 +226,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
       const int key = kt * 32 + ql;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_dual(kl, key, ks, h5), qf[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_dual(vl, key, ks, h5), dof[ks], dp, 0, 0, 0);
+        s = TAD_MFMA_32x32x16(row_frag_dual(kl, key, ks, h5), qf[ks], s);
+        dp = TAD_MFMA_32x32x16(row_frag_dual(vl, key, ks, h5), dof[ks], dp);
       }
       // dS^T = P^T o (dP^T - delta); keys >= N contribute nothing
       if (kv0 + 64 > N) {  // ragged last tile only: keys >= N get P = 0
@@ -235,50 +237,28 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
           if (kg >= N) s[r] = -1e30f;
         }
       }
-      if constexpr (DMA_MODE == 1) {  // next tile's K pieces behind the first half's score products, V pieces behind the second's
-        if (more) {
-          if constexpr (kt == 0) DMA_K_(NBUF, nkv0) else DMA_V_(NBUF, nkv0)
-        }
-      }
       f32x16 ds;
 #pragma unroll
       for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(s[r] * c - lse2) * dp[r];
       lds_wait<4>(tl[0][0], th[0][0], tl[0][1], th[0][1]);
       {
-        const bf16x8 dsf = pack8(ds, 0);
+        const op16x8 dsf = pack8(ds, 0);
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_tr(tl[0][dt], th[0][dt]), dsf, dq[dt], 0, 0, 0);
+        for (int dt = 0; dt < 2; ++dt) dq[dt] = TAD_MFMA_32x32x16(join_tr(tl[0][dt], th[0][dt]), dsf, dq[dt]);
       }
       lds_wait<0>(tl[1][0], th[1][0], tl[1][1], th[1][1]);
       {
-        const bf16x8 dsf = pack8(ds, 1);
+        const op16x8 dsf = pack8(ds, 1);
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_tr(tl[1][dt], th[1][dt]), dsf, dq[dt], 0, 0, 0);
+        for (int dt = 0; dt < 2; ++dt) dq[dt] = TAD_MFMA_32x32x16(join_tr(tl[1][dt], th[1][dt]), dsf, dq[dt]);
       }
     });
-    if (NST == 3) {
-      // the next tile (requested one tile ago) must have landed; the one requested during this tile (4 pieces per wave) stays in flight
-      if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
   };
-  if constexpr (NST == 3) {
-    for (int t = 0; t < nt; t += 3) {
-      dq_tile(std::integral_constant<int, 0>{}, t);
-      if (t + 1 < nt) dq_tile(std::integral_constant<int, 1>{}, t + 1);
-      if (t + 2 < nt) dq_tile(std::integral_constant<int, 2>{}, t + 2);
-    }
-  } else {
-    for (int t = 0; t < nt; t += 2) {
-      dq_tile(std::integral_constant<int, 0>{}, t);
-      if (t + 1 < nt) dq_tile(std::integral_constant<int, 1>{}, t + 1);
-    }
+  for (int t = 0; t < nt; t += 2) {
+    dq_tile(std::integral_constant<int, 0>{}, t);
+    if (t + 1 < nt) dq_tile(std::integral_constant<int, 1>{}, t + 1);
   }
 
   if (qvalid) {
@@ -289,20 +269,21 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
       for (int r4 = 0; r4 < 4; ++r4) {
         const int d = dt * 32 + 8 * r4 + 4 * h5;
         uint2 pk;
-        pk.x = pack_bf16x2(dq[dt][4 * r4 + 0] * scale, dq[dt][4 * r4 + 1] * scale);
-        pk.y = pack_bf16x2(dq[dt][4 * r4 + 2] * scale, dq[dt][4 * r4 + 3] * scale);
+        pk.x = pack_op16x2(dq[dt][4 * r4 + 0] * scale, dq[dt][4 * r4 + 1] * scale);
+        pk.y = pack_op16x2(dq[dt][4 * r4 + 2] * scale, dq[dt][4 * r4 + 3] * scale);
         *reinterpret_cast<uint2*>(op + d) = pk;
       }
   }
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
-template <int DMA_MODE, int NST>
+template <int DMA_MODE>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
                                                            const float* __restrict__ rowc_g, uint16_t* __restrict__ dqkv, int N, int H, int B,
                                                            float scale, unsigned long long* stamps) {
   constexpr int TILE_BYTES = 64 * 128;
   constexpr int STAGE = 2 * TILE_BYTES + 512;  // Q tile, dO tile, 64 x (-lse/scale), 64 x (-delta)
+  constexpr int NST = 2;
   __shared__ __attribute__((aligned(1024))) char lds[NST * STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -322,11 +303,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
   const bool kvalid = krow < N;
   const bool wave_live = key0 < N;  // wave-uniform
   if (!kvalid) krow = N - 1;
-  bf16x8 kfr[4], vfr[4];
+  op16x8 kfr[4], vfr[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    kfr[ks] = *reinterpret_cast<const bf16x8*>(kbase + (int64_t)krow * tok + 16 * ks + 8 * h5);
-    vfr[ks] = *reinterpret_cast<const bf16x8*>(vbase + (int64_t)krow * tok + 16 * ks + 8 * h5);
+    kfr[ks] = *reinterpret_cast<const op16x8*>(kbase + (int64_t)krow * tok + 16 * ks + 8 * h5);
+    vfr[ks] = *reinterpret_cast<const op16x8*>(vbase + (int64_t)krow * tok + 16 * ks + 8 * h5);
   }
 
   // Q / dO tiles go global -> LDS by LDS-DMA (1-KiB piece = 8 rows x 128 B, wave w moves pieces w and w+4 of each; swizzle on the
@@ -388,14 +369,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
 
   const int nt = (N + 63) / 64;
   LOAD_QDO(0, 0);
-  if (NST == 3 && nt > 1) {
-    LOAD_QDO(1, 64);
-    // tile 0 landed; this wave's pieces of tile 1 (4, and the row constants from waves 0 and 1) may still be in flight
-    if (wave < 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   asm volatile("" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -407,10 +381,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
 #endif
   int cur = 0;  // ring slot of tile t
   for (int t = 0; t < nt; ++t) {
-    const bool more = NST == 3 ? (t + 2 < nt) : (t + 1 < nt);           // is there a tile to request during this one?
-    const int nbuf = NST == 3 ? (cur == 0 ? 2 : cur - 1) : (cur ^ 1);    // its ring slot ((t + 2) % 3 resp. (t + 1) % 2) ...
-    const int nq0 = NST == 3 ? (t + 2) * 64 : (t + 1) * 64;             // ... and first query row
-    if (more && (DMA_MODE == 0 || (DMA_MODE == 1 && !wave_live))) LOAD_QDO(nbuf, nq0);
+    const bool more = t + 1 < nt;  // is there a tile to request during this one?
+    const int nbuf = cur ^ 1;      // its ring slot ...
+    const int nq0 = (t + 1) * 64;  // ... and first query row
+    if (more && DMA_MODE == 0) LOAD_QDO(nbuf, nq0);
     const uint32_t so = (uint32_t)(cur * STAGE);
     if (wave_live)  // (see the dQ kernel: waves whose 32 keys all lie past the sequence only stage tiles)
     static_for<0, 2>([&](auto qtc) {
@@ -419,7 +393,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
       if (t * 64 + 32 * qt >= N) return;  // half tile of query rows past the sequence: P = dS = 0 there anyway
       // batch 1: initial accumulators (per-row constants; accumulator register r <-> row (r&3) + 8*(r>>2) + 4*h5) and row fragments
       f32x4 si[4], di[4];
-      bf16x8 qa[4], da[4];
+      op16x8 qa[4], da[4];
       static_for<0, 4>([&](auto r4c) {
         constexpr int r4 = decltype(r4c)::value;
         si[r4] = lds_read_b128<f32x4, (qt * 32 + 8 * r4) * 4>(rca + so);
@@ -427,8 +401,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
       });
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        qa[ks] = lds_read_b128<bf16x8, HT>(rfa[ks] + so);
-        da[ks] = lds_read_b128<bf16x8, TILE_BYTES + HT>(rfa[ks] + so);
+        qa[ks] = lds_read_b128<op16x8, HT>(rfa[ks] + so);
+        da[ks] = lds_read_b128<op16x8, TILE_BYTES + HT>(rfa[ks] + so);
       }
       // batch 2 / 3: transposed fragments for the dV / dK products of rows 0..15 / 16..31 of the half tile
       s16x4 dol[2][2], doh[2][2], qtl[2][2], qth[2][2];  // [s2][dt]
@@ -442,8 +416,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
 #define TR_MFMA(s2_, YOUNGER, pf_, dsf_)                                                                                       \
   lds_wait<YOUNGER>(dol[s2_][0], doh[s2_][0], qtl[s2_][0], qth[s2_][0], dol[s2_][1], doh[s2_][1], qtl[s2_][1], qth[s2_][1]);   \
   _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) {                                                                           \
-    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_tr(dol[s2_][dt], doh[s2_][dt]), pf_, dv[dt], 0, 0, 0);               \
-    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_tr(qtl[s2_][dt], qth[s2_][dt]), dsf_, dk[dt], 0, 0, 0);              \
+    dv[dt] = TAD_MFMA_32x32x16(join_tr(dol[s2_][dt], doh[s2_][dt]), pf_, dv[dt]);               \
+    dk[dt] = TAD_MFMA_32x32x16(join_tr(qtl[s2_][dt], qth[s2_][dt]), dsf_, dk[dt]);              \
   }
       if constexpr (DMA_MODE != 3) {
         TR_ISSUE(0);
@@ -463,15 +437,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
       }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks], kfr[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[ks], vfr[ks], dp, 0, 0, 0);
+        s = TAD_MFMA_32x32x16(qa[ks], kfr[ks], s);
+        dp = TAD_MFMA_32x32x16(da[ks], vfr[ks], dp);
       }
       if constexpr (DMA_MODE != 3) { TR_ISSUE(1); }
-      if constexpr (DMA_MODE == 1) {  // next tile: Q pieces behind the first half's score products, dO + row constants behind the second's
-        if (more) {
-          if constexpr (qt == 0) LOAD_Q_(nbuf, nq0) else LOAD_DO_RC_(nbuf, nq0)
-        }
-      }
       f32x16 pm, ds;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -480,43 +449,30 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
       }
       if constexpr (DMA_MODE != 3) {
         {
-          const bf16x8 pf = pack8(pm, 0), dsf = pack8(ds, 0);
+          const op16x8 pf = pack8(pm, 0), dsf = pack8(ds, 0);
           TR_MFMA(0, 8, pf, dsf);
         }
         {
-          const bf16x8 pf = pack8(pm, 1), dsf = pack8(ds, 1);
+          const op16x8 pf = pack8(pm, 1), dsf = pack8(ds, 1);
           TR_MFMA(1, 0, pf, dsf);
         }
       } else {
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-          const bf16x8 pf = pack8(pm, s2), dsf = pack8(ds, s2);
+          const op16x8 pf = pack8(pm, s2), dsf = pack8(ds, s2);
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt) {
-            dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[2 * s2 + dt], pf, dv[dt], 0, 0, 0);
-            dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[2 * s2 + dt], dsf, dk[dt], 0, 0, 0);
+            dv[dt] = TAD_MFMA_32x32x16(vfr[2 * s2 + dt], pf, dv[dt]);
+            dk[dt] = TAD_MFMA_32x32x16(kfr[2 * s2 + dt], dsf, dk[dt]);
           }
         }
       }
 #undef TR_ISSUE
 #undef TR_MFMA
     });
-    if (NST == 3) {
-      if (more) {
-        if (wave < 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      cur = cur == 2 ? 0 : cur + 1;
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      cur ^= 1;
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
   }
 
 #ifdef TAD_GEMM_ABLATION
@@ -534,310 +490,42 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
       for (int r4 = 0; r4 < 4; ++r4) {
         const int d = dt * 32 + 8 * r4 + 4 * h5;
         uint2 pk, pv;
-        pk.x = pack_bf16x2(dk[dt][4 * r4 + 0] * scale, dk[dt][4 * r4 + 1] * scale);
-        pk.y = pack_bf16x2(dk[dt][4 * r4 + 2] * scale, dk[dt][4 * r4 + 3] * scale);
-        pv.x = pack_bf16x2(dv[dt][4 * r4 + 0], dv[dt][4 * r4 + 1]);
-        pv.y = pack_bf16x2(dv[dt][4 * r4 + 2], dv[dt][4 * r4 + 3]);
+        pk.x = pack_op16x2(dk[dt][4 * r4 + 0] * scale, dk[dt][4 * r4 + 1] * scale);
+        pk.y = pack_op16x2(dk[dt][4 * r4 + 2] * scale, dk[dt][4 * r4 + 3] * scale);
+        pv.x = pack_op16x2(dv[dt][4 * r4 + 0], dv[dt][4 * r4 + 1]);
+        pv.y = pack_op16x2(dv[dt][4 * r4 + 2], dv[dt][4 * r4 + 3]);
         *reinterpret_cast<uint2*>(okp + d) = pk;
         *reinterpret_cast<uint2*>(ovp + d) = pv;
       }
   }
 }
 
-// ---- 64 keys per wave, ONE wave per SIMD (tad_attn_tuning("dkv_keys", 64)).  The 32-key kernel above re-reads every Q / dO tile from the LDS
-// once per 32 keys (row fragments, transposed fragments and the row constants: 96 LDS cycles per half tile and wave against 512 matrix
-// cycles; rocprofv3: LDS array 34 % busy at 45 % matrix-pipe utilisation, 13.6 % of the wave lifetime stalled at LDS issue; without
-// its transposed reads -- ablation mode 3 -- the kernel runs 26 % faster).  Here a wave pins the K / V fragments of TWO 32-key groups
-// and every fragment read from the LDS feeds both, which halves the LDS traffic per MFMA; that takes ~300 registers, i.e. one wave per
-// SIMD (4-wave workgroups of 256 keys, one per CU), and the overlap of matrix and vector work then has to come from inside the wave: the
-// score products of both groups are issued before the exponentials of the first, the dV / dK products of the first before the
-// exponentials of the second.
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
-                                                           const float* __restrict__ rowc_g, uint16_t* __restrict__ dqkv, int N, int H, int B,
-                                                           float scale, unsigned long long* stamps) {
-  constexpr int TILE_BYTES = 64 * 128;
-  constexpr int STAGE = 2 * TILE_BYTES + 512;  // Q tile, dO tile, 64 x (-lse/scale), 64 x (-delta)
-  constexpr int NST = 2, DMA_MODE = 0;
-  __shared__ __attribute__((aligned(1024))) char lds[NST * STAGE];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nblk = (N + 255) / 256;  // 1-D XCD-aware grid (see attn_fwd.hip)
-  const int lin = xcd_remap(blockIdx.x, gridDim.x);
-  const int head = (lin / nblk) % H, b = lin / nblk / H;
-  const int key0 = (lin % nblk) * 256 + wave * 64;  // the wave's two key groups: key0 + 32 g + (lane & 31)
-  const int kl_ = lane & 31, h5 = lane >> 5;
-  const int64_t tok = (int64_t)3 * H * BHD;
-  const uint16_t* base = qkv + (int64_t)b * N * tok + head * BHD;
-  const uint16_t* kbase = base + (int64_t)H * BHD;
-  const uint16_t* vbase = base + (int64_t)2 * H * BHD;
-  const uint16_t* dobase = dout + ((int64_t)b * N * H + head) * BHD;  // row q at + q*H*64
-  const float c = scale * LOG2E;
-
-  const bool wave_live = key0 < N;        // wave-uniform
-  const bool g1_live = key0 + 32 < N;     // wave-uniform: the second key group has keys inside the sequence
-  bf16x8 kfr[2][4], vfr[2][4];
-#pragma unroll
-  for (int g = 0; g < 2; ++g) {
-    int krow = key0 + 32 * g + kl_;
-    if (krow > N - 1) krow = N - 1;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      kfr[g][ks] = *reinterpret_cast<const bf16x8*>(kbase + (int64_t)krow * tok + 16 * ks + 8 * h5);
-      vfr[g][ks] = *reinterpret_cast<const bf16x8*>(vbase + (int64_t)krow * tok + 16 * ks + 8 * h5);
-    }
-  }
-
-  // Q / dO tiles go global -> LDS by LDS-DMA (1-KiB piece = 8 rows x 128 B, wave w moves pieces w and w+4 of each; swizzle on the
-  // per-lane SOURCE chunk); rows past the tensor read as zero, rows >= N are neutralised through the row constants below.
-  const uint32_t qkv_bytes = (uint32_t)B * (uint32_t)N * (uint32_t)tok * 2u;
-  const uint32_t do_bytes = (uint32_t)B * (uint32_t)N * (uint32_t)(H * BHD) * 2u;
-  const auto rs_qkv = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(qkv), 0, (int)qkv_bytes, 0x00020000);
-  const auto rs_do = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(dout), 0, (int)do_bytes, 0x00020000);
-  uint32_t dma_q[2], dma_do[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = (wave + 4 * i) * 8 + (lane >> 3);
-    const uint32_t ch = (uint32_t)(((lane & 7) ^ sw_dual(row)) << 4);
-    dma_q[i] = (uint32_t)(((int64_t)b * N + row) * tok * 2) + (uint32_t)(head * BHD * 2) + ch;
-    dma_do[i] = (uint32_t)((((int64_t)b * N + row) * H + head) * BHD * 2) + ch;
-  }
-  const uint32_t q_step = (uint32_t)(tok * 2), do_step = (uint32_t)(H * BHD * 2);
-  // Row constants (initial accumulator values, written by the dQ kernel): rows [0, BHN) of `rowc` hold -delta, rows [BHN, 2 BHN)
-  // hold -lse/scale.  They are staged by LDS-DMA as well (4 bytes per lane: wave 0 moves the 64 -lse/scale values of the tile,
-  // wave 1 the 64 -delta values), so the tile loop holds no ordinary global load and no LDS store -- with either of them in the loop
-  // the compiler drained the DMA of the next tile (s_waitcnt vmcnt(0)) right after issuing it.
-  const int64_t bhn = (int64_t)B * H * N;
-  const auto rs_rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rowc_g), 0, (int)(2 * bhn * 4), 0x00020000);
-  const uint32_t rc_off = (uint32_t)(((wave == 0 ? bhn : 0) + ((int64_t)b * H + head) * N + lane) * 4);
-#define LOAD_Q_(buf, q0)                                                                                   \
-  {                                                                                                        \
-    char* ql_ = lds + (buf) * STAGE;                                                                       \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                          \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_qkv, LDS_PTR(ql_ + (wave + 4 * i) * 1024), 16, dma_q[i] + (uint32_t)(q0) * q_step, 0, 0, 0); \
-  }
-#define LOAD_DO_RC_(buf, q0)                                                                               \
-  {                                                                                                        \
-    char* ql_ = lds + (buf) * STAGE;                                                                       \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                          \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_do, LDS_PTR(ql_ + TILE_BYTES + (wave + 4 * i) * 1024), 16, dma_do[i] + (uint32_t)(q0) * do_step, 0, 0, 0); \
-    if (wave < 2) /* wave-uniform */                                                                       \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_rc, LDS_PTR(ql_ + 2 * TILE_BYTES + wave * 256), 4, rc_off + (uint32_t)(q0) * 4u, 0, 0, 0); \
-  }
-#define LOAD_QDO(buf, q0) { LOAD_Q_(buf, q0); LOAD_DO_RC_(buf, q0); }
-
-  f32x16 dk[2][2], dv[2][2];  // [key group][d tile]
-#pragma unroll
-  for (int g = 0; g < 2; ++g)
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { dk[g][dt][r] = 0.f; dv[g][dt][r] = 0.f; }
-
-  // Every LDS read of the tile loop is inline asm (common.h): the compiler can then neither drain the DMA of the next tile in front
-  // of a read nor serialise read -> wait -> MFMA one fragment at a time; the reads of a half tile are issued in three batches and
-  // waited for where their consumers start.  Lane-constant addresses (stage 0); the stage offset is added per tile, the half
-  // tile / fragment position is an instruction immediate.
-  const uint32_t lds0 = lds_addr(lds);
-  uint32_t qtr[2][2];  // transposed fragments of the Q tile, [d tile][first / second read]; dO tile: + TILE_BYTES
-  tr_dual_addr(lds0, 0, lane, qtr[0]);
-  tr_dual_addr(lds0, 32, lane, qtr[1]);
-  uint32_t rfa[4];     // row fragments (row lane&31 of a half tile, chunk 2ks + h5) of the Q tile; dO tile: + TILE_BYTES
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) rfa[ks] = lds0 + (uint32_t)(kl_ * 128 + (((2 * ks + h5) ^ sw_dual(kl_)) << 4));
-  const uint32_t rca = lds0 + 2 * TILE_BYTES + 16 * h5;  // row constants: 4 floats at [8 r4 + 4 h5]
-
-  const int nt = (N + 63) / 64;
-  LOAD_QDO(0, 0);
-  if (NST == 3 && nt > 1) {
-    LOAD_QDO(1, 64);
-    // tile 0 landed; this wave's pieces of tile 1 (4, and the row constants from waves 0 and 1) may still be in flight
-    if (wave < 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-#ifdef TAD_GEMM_ABLATION  // diagnostic builds only (tad_attn_debug_stamps): shader clock / 100 MHz clock around the tile loop
-  if (stamps && tid == 0) {
-    stamps[(size_t)blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memrealtime();
-    stamps[(size_t)blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
-  }
-#endif
-  int cur = 0;  // ring slot of tile t
-  for (int t = 0; t < nt; ++t) {
-    const bool more = NST == 3 ? (t + 2 < nt) : (t + 1 < nt);           // is there a tile to request during this one?
-    const int nbuf = NST == 3 ? (cur == 0 ? 2 : cur - 1) : (cur ^ 1);    // its ring slot ((t + 2) % 3 resp. (t + 1) % 2) ...
-    const int nq0 = NST == 3 ? (t + 2) * 64 : (t + 1) * 64;             // ... and first query row
-    if (more && (DMA_MODE == 0 || (DMA_MODE == 1 && !wave_live))) LOAD_QDO(nbuf, nq0);
-    const uint32_t so = (uint32_t)(cur * STAGE);
-    if (wave_live)  // (see the dQ kernel: waves whose 32 keys all lie past the sequence only stage tiles)
-    static_for<0, 2>([&](auto qtc) {
-      constexpr int qt = decltype(qtc)::value;
-      constexpr int HT = qt * 32 * 128;  // byte offset of the half tile inside a tile
-      if (t * 64 + 32 * qt >= N) return;  // half tile of query rows past the sequence: P = dS = 0 there anyway
-      // batch 1: initial accumulators (per-row constants; accumulator register r <-> row (r&3) + 8*(r>>2) + 4*h5) and row fragments
-      f32x4 si[4], di[4];
-      bf16x8 qa[4], da[4];
-      static_for<0, 4>([&](auto r4c) {
-        constexpr int r4 = decltype(r4c)::value;
-        si[r4] = lds_read_b128<f32x4, (qt * 32 + 8 * r4) * 4>(rca + so);
-        di[r4] = lds_read_b128<f32x4, 256 + (qt * 32 + 8 * r4) * 4>(rca + so);
-      });
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        qa[ks] = lds_read_b128<bf16x8, HT>(rfa[ks] + so);
-        da[ks] = lds_read_b128<bf16x8, TILE_BYTES + HT>(rfa[ks] + so);
-      }
-      // batch 2 / 3: transposed fragments for the dV / dK products of rows 0..15 / 16..31 of the half tile
-      s16x4 dol[2][2], doh[2][2], qtl[2][2], qth[2][2];  // [s2][dt]
-#define TR_ISSUE(s2_)                                                                         \
-  _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) {                                          \
-    dol[s2_][dt] = lds_tr16_b64<TILE_BYTES + HT + 16 * (s2_) * 128>(qtr[dt][0] + so);         \
-    doh[s2_][dt] = lds_tr16_b64<TILE_BYTES + HT + 16 * (s2_) * 128>(qtr[dt][1] + so);         \
-    qtl[s2_][dt] = lds_tr16_b64<HT + 16 * (s2_) * 128>(qtr[dt][0] + so);                      \
-    qth[s2_][dt] = lds_tr16_b64<HT + 16 * (s2_) * 128>(qtr[dt][1] + so);                      \
-  }
-      if constexpr (DMA_MODE != 3) {
-        TR_ISSUE(0);
-        lds_wait<16>(si[0], si[1], si[2], si[3], di[0], di[1], di[2], di[3]);  // (the counter saturates at 15: this also covers the row fragments)
-        lds_wait<8>(qa[0], qa[1], qa[2], qa[3], da[0], da[1], da[2], da[3]);
-      }
-      // the row constants are the C operand of the FIRST product of each group's chain (D goes to the group's own registers): no copies
-      f32x16 sinit, dinit, s[2], dp[2];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { sinit[r] = si[r >> 2][r & 3]; dinit[r] = di[r >> 2][r & 3]; }
-      if (t * 64 + 32 * qt + 32 > N) {  // ragged half tile (N % 32 != 0): rows >= N get exp2(c*(s - 3e30)) = 0 and delta = 0
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (t * 64 + 32 * qt + (r & 3) + 8 * (r >> 2) + 4 * h5 >= N) { sinit[r] = -3.0e30f; dinit[r] = 0.f; }
-      }
-      // One wave per SIMD: matrix and vector work overlap only if they alternate in THIS wave's instruction stream, so the half tile is
-      // laid out in four regions and the scheduler is told the interleave (sched_group_barrier: mask 0x8 = MFMA, 0x2 = VALU):
-      //   A  score products of group 0                                   (8 MFMAs; the LDS reads of batch 2 are in flight)
-      //   B  score products of group 1  beside  exponentials of group 0  (8 x [1 MFMA, 8 VALU])
-      //   C  dV / dK products of group 0  beside  exponentials of group 1 (8 x [1 MFMA, 8 VALU])
-      //   D  dV / dK products of group 1                                 (8 MFMAs)
-      // A dead second group (only in the last workgroup of a sequence) is computed and dropped: no branch may split the regions.
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {  // A
-        s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks], kfr[0][ks], ks == 0 ? sinit : s[0], 0, 0, 0);
-        dp[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[ks], vfr[0][ks], ks == 0 ? dinit : dp[0], 0, 0, 0);
-      }
-      TR_ISSUE(1);
-      bf16x8 pf[2][2], dsf[2][2];  // [key group][s2]
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {  // B: matrix half
-        s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks], kfr[1][ks], ks == 0 ? sinit : s[1], 0, 0, 0);
-        dp[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[ks], vfr[1][ks], ks == 0 ? dinit : dp[1], 0, 0, 0);
-      }
-      {  // B: vector half
-        f32x16 pm, ds;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { pm[r] = fast_exp2(s[0][r] * c); ds[r] = pm[r] * dp[0][r]; }
-        pf[0][0] = pack8(pm, 0); pf[0][1] = pack8(pm, 1); dsf[0][0] = pack8(ds, 0); dsf[0][1] = pack8(ds, 1);
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
-      }
-      lds_wait<8>(dol[0][0], doh[0][0], qtl[0][0], qth[0][0], dol[0][1], doh[0][1], qtl[0][1], qth[0][1]);
-      lds_wait<0>(dol[1][0], doh[1][0], qtl[1][0], qth[1][0], dol[1][1], doh[1][1], qtl[1][1], qth[1][1]);
-      bf16x8 dot_[2][2], qt_[2][2];  // [s2][dt] joined transposed fragments (shared by both key groups)
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) { dot_[s2][dt] = join_tr(dol[s2][dt], doh[s2][dt]); qt_[s2][dt] = join_tr(qtl[s2][dt], qth[s2][dt]); }
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)  // C: matrix half
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          dv[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot_[s2][dt], pf[0][s2], dv[0][dt], 0, 0, 0);
-          dk[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt_[s2][dt], dsf[0][s2], dk[0][dt], 0, 0, 0);
-        }
-      {  // C: vector half
-        f32x16 pm, ds;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { pm[r] = fast_exp2(s[1][r] * c); ds[r] = pm[r] * dp[1][r]; }
-        pf[1][0] = pack8(pm, 0); pf[1][1] = pack8(pm, 1); dsf[1][0] = pack8(ds, 0); dsf[1][1] = pack8(ds, 1);
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-        __builtin_amdgcn_sched_group_barrier(0x002, 8, 1);
-      }
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)  // D
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          dv[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot_[s2][dt], pf[1][s2], dv[1][dt], 0, 0, 0);
-          dk[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt_[s2][dt], dsf[1][s2], dk[1][dt], 0, 0, 0);
-        }
-#undef TR_ISSUE
-    });
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    cur ^= 1;
-  }
-
-#ifdef TAD_GEMM_ABLATION
-  if (stamps && tid == 0) {
-    stamps[(size_t)blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
-    stamps[(size_t)blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime();
-  }
-#endif
-#pragma unroll
-  for (int g = 0; g < 2; ++g) {
-    const int krow = key0 + 32 * g + kl_;
-    if (krow >= N) continue;
-    uint16_t* okp = dqkv + ((int64_t)b * N + krow) * tok + (int64_t)H * BHD + head * BHD;
-    uint16_t* ovp = okp + (int64_t)H * BHD;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const int d = dt * 32 + 8 * r4 + 4 * h5;
-        uint2 pk, pv;
-        pk.x = pack_bf16x2(dk[g][dt][4 * r4 + 0] * scale, dk[g][dt][4 * r4 + 1] * scale);
-        pk.y = pack_bf16x2(dk[g][dt][4 * r4 + 2] * scale, dk[g][dt][4 * r4 + 3] * scale);
-        pv.x = pack_bf16x2(dv[g][dt][4 * r4 + 0], dv[g][dt][4 * r4 + 1]);
-        pv.y = pack_bf16x2(dv[g][dt][4 * r4 + 2], dv[g][dt][4 * r4 + 3]);
-        *reinterpret_cast<uint2*>(okp + d) = pk;
-        *reinterpret_cast<uint2*>(ovp + d) = pv;
-      }
-  }
-}
-
-}  // namespace tad
+TAD_NAMESPACE_END
 
 using namespace tad;
 
-static unsigned long long* g_attn_stamps = nullptr;
-int g_attn_dma_mode = getenv("TAD_ATTN_DMA_MODE") ? atoi(getenv("TAD_ATTN_DMA_MODE")) : 0;  // shared with attn_fwd.hip
-static int g_attn_bwd_stages = getenv("TAD_ATTN_BWD_STAGES") ? atoi(getenv("TAD_ATTN_BWD_STAGES")) : 2;
-static int g_attn_dkv_keys = getenv("TAD_ATTN_DKV_KEYS") ? atoi(getenv("TAD_ATTN_DKV_KEYS")) : 32;  // keys per wave of the dK/dV kernel
+// Process-wide state of the attention kernels: one copy for the library (defined by the bf16 pass, shared by the half pass).
+namespace tad { namespace knobs {
+#ifndef TAD_OPND_F16
+unsigned long long* attn_stamps = nullptr;
+int attn_dma_mode = getenv("TAD_ATTN_DMA_MODE") ? atoi(getenv("TAD_ATTN_DMA_MODE")) : 0;  // 2 / 3: timing-only ablations (ablation builds); shared with attn_fwd.hip
+#else
+extern unsigned long long* attn_stamps;
+extern int attn_dma_mode;
+#endif
+}}  // namespace tad::knobs
+using namespace tad::knobs;
 
+#ifndef TAD_OPND_F16
 extern "C" int tad_attn_tuning(const char* key, int value) {
   TAD_REQUIRE(key, "attn_tuning: null key");
   if (!strcmp(key, "dma_mode")) {
 #ifdef TAD_GEMM_ABLATION
-    TAD_REQUIRE(value >= 0 && value <= 3, "attn_tuning: dma_mode=%d not in 0..3", value);
+    TAD_REQUIRE(value == 0 || value == 2 || value == 3, "attn_tuning: dma_mode=%d not in {0, 2, 3}", value);
 #else
-    TAD_REQUIRE(value >= 0 && value <= 1, "attn_tuning: dma_mode=%d not in 0..1 (2 = timing-only ablation, ablation builds)", value);
+    TAD_REQUIRE(value == 0, "attn_tuning: dma_mode=%d: only 0 outside ablation builds (2 / 3 are timing-only ablations)", value);
 #endif
-    g_attn_dma_mode = value;
-    return TAD_OK;
-  }
-  if (!strcmp(key, "dkv_keys")) {
-    TAD_REQUIRE(value == 32 || value == 64, "attn_tuning: dkv_keys=%d not in {32, 64}", value);
-    g_attn_dkv_keys = value;
-    return TAD_OK;
-  }
-  if (!strcmp(key, "bwd_stages")) {
-    TAD_REQUIRE(value == 2 || value == 3, "attn_tuning: bwd_stages=%d not in {2, 3}", value);
-    g_attn_bwd_stages = value;
+    attn_dma_mode = value;
     return TAD_OK;
   }
   set_error("attn_tuning: unknown key '%s'", key);
@@ -850,7 +538,7 @@ extern "C" int tad_attn_debug_stamps(void* buf) {
 #ifndef TAD_GEMM_ABLATION
   if (buf) { set_error("attn_debug_stamps: needs an ablation build (TAD_BUILD_ABLATION=1 python -m simple_tad_amd.build --force)"); return TAD_EINVAL; }
 #endif
-  g_attn_stamps = (unsigned long long*)buf;
+  attn_stamps = (unsigned long long*)buf;
   return TAD_OK;
 }
 
@@ -858,9 +546,10 @@ extern "C" size_t tad_attn_bwd_scratch_bytes(int B, int N, int H) {
   if (B <= 0 || N <= 0 || H <= 0) return 0;
   return (size_t)2 * B * H * N * sizeof(float);
 }
+#endif
 
-extern "C" int tad_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* lse, uint16_t* dqkv, float* delta,
-                            int B, int N, int H, int d, float scale, tad_stream_t stream) {
+extern "C" int tad_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* out_lo, const uint16_t* dout, const float* lse,
+                            uint16_t* dqkv, float* delta, int B, int N, int H, int d, float scale, tad_stream_t stream) {
   TAD_REQUIRE(qkv && out && dout && lse && dqkv && delta, "attn_bwd: null pointer");
   TAD_REQUIRE(d == BHD, "attn_bwd: head_dim must be 64 (got %d)", d);
   TAD_REQUIRE(B > 0 && N > 0 && H > 0 && H <= 65535 && B <= 65535, "attn_bwd: bad shape");
@@ -869,29 +558,20 @@ extern "C" int tad_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint
   TAD_REQUIRE((int64_t)B * N * 3 * H * BHD * 2 < (1ll << 32), "attn_bwd: qkv exceeds the 4 GiB buffer descriptor (B=%d N=%d H=%d)", B, N, H);
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)(((N + 127) / 128) * H * B)), block(256);
-  const int mode = g_attn_dma_mode;
-  if (g_attn_dkv_keys == 64) {
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<0, 2>), grid, block, 0, st, qkv, out, dout, lse, delta, dqkv, N, H, B, scale);
-    int rc = check_launch("attn_bwd_dq");
-    if (rc) return rc;
-    const dim3 grid64((unsigned)(((N + 255) / 256) * H * B));
-    hipLaunchKernelGGL(attn_bwd_dkv64_kernel, grid64, block, 0, st, qkv, dout, delta, dqkv, N, H, B, scale, g_attn_stamps);
-    return check_launch("attn_bwd_dkv64");
+  const int mode = attn_dma_mode;
+#define LAUNCH_BWD(M_)                                                                                                       \
+  {                                                                                                                          \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<M_>), grid, block, 0, st, qkv, out, out_lo, dout, lse, delta, dqkv, N, H, B, scale);      \
+    int rc = check_launch("attn_bwd_dq");                                                                                    \
+    if (rc) return rc;                                                                                                       \
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<M_>), grid, block, 0, st, qkv, dout, delta, dqkv, N, H, B, scale, attn_stamps);  \
+    return check_launch("attn_bwd_dkv");                                                                                     \
   }
-#define LAUNCH_BWD(M_, S_)                                                                                                          \
-  {                                                                                                                                 \
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<M_, S_>), grid, block, 0, st, qkv, out, dout, lse, delta, dqkv, N, H, B, scale);         \
-    int rc = check_launch("attn_bwd_dq");                                                                                           \
-    if (rc) return rc;                                                                                                              \
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<M_, S_>), grid, block, 0, st, qkv, dout, delta, dqkv, N, H, B, scale, g_attn_stamps);   \
-    return check_launch("attn_bwd_dkv");                                                                                            \
-  }
-  if (g_attn_bwd_stages == 3) LAUNCH_BWD(0, 3)
-  if (mode == 1) LAUNCH_BWD(1, 2)
 #ifdef TAD_GEMM_ABLATION
-  if (mode == 2) LAUNCH_BWD(2, 2)
-  if (mode == 3) LAUNCH_BWD(3, 2)  // (dQ kernel: as mode 0; dK/dV kernel: no transposed LDS reads)
+  if (mode == 2) LAUNCH_BWD(2)
+  if (mode == 3) LAUNCH_BWD(3)  // (dQ kernel: as mode 0; dK/dV kernel: no transposed LDS reads)
 #endif
-  LAUNCH_BWD(0, 2)
+  (void)mode;
+  LAUNCH_BWD(0)
 #undef LAUNCH_BWD
 }

@@ -14,7 +14,7 @@
 #include <string.h>
 #include "common.h"
 
-namespace tad {
+TAD_NAMESPACE_BEGIN
 namespace {
 
 struct RcclApi {
@@ -73,7 +73,7 @@ bool dtype_of(int dtype, ncclDataType_t* out) {
 }
 
 }  // namespace
-}  // namespace tad
+TAD_NAMESPACE_END
 
 using namespace tad;
 

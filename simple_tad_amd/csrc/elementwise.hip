@@ -2,7 +2,7 @@
 // All are streaming kernels: 16-byte vector accesses, grid capped at ~8 blocks/CU with grid-stride loops.
 #include "common.h"
 
-namespace tad {
+TAD_NAMESPACE_BEGIN
 
 static inline int capped_grid(int64_t work_items, int block) {
   int64_t g = (work_items + block - 1) / block;
@@ -19,15 +19,15 @@ __global__ void cast_f32_bf16_kernel(const float* __restrict__ src, uint16_t* __
     const float4 a = reinterpret_cast<const float4*>(src)[2 * i];
     const float4 b = reinterpret_cast<const float4*>(src)[2 * i + 1];
     uint4 o;
-    o.x = pack_bf16x2(a.x, a.y);
-    o.y = pack_bf16x2(a.z, a.w);
-    o.z = pack_bf16x2(b.x, b.y);
-    o.w = pack_bf16x2(b.z, b.w);
+    o.x = pack_op16x2(a.x, a.y);
+    o.y = pack_op16x2(a.z, a.w);
+    o.z = pack_op16x2(b.x, b.y);
+    o.w = pack_op16x2(b.z, b.w);
     reinterpret_cast<uint4*>(dst)[i] = o;
   }
   // tail
   for (int64_t i = (n8 << 3) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-    dst[i] = f32_to_bf16(src[i]);
+    dst[i] = f32_to_op16(src[i]);
 }
 
 // ---------------------------------------------------------------- transpose + cast: src [R,C] f32 -> dst [C,R] bf16
@@ -43,7 +43,7 @@ __global__ void transpose_cast_kernel(const float* __restrict__ src, uint16_t* _
   __syncthreads();
   for (int i = ty; i < 64; i += 4) {
     const int c = c0 + i, r = r0 + tx;
-    if (c < C && r < R) dst[(int64_t)c * R + r] = f32_to_bf16(tile[tx][i]);
+    if (c < C && r < R) dst[(int64_t)c * R + r] = f32_to_op16(tile[tx][i]);
   }
 }
 
@@ -129,7 +129,7 @@ __global__ void im2col_tubelets_u8_kernel(const uint8_t* __restrict__ frames, ui
       }
       const int k = ((c * tub + kt) * p + kh) * p + kw;
       *reinterpret_cast<uint4*>(cols + n * K + k) =
-          make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+          make_uint4(pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3]), pack_op16x2(v[4], v[5]), pack_op16x2(v[6], v[7]));
     }
   }
 }
@@ -160,10 +160,10 @@ __global__ void im2col_tubelets_kernel(const float* __restrict__ x, uint16_t* __
     const int64_t n = ((int64_t)(b * Tp + tp) * Hp + hp) * Wp + wp;
     const int k = ((c * tub + kt) * p + kh) * p + kw;
     uint4 o;
-    o.x = pack_bf16x2(a0.x, a0.y);
-    o.y = pack_bf16x2(a0.z, a0.w);
-    o.z = pack_bf16x2(a1.x, a1.y);
-    o.w = pack_bf16x2(a1.z, a1.w);
+    o.x = pack_op16x2(a0.x, a0.y);
+    o.y = pack_op16x2(a0.z, a0.w);
+    o.z = pack_op16x2(a1.x, a1.y);
+    o.w = pack_op16x2(a1.z, a1.w);
     *reinterpret_cast<uint4*>(cols + n * K + k) = o;
   }
 }
@@ -192,7 +192,7 @@ __global__ void im2col_tubelets_pairs_kernel(const float* __restrict__ x, OutT* 
     const int64_t n = ((int64_t)(b * Tp + tp) * Hp + hp) * Wp + wp;
     const int k = ((c * tub + kt) * p + kh) * p + kw;
     OutT* row = cols + n * ldk;
-    if constexpr (sizeof(OutT) == 2) *reinterpret_cast<uint32_t*>(row + k) = pack_bf16x2(a.x, a.y);
+    if constexpr (sizeof(OutT) == 2) *reinterpret_cast<uint32_t*>(row + k) = pack_op16x2(a.x, a.y);
     else *reinterpret_cast<float2*>(row + k) = a;
     if (k == 0) {
       for (int z = K; z < ldk; z += 2) {
@@ -253,8 +253,8 @@ __global__ void meanpool_bwd_kernel(const float* __restrict__ dy, float* __restr
     if (dx) reinterpret_cast<float4*>(dx)[i] = v;
     if (dxb) {
       uint2 o;
-      o.x = pack_bf16x2(v.x, v.y);
-      o.y = pack_bf16x2(v.z, v.w);
+      o.x = pack_op16x2(v.x, v.y);
+      o.y = pack_op16x2(v.z, v.w);
       reinterpret_cast<uint2*>(dxb)[i] = o;
     }
   }
@@ -273,10 +273,10 @@ __global__ void colsum_partial_kernel(const uint16_t* __restrict__ a, float* __r
   if (c0 < N) {
     for (int64_t m = m0 + wave; m < m1; m += 4) {
       const uint4 v = *reinterpret_cast<const uint4*>(a + m * N + c0);
-      acc[0] += __uint_as_float(v.x << 16); acc[1] += __uint_as_float(v.x & 0xffff0000u);
-      acc[2] += __uint_as_float(v.y << 16); acc[3] += __uint_as_float(v.y & 0xffff0000u);
-      acc[4] += __uint_as_float(v.z << 16); acc[5] += __uint_as_float(v.z & 0xffff0000u);
-      acc[6] += __uint_as_float(v.w << 16); acc[7] += __uint_as_float(v.w & 0xffff0000u);
+      acc[0] += op16_lo_f32(v.x); acc[1] += op16_hi_f32(v.x);
+      acc[2] += op16_lo_f32(v.y); acc[3] += op16_hi_f32(v.y);
+      acc[4] += op16_lo_f32(v.z); acc[5] += op16_hi_f32(v.z);
+      acc[6] += op16_lo_f32(v.w); acc[7] += op16_hi_f32(v.w);
     }
   }
 #pragma unroll
@@ -417,8 +417,8 @@ __global__ void scale_cast_kernel(const float* __restrict__ x, uint16_t* __restr
       v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w;
     }
     uint2 o;
-    o.x = pack_bf16x2(v.x * s, v.y * s);
-    o.y = pack_bf16x2(v.z * s, v.w * s);
+    o.x = pack_op16x2(v.x * s, v.y * s);
+    o.y = pack_op16x2(v.z * s, v.w * s);
     reinterpret_cast<uint2*>(y)[i] = o;
   }
 }
@@ -523,9 +523,9 @@ int launch_reduce_partials(const float* partial, float* out, int splits, int64_t
   return check_launch("reduce_partials");
 }
 
-}  // namespace tad
+TAD_NAMESPACE_END
 
-namespace tad {
+TAD_NAMESPACE_BEGIN
 // precise-mode (f32) patch matrix for even patch sizes that are not a multiple of 4; called from precise.hip
 int launch_im2col_pairs_f32(const float* x, float* cols, int B, int C, int T, int H, int W, int tubelet, int patch, int ldk, hipStream_t st) {
   const int64_t pairs = (int64_t)B * C * T * H * (W / 2);
@@ -533,7 +533,46 @@ int launch_im2col_pairs_f32(const float* x, float* cols, int B, int C, int T, in
                      patch, ldk);
   return check_launch("im2col_f32");
 }
-}  // namespace tad
+// ---------------------------------------------------------------- operand split for the precise / split-operand Linears
+// x = hi + lo with hi = op16(x), lo = op16(x - hi) (bf16: 16 significant bits, f16: 22).  A product of two f32 operands is recovered
+// to ~2^-17 (bf16) relative from three MFMA products  A_hi*B_hi + A_hi*B_lo + A_lo*B_hi  -- and those three products are ONE GEMM
+// over a 3x longer reduction dimension: [A_hi | A_hi | A_lo] . [B_hi | B_lo | B_hi]^T.  So the split Linear reuses the production
+// MFMA GEMM kernels unchanged; only the operand preparation differs.
+// out row r, for source row m = r % M (stack mode) or r (concat mode)
+// concat (along K): out [M, 3K]; role A: [hi | hi | lo], role B: [hi | lo | hi]
+// stack  (along M): out [3M, K]; role A: rows [hi ; hi ; lo], role B: rows [hi ; lo ; hi]
+__global__ void split_bf16x3_kernel(const float* __restrict__ x, uint16_t* __restrict__ out, int64_t M, int K, int role_b, int stack) {
+  const int K4 = K >> 2;
+  const int64_t total = M * K4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t m = i / K4;
+    const int c = (int)(i - m * K4) * 4;
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float f[4] = {v.x, v.y, v.z, v.w};
+    uint16_t hi[4], lo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      hi[e] = f32_to_op16(f[e]);
+      lo[e] = f32_to_op16(f[e] - op16_to_f32(hi[e]));
+    }
+    const uint2 H = make_uint2((uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16));
+    const uint2 L = make_uint2((uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16));
+    const uint2 s0 = H, s1 = role_b ? L : H, s2 = role_b ? H : L;
+    if (stack) {
+      *reinterpret_cast<uint2*>(out + (m)*K + c) = s0;
+      *reinterpret_cast<uint2*>(out + (M + m) * K + c) = s1;
+      *reinterpret_cast<uint2*>(out + (2 * M + m) * K + c) = s2;
+    } else {
+      uint16_t* o = out + m * 3 * K;
+      *reinterpret_cast<uint2*>(o + c) = s0;
+      *reinterpret_cast<uint2*>(o + K + c) = s1;
+      *reinterpret_cast<uint2*>(o + 2 * K + c) = s2;
+    }
+  }
+}
+
+TAD_NAMESPACE_END
 
 using namespace tad;
 
@@ -553,6 +592,7 @@ int tad_transpose_cast_f32_bf16(const float* src, uint16_t* dst, int R, int C, t
   return check_launch("transpose_cast");
 }
 
+#ifndef TAD_OPND_F16  // format-independent: one copy for the library (bf16 pass)
 int tad_transpose_bf16_batched(const uint16_t* src, uint16_t* dst, const int32_t* table, int n_tiles, tad_stream_t stream) {
   TAD_REQUIRE(src && dst && table && n_tiles > 0, "transpose_bf16_batched: bad args");
   TAD_REQUIRE((((uintptr_t)src | (uintptr_t)dst | (uintptr_t)table) & 15) == 0, "transpose_bf16_batched: buffers must be 16-byte aligned");
@@ -565,6 +605,7 @@ int tad_patch_embed_ldk(int C, int tubelet, int patch) {
   const int K = C * tubelet * patch * patch;
   return (K + 63) / 64 * 64;
 }
+#endif
 
 int tad_im2col_tubelets(const float* x, uint16_t* cols, int B, int C, int T, int H, int W, int tubelet, int patch,
                         tad_stream_t stream) {
@@ -599,12 +640,14 @@ int tad_im2col_tubelets_u8(const uint8_t* frames, uint16_t* cols, int B, int T, 
   return check_launch("im2col_tubelets_u8");
 }
 
+#ifndef TAD_OPND_F16  // format-independent: one copy for the library (bf16 pass)
 int tad_meanpool_fwd(const float* x, float* y, float* ws, int B, int N, int D, tad_stream_t stream) {
   TAD_REQUIRE(x && y && ws && B > 0 && N > 0 && D > 0 && D % 4 == 0, "meanpool_fwd: bad args (D must be a multiple of 4)");
   hipLaunchKernelGGL(meanpool_partial_kernel, dim3((D / 4 + 63) / 64, TAD_POOL_SPLIT, B), dim3(256), 0, (hipStream_t)stream, x, ws, N, D);
   hipLaunchKernelGGL(meanpool_final_kernel, dim3((B * D + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, y, B, N, D);
   return check_launch("meanpool_fwd");
 }
+#endif
 
 int tad_meanpool_bwd(const float* dy, float* dx, uint16_t* dx_bf16, int B, int N, int D, tad_stream_t stream) {
   TAD_REQUIRE(dy && (dx || dx_bf16) && B > 0 && N > 0 && D % 4 == 0, "meanpool_bwd: bad args");
@@ -619,7 +662,9 @@ static inline int colsum_splits(int64_t M) {
   if (s < 1) s = 1;
   return (int)s;
 }
+#ifndef TAD_OPND_F16  // format-independent: one copy for the library (bf16 pass)
 size_t tad_colsum_workspace_bytes(int64_t M, int N) { return (size_t)colsum_splits(M) * (size_t)N * sizeof(float); }
+#endif
 
 int tad_colsum_bf16(const uint16_t* a, float* out, int accumulate, void* ws, size_t ws_bytes, int64_t M, int N,
                     tad_stream_t stream) {
@@ -631,6 +676,7 @@ int tad_colsum_bf16(const uint16_t* a, float* out, int accumulate, void* ws, siz
   return launch_reduce_partials((const float*)ws, out, splits, N, accumulate, (hipStream_t)stream);
 }
 
+#ifndef TAD_OPND_F16  // format-independent: one copy for the library (bf16 pass)
 int tad_colsum_window_f32(const float* a, float* out, int accumulate, void* ws, size_t ws_bytes, int B, int R, int N, int r0, int rc,
                           tad_stream_t stream) {
   TAD_REQUIRE(a && out && ws && B > 0 && R > 0 && N > 0 && N % 4 == 0, "colsum_window: bad args (N must be a multiple of 4)");
@@ -645,6 +691,7 @@ int tad_colsum_window_f32(const float* a, float* out, int accumulate, void* ws, 
   if (rc_) return rc_;
   return launch_reduce_partials((const float*)ws, out, splits, N, accumulate, (hipStream_t)stream);
 }
+#endif
 
 int tad_scale_cast_bf16(const float* x, uint16_t* y, const float* gamma, const float* rowscale, int rows_per_scale, int64_t M,
                         int N, tad_stream_t stream) {
@@ -655,11 +702,19 @@ int tad_scale_cast_bf16(const float* x, uint16_t* y, const float* gamma, const f
   return check_launch("scale_cast");
 }
 
+#ifndef TAD_OPND_F16  // format-independent: one copy for the library (bf16 pass)
 int tad_sumsq_f32(const float* x, int64_t n, float* out, tad_stream_t stream) {
   TAD_REQUIRE(x && out && n >= 0, "sumsq: bad args");
   if (n == 0) return TAD_OK;
   hipLaunchKernelGGL(sumsq_kernel, dim3(capped_grid(n, 256 * 8)), dim3(256), 0, (hipStream_t)stream, x, n, out);
   return check_launch("sumsq");
+}
+#endif
+
+int tad_split_bf16x3(const float* x, uint16_t* out, int64_t M, int K, int role_b, int stack, tad_stream_t stream) {
+  TAD_REQUIRE(x && out && M > 0 && K > 0 && K % 4 == 0, "split_bf16x3: bad args (K must be a multiple of 4)");
+  hipLaunchKernelGGL(split_bf16x3_kernel, dim3(capped_grid(M * (K / 4), 256)), dim3(256), 0, (hipStream_t)stream, x, out, M, K, role_b, stack);
+  return check_launch("split_bf16x3");
 }
 
 }  // extern "C"

@@ -3,7 +3,7 @@
 // row movers / reductions; every row is D f32 with D % 4 == 0 (float4 per lane).
 #include "common.h"
 
-namespace tad {
+TAD_NAMESPACE_BEGIN
 
 static inline int rows_grid(int64_t rows) {
   int64_t g = (rows + 3) / 4;  // 4 rows (waves) per 256-thread block
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred
   if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-}  // namespace tad
+TAD_NAMESPACE_END
 
 using namespace tad;
 

@@ -4,7 +4,7 @@
 // of k(p) = #{t : p >= t}: a sample is predicted positive at threshold index i exactly when i < k(p).  Counts are exact integers.
 #include "common.h"
 
-namespace tad {
+TAD_NAMESPACE_BEGIN
 
 constexpr int MAX_THR = 255;
 
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void threshold_hist_kernel(const float* __rest
     if (sh[i]) atomicAdd(&hist[i], (unsigned long long)sh[i]);
 }
 
-}  // namespace tad
+TAD_NAMESPACE_END
 
 using namespace tad;
 

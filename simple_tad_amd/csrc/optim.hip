@@ -10,7 +10,7 @@
 #include "common.h"
 #include <math.h>
 
-namespace tad {
+TAD_NAMESPACE_BEGIN
 
 struct AdamGroups {
   float decay[TAD_ADAMW_MAX_GROUPS];      // 1 - lr*wd
@@ -28,9 +28,12 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   __shared__ float red[4];
   const int grp = chunk_group[blockIdx.x];
   float sq = 0.f;
-  if (grp != 255) {
+  const float gs = grad_scale ? *grad_scale : 1.f;
+  // *grad_scale == 0 (or not finite) skips the update: what GradScaler.step does when the scaled gradients overflowed (utils.py:386-412;
+  // the host folds "found inf" into the scale: engine.NativeScalerWithGradNormCount), decided on the device without a host sync
+  const bool skip = grad_scale && !(fabsf(gs) > 0.f && fabsf(gs) < INFINITY);
+  if (grp != 255 && !skip) {
     const float decay = hp.decay[grp], ss = hp.step_size[grp], bc2_sqrt = hp.bc2_sqrt[grp];
-    const float gs = grad_scale ? *grad_scale : 1.f;
     const int64_t base = (int64_t)blockIdx.x * TAD_ADAMW_CHUNK;
 #pragma unroll
     for (int it = 0; it < TAD_ADAMW_CHUNK / 1024; ++it) {
@@ -54,10 +57,20 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
       *reinterpret_cast<float4*>(p + i) = make_float4(pa[0], pa[1], pa[2], pa[3]);
       *reinterpret_cast<float4*>(m + i) = make_float4(ma[0], ma[1], ma[2], ma[3]);
       *reinterpret_cast<float4*>(v + i) = make_float4(va[0], va[1], va[2], va[3]);
-      if (pb) *reinterpret_cast<uint2*>(pb + i) = make_uint2(pack_bf16x2(pa[0], pa[1]), pack_bf16x2(pa[2], pa[3]));
+      if (pb) *reinterpret_cast<uint2*>(pb + i) = make_uint2(pack_op16x2(pa[0], pa[1]), pack_op16x2(pa[2], pa[3]));
     }
   }
   if (sumsq_partial) {  // fixed reduction order: deterministic norm
+    if (grp != 255 && skip) {  // a skipped step still reports the norm of what it skipped
+      const int64_t base = (int64_t)blockIdx.x * TAD_ADAMW_CHUNK;
+#pragma unroll
+      for (int it = 0; it < TAD_ADAMW_CHUNK / 1024; ++it) {
+        const int64_t i = base + (int64_t)(it * 256 + threadIdx.x) * 4;
+        if (i >= n) break;
+        const float4 gv = *reinterpret_cast<const float4*>(g + i);
+        sq = fmaf(gv.x, gv.x, fmaf(gv.y, gv.y, fmaf(gv.z, gv.z, fmaf(gv.w, gv.w, sq))));
+      }
+    }
     sq = wave_sum(sq);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
     __syncthreads();
@@ -65,7 +78,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   }
 }
 
-}  // namespace tad
+TAD_NAMESPACE_END
 
 using namespace tad;
 

@@ -1,48 +1,11 @@
 // "Precise" mode helpers: f32-accurate variants used for the parity gate (end-to-end <= 1e-3 against the fp32 reference),
 // not for throughput.
 //
-//  * split_bf16x3: x = hi + lo with hi = bf16(x), lo = bf16(x - hi).  A product of two f32 operands is recovered to ~2^-17
-//    relative from three bf16 MFMA products  A_hi*B_hi + A_hi*B_lo + A_lo*B_hi  -- and those three products are ONE bf16 GEMM
-//    over a 3x longer reduction dimension: [A_hi | A_hi | A_lo] . [B_hi | B_lo | B_hi]^T.  So the precise Linear reuses the
-//    production MFMA GEMM kernels unchanged; only the operand preparation differs.
+//  * (the operand split x = hi + lo behind the precise Linear is tad_split_bf16x3 / tad_split_f16x3, elementwise.hip)
 //  * attn_fwd_f32_kernel: plain f32 (VALU FMA) flash-style attention for packed f32 qkv, 64 query rows per workgroup.
 #include "common.h"
 
-namespace tad {
-
-// out row r, for source row m = r % M (stack mode) or r (concat mode)
-// concat (along K): out [M, 3K]; role A: [hi | hi | lo], role B: [hi | lo | hi]
-// stack  (along M): out [3M, K]; role A: rows [hi ; hi ; lo], role B: rows [hi ; lo ; hi]
-__global__ void split_bf16x3_kernel(const float* __restrict__ x, uint16_t* __restrict__ out, int64_t M, int K, int role_b, int stack) {
-  const int K4 = K >> 2;
-  const int64_t total = M * K4;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    const int64_t m = i / K4;
-    const int c = (int)(i - m * K4) * 4;
-    const float4 v = reinterpret_cast<const float4*>(x)[i];
-    const float f[4] = {v.x, v.y, v.z, v.w};
-    uint16_t hi[4], lo[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      hi[e] = f32_to_bf16(f[e]);
-      lo[e] = f32_to_bf16(f[e] - bf16_to_f32(hi[e]));
-    }
-    const uint2 H = make_uint2((uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16));
-    const uint2 L = make_uint2((uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16));
-    const uint2 s0 = H, s1 = role_b ? L : H, s2 = role_b ? H : L;
-    if (stack) {
-      *reinterpret_cast<uint2*>(out + (m)*K + c) = s0;
-      *reinterpret_cast<uint2*>(out + (M + m) * K + c) = s1;
-      *reinterpret_cast<uint2*>(out + (2 * M + m) * K + c) = s2;
-    } else {
-      uint16_t* o = out + m * 3 * K;
-      *reinterpret_cast<uint2*>(o + c) = s0;
-      *reinterpret_cast<uint2*>(o + K + c) = s1;
-      *reinterpret_cast<uint2*>(o + 2 * K + c) = s2;
-    }
-  }
-}
+TAD_NAMESPACE_BEGIN
 
 // x [B,C,T,H,W] f32 -> cols [B*N, K] f32 (same token / k order as im2col_tubelets_kernel)
 __global__ void im2col_tubelets_f32_kernel(const float* __restrict__ x, float* __restrict__ cols, int B, int C, int T, int H, int W,
@@ -428,20 +391,15 @@ static inline int grid_for(int64_t items) {
   return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
 }
 
-}  // namespace tad
+TAD_NAMESPACE_END
 
-namespace tad {
+TAD_NAMESPACE_BEGIN
 int launch_im2col_pairs_f32(const float* x, float* cols, int B, int C, int T, int H, int W, int tubelet, int patch, int ldk, hipStream_t st);
-}
+TAD_NAMESPACE_END
 using namespace tad;
 
 extern "C" {
 
-int tad_split_bf16x3(const float* x, uint16_t* out, int64_t M, int K, int role_b, int stack, tad_stream_t stream) {
-  TAD_REQUIRE(x && out && M > 0 && K > 0 && K % 4 == 0, "split_bf16x3: bad args (K must be a multiple of 4)");
-  hipLaunchKernelGGL(split_bf16x3_kernel, dim3(grid_for(M * (K / 4))), dim3(256), 0, (hipStream_t)stream, x, out, M, K, role_b, stack);
-  return check_launch("split_bf16x3");
-}
 
 int tad_im2col_tubelets_f32(const float* x, float* cols, int B, int C, int T, int H, int W, int tubelet, int patch, tad_stream_t stream) {
   TAD_REQUIRE(x && cols, "im2col_f32: null pointer");

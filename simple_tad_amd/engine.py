@@ -3,9 +3,10 @@
 
 Same step ordering as ``engine_for_finetuning.train_one_epoch``: per-step lr/wd assignment from the
 schedule tables, forward, loss, ``loss.item()`` finiteness check, backward, gradient norm / clipping,
-optimizer step, ``zero_grad``, device synchronise, meters.  Differences, by design: bf16 MFMA kernels
-need no loss scaling (the scaler keeps the reference's interface and reports ``scale == 1.0``), and the
-gradient all-reduce is the bucketed RCCL exchange of ``parallel.DataParallel``.
+optimizer step, ``zero_grad``, device synchronise, meters.  Differences, by design: loss scaling is live only
+for IEEE-half operands (``set_precision("half")``, the reference's own autocast dtype); the bfloat16 kernels need
+none and the scaler then reports ``scale == 1.0``; the gradient all-reduce is the bucketed RCCL exchange of
+``parallel.DataParallel``.
 """
 from __future__ import annotations
 
@@ -126,39 +127,80 @@ def get_grad_norm_(parameters, norm_type: float = 2.0) -> torch.Tensor:
 
 
 class NativeScalerWithGradNormCount:
-    """Interface of utils.NativeScalerWithGradNormCount (utils.py:386-412).  bf16 kernels need no loss scaling, so
-    scale == 1.0 always; backward -> (all-reduce wait) -> clip or norm -> optimizer.step."""
+    """utils.NativeScalerWithGradNormCount (utils.py:386-412): backward -> (all-reduce wait) -> unscale -> clip or norm -> optimizer
+    step -> scale update.  The reference wraps ``torch.cuda.amp.GradScaler()`` because its autocast arithmetic is float16; here loss
+    scaling is live exactly when the kernels run on IEEE-half operands (``set_precision("half")``) and a no-op (scale 1.0) for the
+    bfloat16 and precise modes, whose range is f32's.  GradScaler's defaults and rules: scale 65536, halved after a step whose
+    gradients held an inf / NaN (that step is skipped), doubled after 2000 consecutive good steps.  The scale is removed inside the
+    fused AdamW (its ``grad_scale`` operand, together with the clipping coefficient), so no extra pass touches the gradients; as in
+    GradScaler.step, "found inf" is read on the host (one scalar) before the optimizer runs."""
     state_dict_key = "amp_scaler"
 
-    def __init__(self, model: Optional[torch.nn.Module] = None):
+    def __init__(self, model: Optional[torch.nn.Module] = None, enabled: Optional[bool] = None, init_scale: float = 65536.0,
+                 growth_factor: float = 2.0, backoff_factor: float = 0.5, growth_interval: int = 2000):
         self.model = model
+        self.enabled = enabled  # None: follow the precision mode at call time
+        self.scale = float(init_scale)
+        self.growth_factor, self.backoff_factor, self.growth_interval = float(growth_factor), float(backoff_factor), int(growth_interval)
+        self.growth_tracker = 0
+        self.skipped_steps = 0
+
+    def scaling(self) -> bool:
+        return (ops.get_precision() == "half") if self.enabled is None else bool(self.enabled)
+
+    def _update_scale(self, found_inf: bool):
+        if found_inf:
+            self.scale *= self.backoff_factor
+            self.growth_tracker = 0
+            self.skipped_steps += 1
+        else:
+            self.growth_tracker += 1
+            if self.growth_tracker >= self.growth_interval:
+                self.scale *= self.growth_factor
+                self.growth_tracker = 0
 
     def __call__(self, loss, optimizer, clip_grad=None, parameters=None, create_graph=False, update_grad=True):
         dp = self.model if isinstance(self.model, DataParallel) else None
         if dp is not None:
             dp.require_sync = bool(update_grad)  # gradient accumulation: exchange only on the last micro-step
-        loss.backward(create_graph=create_graph)
+        scaling = self.scaling()
+        (loss * self.scale if scaling else loss).backward(create_graph=create_graph)
         if not update_grad:
             return None
         if dp is not None:
             dp.finish()
         from .optim import FusedAdamW
+        inv = 1.0 / self.scale if scaling else 1.0
         if isinstance(optimizer, FusedAdamW):
-            # the norm of utils.get_grad_norm_ comes out of the optimizer's own pass over the gradients; with clipping the
-            # coefficient of torch.nn.utils.clip_grad_norm_ (max_norm / (norm + 1e-6), capped at 1) stays on the device
-            if clip_grad is not None and clip_grad > 0:
+            # the norm of utils.get_grad_norm_ comes out of the optimizer's own pass over the gradients; with clipping or loss scaling
+            # the coefficient (1 / scale) * min(1, max_norm / (norm + 1e-6)) of GradScaler.unscale_ + clip_grad_norm_ stays on the device
+            clip = clip_grad is not None and clip_grad > 0
+            if clip or scaling:
                 acc = torch.zeros(1, dtype=torch.float32, device=optimizer.flat_grad.device)
-                norm = K.sumsq(optimizer.flat_grad, acc).sqrt()[0]
-                coef = torch.clamp(clip_grad / (norm + 1e-6), max=1.0).reshape(1).float()
-                optimizer.step(grad_scale=coef)
+                norm = K.sumsq(optimizer.flat_grad, acc).sqrt()[0] * inv
+                if scaling:
+                    found_inf = not bool(torch.isfinite(norm).item())
+                    self._update_scale(found_inf)
+                    if found_inf:  # GradScaler.step: the optimizer is not called for this step
+                        return norm
+                coef = (torch.clamp(clip_grad / (norm + 1e-6), max=1.0) if clip else torch.ones_like(norm)) * inv
+                optimizer.step(grad_scale=coef.reshape(1).float())
             else:
                 norm = optimizer.step(want_sumsq=True).sqrt()
             return norm
+        if scaling:  # any other optimizer: unscale in place (GradScaler.unscale_), then the reference's order
+            grads = [p.grad for p in (parameters or []) if p.grad is not None]
+            for g in grads:
+                g.mul_(inv)
+            found_inf = not all(bool(torch.isfinite(g).all()) for g in grads)
+            self._update_scale(found_inf)
+            if found_inf:
+                return torch.tensor(float("inf"))
         if clip_grad is not None and clip_grad > 0:
             assert parameters is not None
             norm = torch.nn.utils.clip_grad_norm_(parameters, clip_grad)
         else:
-            if dp is not None:
+            if dp is not None and not scaling:
                 acc = torch.zeros(1, dtype=torch.float32, device=dp.flat_grad.device)
                 norm = (K.sumsq(dp.flat_grad, acc).sqrt()[0] if dp.flat_grad.is_cuda else dp.flat_grad.norm())
             else:
@@ -168,10 +210,14 @@ class NativeScalerWithGradNormCount:
         return norm
 
     def state_dict(self):
-        return {"scale": 1.0}
+        """GradScaler.state_dict()'s keys; ``scale`` reads 1.0 while no scaling is applied (what the engines log as loss_scale)"""
+        return {"scale": self.scale if self.scaling() else 1.0, "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
+                "growth_interval": self.growth_interval, "_growth_tracker": self.growth_tracker}
 
     def load_state_dict(self, state_dict):
-        pass
+        if self.scaling() and "scale" in state_dict:
+            self.scale = float(state_dict["scale"])
+            self.growth_tracker = int(state_dict.get("_growth_tracker", 0))
 
 
 METER_NAMES = ("loss", "class_acc", "grad_norm", "lr", "min_lr", "loss_scale")

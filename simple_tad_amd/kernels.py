@@ -10,7 +10,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, TAD_BF16, TAD_F32, check
+from ._lib import EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, TAD_BF16, TAD_F16, TAD_F32, check
 
 _workspaces = {}
 
@@ -106,7 +106,56 @@ def _dt(t: torch.Tensor) -> int:
         return TAD_F32
     if t.dtype == torch.bfloat16:
         return TAD_BF16
+    if t.dtype == torch.float16:
+        return TAD_F16
     raise _lib.TadError(f"unsupported dtype {t.dtype}")
+
+
+# ----------------------------------------------------------------------------- 16-bit operand format
+# Every kernel that touches GEMM / attention operands exists for bfloat16 (tad_*) and for IEEE half (tad_*_f16) -- the same
+# kernels compiled for the other format (include/tad_mi355x.h).  A call's format is the dtype of its 16-bit tensors; functions that
+# CREATE 16-bit tensors from f32 (casts, LayerNorm, im2col ...) take it from ``dtype=`` or, by default, from the process-wide operand
+# format below (ops.set_precision selects it: "fast" -> bfloat16, "half" -> float16).
+OP16_DTYPES = (torch.bfloat16, torch.float16)
+_op16 = torch.bfloat16
+
+
+def set_operand_dtype(dtype) -> None:
+    global _op16
+    if dtype not in OP16_DTYPES:
+        raise ValueError(f"operand dtype must be torch.bfloat16 or torch.float16, got {dtype}")
+    _op16 = dtype
+
+
+def operand_dtype():
+    return _op16
+
+
+def _fn(name: str, dtype):
+    """the entry point `name` for 16-bit operands of `dtype` (its _f16 twin for torch.float16)"""
+    return getattr(_lib.load(), _lib.F16_TWINS[name] if dtype == torch.float16 else name)
+
+
+def _req16(t: torch.Tensor, name: str, like=None):
+    """a contiguous GPU tensor in one of the two 16-bit operand formats (the same one as ``like`` if given); returns its dtype"""
+    if not t.is_cuda:
+        raise _lib.TadError(f"{name}: expected a GPU tensor (the MI355X path has no CPU fallback), got {t.device}")
+    if t.dtype not in OP16_DTYPES or (like is not None and t.dtype != like):
+        raise _lib.TadError(f"{name}: expected {like if like is not None else 'bfloat16 or float16'}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _lib.TadError(f"{name}: tensor must be contiguous")
+    return t.dtype
+
+
+def _out16(out_dtype, op):
+    """output dtype of a call with 16-bit operands of format `op`: f32, or that same 16-bit format (None = the operands' own)"""
+    if out_dtype is None or out_dtype in OP16_DTYPES:
+        if out_dtype is not None and out_dtype != op:
+            raise _lib.TadError(f"16-bit output {out_dtype} does not match the operands' format {op}")
+        return op
+    if out_dtype != torch.float32:
+        raise _lib.TadError(f"unsupported output dtype {out_dtype}")
+    return out_dtype
 
 
 def _ws_key(device, stream=None):
@@ -146,22 +195,27 @@ def release_workspace(device, stream=None) -> None:
 
 
 # ----------------------------------------------------------------------------- casts
-def cast_bf16(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    _req(x, torch.float32, "cast_bf16.x")
+def cast_op16(x: torch.Tensor, out: Optional[torch.Tensor] = None, dtype=None) -> torch.Tensor:
+    """f32 -> the 16-bit operand format (``out``'s, ``dtype``, or the process-wide one)"""
+    _req(x, torch.float32, "cast_op16.x")
     if out is None:
-        out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+        out = torch.empty(x.shape, dtype=dtype or _op16, device=x.device)
+    op = _req16(out, "cast_op16.out")
     with _timed("cast", 0.0, 6.0 * x.numel()):
-        check(_lib.load().tad_cast_f32_bf16(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "tad_cast_f32_bf16")
+        check(_fn("tad_cast_f32_bf16", op)(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "tad_cast_f32_bf16")
     return out
 
 
-def transpose_cast_bf16(w: torch.Tensor) -> torch.Tensor:
-    """w [R,C] f32 -> [C,R] bf16"""
+def transpose_cast_op16(w: torch.Tensor, dtype=None) -> torch.Tensor:
+    """w [R,C] f32 -> [C,R] in the 16-bit operand format"""
     _req(w, torch.float32, "transpose_cast.w")
     R, Cc = w.shape
-    out = torch.empty((Cc, R), dtype=torch.bfloat16, device=w.device)
-    check(_lib.load().tad_transpose_cast_f32_bf16(w.data_ptr(), out.data_ptr(), R, Cc, _stream()), "tad_transpose_cast")
+    out = torch.empty((Cc, R), dtype=dtype or _op16, device=w.device)
+    check(_fn("tad_transpose_cast_f32_bf16", out.dtype)(w.data_ptr(), out.data_ptr(), R, Cc, _stream()), "tad_transpose_cast")
     return out
+
+
+cast_bf16, transpose_cast_bf16 = cast_op16, transpose_cast_op16  # (names from before the half format existed)
 
 
 def transpose_table(mats):
@@ -182,8 +236,8 @@ def transpose_table(mats):
 
 
 def transpose_bf16_batched(src, dst, table):
-    _req(src, torch.bfloat16, "transpose_batched.src")
-    _req(dst, torch.bfloat16, "transpose_batched.dst")
+    """16-bit transposes: moves bit patterns, so one entry point serves both operand formats"""
+    _req16(dst, "transpose_batched.dst", like=_req16(src, "transpose_batched.src"))
     if table.dtype != torch.int32 or not table.is_cuda or table.dim() != 2 or table.shape[1] != 8 or not table.is_contiguous():
         raise _lib.TadError("transpose_bf16_batched: table must be a contiguous int32 [n_tiles, 8] device tensor")
     with _timed("cast", 0.0, 4.0 * 4096 * table.shape[0]):
@@ -192,14 +246,17 @@ def transpose_bf16_batched(src, dst, table):
     return dst
 
 
-def scale_cast_bf16(x, gamma=None, rowscale=None, rows_per_scale=1):
+def scale_cast_op16(x, gamma=None, rowscale=None, rows_per_scale=1, dtype=None):
     _req(x, torch.float32, "scale_cast.x")
     M, N = x.shape
-    out = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    out = torch.empty((M, N), dtype=dtype or _op16, device=x.device)
     with _timed("cast", 0.0, 6.0 * M * N):
-        check(_lib.load().tad_scale_cast_bf16(x.data_ptr(), out.data_ptr(), _p(gamma), _p(rowscale), int(rows_per_scale), M, N,
-                                              _stream()), "tad_scale_cast_bf16")
+        check(_fn("tad_scale_cast_bf16", out.dtype)(x.data_ptr(), out.data_ptr(), _p(gamma), _p(rowscale), int(rows_per_scale), M, N,
+                                                    _stream()), "tad_scale_cast_bf16")
     return out
+
+
+scale_cast_bf16 = scale_cast_op16
 
 
 # ----------------------------------------------------------------------------- patch embed
@@ -213,17 +270,17 @@ def pad_k(w: torch.Tensor, ldk: int) -> torch.Tensor:
     return w if w.shape[1] == ldk else torch.nn.functional.pad(w, (0, ldk - w.shape[1]))
 
 
-def im2col_tubelets(x: torch.Tensor, tubelet: int, patch: int) -> torch.Tensor:
+def im2col_tubelets(x: torch.Tensor, tubelet: int, patch: int, dtype=None) -> torch.Tensor:
     _req(x, torch.float32, "im2col.x")
     B, Cc, T, H, W = x.shape
     ntok = (T // tubelet) * (H // patch) * (W // patch)
-    cols = torch.empty((B * ntok, patch_embed_ldk(Cc, tubelet, patch)), dtype=torch.bfloat16, device=x.device)
-    check(_lib.load().tad_im2col_tubelets(x.data_ptr(), cols.data_ptr(), B, Cc, T, H, W, tubelet, patch, _stream()),
+    cols = torch.empty((B * ntok, patch_embed_ldk(Cc, tubelet, patch)), dtype=dtype or _op16, device=x.device)
+    check(_fn("tad_im2col_tubelets", cols.dtype)(x.data_ptr(), cols.data_ptr(), B, Cc, T, H, W, tubelet, patch, _stream()),
           "tad_im2col_tubelets")
     return cols
 
 
-def im2col_tubelets_u8(frames: torch.Tensor, tubelet: int, patch: int, mean, std, bgr: bool = False, t_offset: int = 0) -> torch.Tensor:
+def im2col_tubelets_u8(frames: torch.Tensor, tubelet: int, patch: int, mean, std, bgr: bool = False, t_offset: int = 0, dtype=None) -> torch.Tensor:
     """frames [B,T,H,W,3] uint8 -> normalised bf16 patch matrix [B*N, 3*tub*p*p] (tad_im2col_tubelets_u8)"""
     import ctypes as C
     _req(frames, torch.uint8, "im2col_u8.frames")
@@ -231,19 +288,19 @@ def im2col_tubelets_u8(frames: torch.Tensor, tubelet: int, patch: int, mean, std
         raise _lib.TadError(f"im2col_u8: frames must be [B,T,H,W,3] uint8, got {tuple(frames.shape)}")
     B, T, H, W, _ = frames.shape
     ntok = (T // tubelet) * (H // patch) * (W // patch)
-    cols = torch.empty((B * ntok, 3 * tubelet * patch * patch), dtype=torch.bfloat16, device=frames.device)
+    cols = torch.empty((B * ntok, 3 * tubelet * patch * patch), dtype=dtype or _op16, device=frames.device)
     m = (C.c_float * 3)(*[float(v) for v in mean])
     s = (C.c_float * 3)(*[float(v) for v in std])
     with _timed("im2col_u8", 0.0, float(frames.numel()) + 2.0 * cols.numel()):
-        check(_lib.load().tad_im2col_tubelets_u8(frames.data_ptr(), cols.data_ptr(), B, T, H, W, tubelet, patch, m, s, int(bool(bgr)),
+        check(_fn("tad_im2col_tubelets_u8", cols.dtype)(frames.data_ptr(), cols.data_ptr(), B, T, H, W, tubelet, patch, m, s, int(bool(bgr)),
                                                  int(t_offset), _stream()), "tad_im2col_tubelets_u8")
     return cols
 
 
 def patch_embed_gemm(cols, w_bf16, bias, pos, ntok: int):
     """cols [B*ntok, K] bf16 -> out [B, ntok, D] f32 = cols w^T + bias (+ pos [ntok, D] broadcast over the batch)"""
-    _req(cols, torch.bfloat16, "patch_embed_gemm.cols")
-    _req(w_bf16, torch.bfloat16, "patch_embed_gemm.w")
+    op = _req16(cols, "patch_embed_gemm.cols")
+    _req16(w_bf16, "patch_embed_gemm.w", like=op)
     M, Kd = cols.shape
     D, K2 = w_bf16.shape
     if Kd != K2 or M % ntok:
@@ -256,7 +313,7 @@ def patch_embed_gemm(cols, w_bf16, bias, pos, ntok: int):
         _req(bias, torch.float32, "patch_embed_gemm.bias")
     out = torch.empty((M // ntok, ntok, D), dtype=torch.float32, device=cols.device)
     with _timed("patch_embed_fwd", 2.0 * M * D * Kd, 2.0 * M * Kd + 4.0 * M * D):
-        check(_lib.load().tad_patch_embed_gemm(cols.data_ptr(), w_bf16.data_ptr(), _p(bias), _p(pos), out.data_ptr(), M, ntok, D, Kd,
+        check(_fn("tad_patch_embed_gemm", op)(cols.data_ptr(), w_bf16.data_ptr(), _p(bias), _p(pos), out.data_ptr(), M, ntok, D, Kd,
                                                _stream()), "tad_patch_embed_gemm")
     return out
 
@@ -264,7 +321,7 @@ def patch_embed_gemm(cols, w_bf16, bias, pos, ntok: int):
 def patch_embed_fwd(x, w_bf16, bias, pos, tubelet: int, patch: int):
     """x [B,C,T,H,W] f32, w_bf16 [D,K], bias [D] f32|None, pos [N,D] f32|None -> (out [B,N,D] f32, cols [B*N,K] bf16)"""
     _req(x, torch.float32, "patch_embed.x")
-    _req(w_bf16, torch.bfloat16, "patch_embed.w")
+    op = _req16(w_bf16, "patch_embed.w")
     B, Cc, T, H, W = x.shape
     D, K = w_bf16.shape
     if K != patch_embed_ldk(Cc, tubelet, patch):
@@ -277,26 +334,27 @@ def patch_embed_fwd(x, w_bf16, bias, pos, tubelet: int, patch: int):
             raise _lib.TadError(f"patch_embed: pos_embed shape {tuple(pos.shape)} != {(ntok, D)}")
     if bias is not None:
         _req(bias, torch.float32, "patch_embed.bias")
-    cols = torch.empty((B * ntok, K), dtype=torch.bfloat16, device=x.device)
+    cols = torch.empty((B * ntok, K), dtype=op, device=x.device)
     out = torch.empty((B, ntok, D), dtype=torch.float32, device=x.device)
     with _timed("patch_embed_fwd", 2.0 * B * ntok * D * K, 4.0 * x.numel() + 2.0 * 2 * B * ntok * K + 4.0 * B * ntok * D):
-        check(_lib.load().tad_patch_embed_fwd(x.data_ptr(), w_bf16.data_ptr(), _p(bias), _p(pos), out.data_ptr(), cols.data_ptr(),
+        check(_fn("tad_patch_embed_fwd", op)(x.data_ptr(), w_bf16.data_ptr(), _p(bias), _p(pos), out.data_ptr(), cols.data_ptr(),
                                               B, Cc, T, H, W, tubelet, patch, D, _stream()), "tad_patch_embed_fwd")
     return out, cols
 
 
 # ----------------------------------------------------------------------------- layernorm
-def layernorm_fwd(x, gamma, beta, eps: float, out_dtype=torch.bfloat16, save_stats=True):
+def layernorm_fwd(x, gamma, beta, eps: float, out_dtype=None, save_stats=True):
+    """out_dtype: torch.float32, or a 16-bit operand format (None = the process-wide one)"""
     _req(x, torch.float32, "layernorm.x")
     _req(gamma, torch.float32, "layernorm.gamma")
     _req(beta, torch.float32, "layernorm.beta")
     D = x.shape[-1]
     rows = x.numel() // D
-    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    y = torch.empty(x.shape, dtype=out_dtype or _op16, device=x.device)
     mean = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
     with _timed("layernorm_fwd", 0.0, rows * D * (4.0 + y.element_size())):
-        check(_lib.load().tad_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _dt(y), _p(mean), _p(rstd),
+        check(_fn("tad_layernorm_fwd", y.dtype if y.dtype in OP16_DTYPES else _op16)(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _dt(y), _p(mean), _p(rstd),
                                             rows, D, float(eps), _stream()), "tad_layernorm_fwd")
     return y, mean, rstd
 
@@ -307,14 +365,15 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, want_bf16=False, want_col
     bf16 copy and the column sums (drop-path).  into=(dgamma, dbeta, colsum|None): accumulate the three reductions into these
     existing f32 tensors (gradient sinks) instead of returning fresh ones."""
     _req(x, torch.float32, "layernorm_bwd.x")
-    if dy.dtype not in (torch.float32, torch.bfloat16) or not dy.is_contiguous():
-        raise _lib.TadError("layernorm_bwd.dy: must be contiguous f32 or bf16")
+    if dy.dtype not in (torch.float32,) + OP16_DTYPES or not dy.is_contiguous():
+        raise _lib.TadError("layernorm_bwd.dy: must be contiguous f32, bf16 or f16")
+    op = dy.dtype if dy.dtype in OP16_DTYPES else _op16  # format of the 16-bit copy of dx (and of dy, if it is 16-bit)
     D = x.shape[-1]
     rows = x.numel() // D
     if dres is not None:
         _req(dres, torch.float32, "layernorm_bwd.dres")
     dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
-    dxb = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    dxb = torch.empty(x.shape, dtype=op, device=x.device) if want_bf16 else None
     if into is not None:
         dg, db, cs = into
         for t in (dg, db) + ((cs,) if want_colsum else ()):
@@ -333,18 +392,19 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, want_bf16=False, want_col
     nbytes = lib.tad_layernorm_bwd_workspace_bytes(rows, D)
     ws = workspace(nbytes, x.device)
     with _timed("layernorm_bwd", 0.0, rows * D * (dy.element_size() + 4.0 + 4.0 + (4.0 if dres is not None else 0.0) + (2.0 if want_bf16 else 0.0))):
-        check(lib.tad_layernorm_bwd(dy.data_ptr(), _dt(dy), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(dres),
+        check(_fn("tad_layernorm_bwd", op)(dy.data_ptr(), _dt(dy), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(dres),
                                     dx.data_ptr(), _p(dxb), dg.data_ptr(), db.data_ptr(), _p(cs), _p(rowscale), int(rows_per_scale),
                                     int(into is not None), ws.data_ptr(), ws.numel(), rows, D, _stream()), "tad_layernorm_bwd")
     return dx, dxb, dg, db, cs
 
 
 # ----------------------------------------------------------------------------- linear
-def linear_fwd(x, w, bias=None, out_dtype=torch.bfloat16, epilogue=EPI_BIAS, want_preact=False, residual=None, gamma=None,
+def linear_fwd(x, w, bias=None, out_dtype=None, epilogue=EPI_BIAS, want_preact=False, residual=None, gamma=None,
                rowscale=None, rows_per_scale=1):
-    """x [M,K] bf16, w [N,K] bf16 -> y [M,N]; returns (y, preact|None)"""
-    _req(x, torch.bfloat16, "linear.x")
-    _req(w, torch.bfloat16, "linear.w")
+    """x [M,K], w [N,K] (both bf16 or both f16) -> y [M,N] (out_dtype: f32, or None = the operands' format); returns (y, preact|None)"""
+    op = _req16(x, "linear.x")
+    _req16(w, "linear.w", like=op)
+    out_dtype = _out16(out_dtype, op)
     if x.shape[1] == w.shape[1] and x.shape[1] % 64:
         x, w = _pad_reduction(x, w)  # reduction length off the 64-deep K-tile (a 1176-wide MAE decoder head of a /14 model): zero columns
     M, K = x.shape
@@ -358,9 +418,9 @@ def linear_fwd(x, w, bias=None, out_dtype=torch.bfloat16, epilogue=EPI_BIAS, wan
         _req(residual, torch.float32, "linear.residual")
         assert tuple(residual.shape) == (M, N)
     y = torch.empty((M, N), dtype=out_dtype, device=x.device)
-    pre = torch.empty((M, N), dtype=torch.bfloat16, device=x.device) if want_preact else None
+    pre = torch.empty((M, N), dtype=op, device=x.device) if want_preact else None
     with _timed("gemm_nt", 2.0 * M * N * K, 2.0 * (M * K + N * K) + y.element_size() * M * N):
-        check(_lib.load().tad_linear_fwd(x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), _dt(y), epilogue, _p(pre), _p(residual),
+        check(_fn("tad_linear_fwd", op)(x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), _dt(y), epilogue, _p(pre), _p(residual),
                                          _p(gamma), _p(rowscale), int(rows_per_scale), M, N, K, _stream()), "tad_linear_fwd")
     return y, pre
 
@@ -371,7 +431,7 @@ def _pad_reduction(a, b, mult: int = 64):
     return torch.nn.functional.pad(a, (0, pad)).contiguous(), torch.nn.functional.pad(b, (0, pad)).contiguous()
 
 
-LINEAR_TUNING_DEFAULTS = dict(persistent=1, stagger_pct=0, stagger_group=1, direct_epilogue=1, split_tail=1, dynamic_tiles=0, group_m=0, variant=0)
+LINEAR_TUNING_DEFAULTS = dict(persistent=1, direct_epilogue=1, split_tail=1, group_m=0, variant=0)
 
 
 def linear_tuning(**knobs):
@@ -380,29 +440,30 @@ def linear_tuning(**knobs):
         check(_lib.load().tad_linear_tuning(k.encode(), int(v)), f"tad_linear_tuning({k}={v})")
 
 
-def linear_bwd_input(dy, wT, out_dtype=torch.bfloat16, gelu_preact=None):
-    """dy [M,N] bf16, wT [K,N] bf16 -> dx [M,K]"""
-    _req(dy, torch.bfloat16, "linear_bwd_input.dy")
-    _req(wT, torch.bfloat16, "linear_bwd_input.wT")
+def linear_bwd_input(dy, wT, out_dtype=None, gelu_preact=None):
+    """dy [M,N], wT [K,N] (both bf16 or both f16) -> dx [M,K]"""
+    op = _req16(dy, "linear_bwd_input.dy")
+    _req16(wT, "linear_bwd_input.wT", like=op)
+    out_dtype = _out16(out_dtype, op)
     if dy.shape[1] == wT.shape[1] and dy.shape[1] % 64:
         dy, wT = _pad_reduction(dy, wT)
     M, N = dy.shape
     K, N2 = wT.shape
     assert N == N2, (N, N2)
     if gelu_preact is not None:
-        _req(gelu_preact, torch.bfloat16, "linear_bwd_input.gelu_preact")
+        _req16(gelu_preact, "linear_bwd_input.gelu_preact", like=op)
         assert tuple(gelu_preact.shape) == (M, K)
     dx = torch.empty((M, K), dtype=out_dtype, device=dy.device)
     with _timed("gemm_nt", 2.0 * M * N * K, 2.0 * (M * N + N * K) + dx.element_size() * M * K):
-        check(_lib.load().tad_linear_bwd_input(dy.data_ptr(), wT.data_ptr(), dx.data_ptr(), _dt(dx), _p(gelu_preact), M, N, K, _stream()),
+        check(_fn("tad_linear_bwd_input", op)(dy.data_ptr(), wT.data_ptr(), dx.data_ptr(), _dt(dx), _p(gelu_preact), M, N, K, _stream()),
               "tad_linear_bwd_input")
     return dx
 
 
 def linear_bwd_weight(dy, x, want_bias=True, dW=None, db=None, accumulate=False):
     """dy [M,N] bf16, x [M,K] bf16 -> dW [N,K] f32, db [N] f32|None"""
-    _req(dy, torch.bfloat16, "linear_bwd_weight.dy")
-    _req(x, torch.bfloat16, "linear_bwd_weight.x")
+    op = _req16(dy, "linear_bwd_weight.dy")
+    _req16(x, "linear_bwd_weight.x", like=op)
     M, N = dy.shape
     M2, K = x.shape
     assert M == M2
@@ -414,15 +475,16 @@ def linear_bwd_weight(dy, x, want_bias=True, dW=None, db=None, accumulate=False)
     lib = _lib.load()
     ws = workspace(lib.tad_linear_bwd_weight_workspace_bytes(M, N, K), dy.device)
     with _timed("gemm_tn", 2.0 * M * N * K, 2.0 * (M * N + M * K) + 4.0 * N * K):
-        check(lib.tad_linear_bwd_weight(dy.data_ptr(), x.data_ptr(), dW.data_ptr(), _p(db) if want_bias else None, int(accumulate),
+        check(_fn("tad_linear_bwd_weight", op)(dy.data_ptr(), x.data_ptr(), dW.data_ptr(), _p(db) if want_bias else None, int(accumulate),
                                         ws.data_ptr(), ws.numel(), M, N, K, _stream()), "tad_linear_bwd_weight")
     return dW, (db if want_bias else None)
 
 
-def linear_fwd_qkv(x, w, q_bias, v_bias, out_dtype=torch.bfloat16):
+def linear_fwd_qkv(x, w, q_bias, v_bias, out_dtype=None):
     """qkv Linear with bias = cat(q_bias, 0, v_bias) (modeling_finetune.py:89-92) taken from the two parameters directly"""
-    _req(x, torch.bfloat16, "linear_qkv.x")
-    _req(w, torch.bfloat16, "linear_qkv.w")
+    op = _req16(x, "linear_qkv.x")
+    _req16(w, "linear_qkv.w", like=op)
+    out_dtype = _out16(out_dtype, op)
     M, K = x.shape
     N, K2 = w.shape
     if K != K2:
@@ -433,50 +495,53 @@ def linear_fwd_qkv(x, w, q_bias, v_bias, out_dtype=torch.bfloat16):
         assert q_bias.numel() == v_bias.numel() == N // 3
     y = torch.empty((M, N), dtype=out_dtype, device=x.device)
     with _timed("gemm_nt", 2.0 * M * N * K, 2.0 * (M * K + N * K) + y.element_size() * M * N):
-        check(_lib.load().tad_linear_fwd_qkv(x.data_ptr(), w.data_ptr(), _p(q_bias), _p(v_bias), y.data_ptr(), _dt(y), M, N, K, _stream()),
+        check(_fn("tad_linear_fwd_qkv", op)(x.data_ptr(), w.data_ptr(), _p(q_bias), _p(v_bias), y.data_ptr(), _dt(y), M, N, K, _stream()),
               "tad_linear_fwd_qkv")
     return y
 
 
 def linear_bwd_weight_qkv(dy, x, dW, dq_bias, dv_bias, accumulate):
     """weight gradient of the qkv Linear with the bias column sums split into dq_bias / dv_bias [N/3] (in place)"""
-    _req(dy, torch.bfloat16, "linear_bwd_weight_qkv.dy")
-    _req(x, torch.bfloat16, "linear_bwd_weight_qkv.x")
+    op = _req16(dy, "linear_bwd_weight_qkv.dy")
+    _req16(x, "linear_bwd_weight_qkv.x", like=op)
     M, N = dy.shape
     M2, K = x.shape
     assert M == M2 and dq_bias.numel() == dv_bias.numel() == N // 3
     lib = _lib.load()
     ws = workspace(lib.tad_linear_bwd_weight_workspace_bytes(M, N, K), dy.device)
     with _timed("gemm_tn", 2.0 * M * N * K, 2.0 * (M * N + M * K) + 4.0 * N * K):
-        check(lib.tad_linear_bwd_weight_qkv(dy.data_ptr(), x.data_ptr(), dW.data_ptr(), dq_bias.data_ptr(), dv_bias.data_ptr(), int(accumulate),
+        check(_fn("tad_linear_bwd_weight_qkv", op)(dy.data_ptr(), x.data_ptr(), dW.data_ptr(), dq_bias.data_ptr(), dv_bias.data_ptr(), int(accumulate),
                                             ws.data_ptr(), ws.numel(), M, N, K, _stream()), "tad_linear_bwd_weight_qkv")
     return dW
 
 
 def colsum_bf16(a, out=None):
-    _req(a, torch.bfloat16, "colsum.a")
+    op = _req16(a, "colsum.a")
     M, N = a.shape
     if out is None:
         out = torch.empty(N, dtype=torch.float32, device=a.device)
     lib = _lib.load()
     ws = workspace(lib.tad_colsum_workspace_bytes(M, N), a.device)
     with _timed("colsum", 0.0, 2.0 * M * N):
-        check(lib.tad_colsum_bf16(a.data_ptr(), out.data_ptr(), 0, ws.data_ptr(), ws.numel(), M, N, _stream()), "tad_colsum_bf16")
+        check(_fn("tad_colsum_bf16", op)(a.data_ptr(), out.data_ptr(), 0, ws.data_ptr(), ws.numel(), M, N, _stream()), "tad_colsum_bf16")
     return out
 
 
 # ----------------------------------------------------------------------------- attention
-def attn_fwd(qkv, B: int, N: int, H: int, scale: float, out_dtype=torch.bfloat16, want_lse=True):
-    """qkv [B*N, 3*H*64] bf16 (packed [B,N,3,H,64]) -> out [B*N, H*64], lse [B,H,N] f32"""
-    _req(qkv, torch.bfloat16, "attn.qkv")
+def attn_fwd(qkv, B: int, N: int, H: int, scale: float, out_dtype=None, want_lse=True, want_lo=False):
+    """qkv [B*N, 3*H*64] bf16 or f16 (packed [B,N,3,H,64]) -> out [B*N, H*64], lse [B,H,N] f32.  want_lo: returns (out, lse, out_lo)
+    with out_lo = what the 16-bit rounding of out dropped (for attn_bwd's delta)"""
+    op = _req16(qkv, "attn.qkv")
+    out_dtype = _out16(out_dtype, op)
     if qkv.numel() != B * N * 3 * H * 64:
         raise _lib.TadError(f"attn_fwd: qkv has {qkv.numel()} elements, expected {B * N * 3 * H * 64}")
     out = torch.empty((B * N, H * 64), dtype=out_dtype, device=qkv.device)
     lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device) if want_lse else None
-    with _timed("attn_fwd", 4.0 * B * H * N * N * 64, 2.0 * 4 * B * N * H * 64):
-        check(_lib.load().tad_attn_fwd(qkv.data_ptr(), out.data_ptr(), _dt(out), _p(lse), B, N, H, 64, float(scale), _stream()),
+    lo = torch.empty_like(out) if (want_lo and out.dtype in OP16_DTYPES) else None
+    with _timed("attn_fwd", 4.0 * B * H * N * N * 64, 2.0 * (4 + (lo is not None)) * B * N * H * 64):
+        check(_fn("tad_attn_fwd", op)(qkv.data_ptr(), out.data_ptr(), _dt(out), _p(lo), _p(lse), B, N, H, 64, float(scale), _stream()),
               "tad_attn_fwd")
-    return out, lse
+    return (out, lse, lo) if want_lo else (out, lse)
 
 
 def attn_tuning(**knobs):
@@ -485,14 +550,15 @@ def attn_tuning(**knobs):
         check(_lib.load().tad_attn_tuning(k.encode(), int(v)), f"tad_attn_tuning({k}={v})")
 
 
-def attn_bwd(qkv, out, dout, lse, B: int, N: int, H: int, scale: float):
-    for t, n in ((qkv, "qkv"), (out, "out"), (dout, "dout")):
-        _req(t, torch.bfloat16, "attn_bwd." + n)
+def attn_bwd(qkv, out, dout, lse, B: int, N: int, H: int, scale: float, out_lo=None):
+    op = _req16(qkv, "attn_bwd.qkv")
+    for t, n in ((out, "out"), (dout, "dout")) + (((out_lo, "out_lo"),) if out_lo is not None else ()):
+        _req16(t, "attn_bwd." + n, like=op)
     _req(lse, torch.float32, "attn_bwd.lse")
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((_lib.load().tad_attn_bwd_scratch_bytes(B, N, H) // 4,), dtype=torch.float32, device=qkv.device)  # -rowsum(dout*out), -lse/scale
-    with _timed("attn_bwd", 8.0 * B * H * N * N * 64, 2.0 * 8 * B * N * H * 64):
-        check(_lib.load().tad_attn_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), delta.data_ptr(),
+    with _timed("attn_bwd", 8.0 * B * H * N * N * 64, 2.0 * (8 + (out_lo is not None)) * B * N * H * 64):
+        check(_fn("tad_attn_bwd", op)(qkv.data_ptr(), out.data_ptr(), _p(out_lo), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), delta.data_ptr(),
                                        B, N, H, 64, float(scale), _stream()), "tad_attn_bwd")
     return dqkv
 
@@ -511,8 +577,8 @@ def meanpool_bwd(dy, N: int, want_bf16=False):
     _req(dy, torch.float32, "meanpool_bwd.dy")
     B, D = dy.shape
     dx = torch.empty((B, N, D), dtype=torch.float32, device=dy.device)
-    dxb = torch.empty((B, N, D), dtype=torch.bfloat16, device=dy.device) if want_bf16 else None
-    check(_lib.load().tad_meanpool_bwd(dy.data_ptr(), dx.data_ptr(), _p(dxb), B, N, D, _stream()), "tad_meanpool_bwd")
+    dxb = torch.empty((B, N, D), dtype=_op16, device=dy.device) if want_bf16 else None
+    check(_fn("tad_meanpool_bwd", _op16)(dy.data_ptr(), dx.data_ptr(), _p(dxb), B, N, D, _stream()), "tad_meanpool_bwd")
     return dx, dxb
 
 
@@ -535,8 +601,9 @@ def adamw_step(param, grad, exp_avg, exp_avg_sq, chunk_group, group_lr, group_wd
     chunks = (n + _lib.ADAMW_CHUNK - 1) // _lib.ADAMW_CHUNK
     if chunk_group.dtype != torch.uint8 or chunk_group.numel() != chunks or not chunk_group.is_cuda:
         raise _lib.TadError(f"adamw_step: chunk_group must be a uint8 device tensor with {chunks} entries")
+    op = torch.bfloat16
     if param_bf16 is not None:
-        _req(param_bf16, torch.bfloat16, "adamw.param_bf16")
+        op = _req16(param_bf16, "adamw.param_bf16")
         assert param_bf16.numel() == n
     if sumsq_partials is not None:
         _req(sumsq_partials, torch.float32, "adamw.sumsq_partials")
@@ -549,7 +616,7 @@ def adamw_step(param, grad, exp_avg, exp_avg_sq, chunk_group, group_lr, group_wd
     wd = (C.c_float * ng)(*[float(v) for v in group_wd])
     st = (C.c_int32 * ng)(*[int(v) for v in group_step])
     with _timed("adamw", 0.0, 30.0 * n):
-        check(_lib.load().tad_adamw_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), _p(param_bf16),
+        check(_fn("tad_adamw_step", op)(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), _p(param_bf16),
                                          chunk_group.data_ptr(), n, lr, wd, ng, st, float(beta1), float(beta2), float(eps),
                                          _p(grad_scale), _p(sumsq_partials), _stream()), "tad_adamw_step")
 
@@ -644,12 +711,12 @@ def device_info():
 
 
 # ----------------------------------------------------------------------------- precise mode (parity gate)
-def split_bf16x3(x, role_b: bool, stack: bool = False):
-    """x [M,K] f32 -> bf16 [M,3K] ([hi|hi|lo] or [hi|lo|hi]) or, stacked, [3M,K]"""
+def split_bf16x3(x, role_b: bool, stack: bool = False, dtype=torch.bfloat16):
+    """x [M,K] f32 -> 16-bit [M,3K] ([hi|hi|lo] or [hi|lo|hi]) or, stacked, [3M,K]; hi = op16(x), lo = op16(x - hi)"""
     _req(x, torch.float32, "split.x")
     M, K = x.shape
-    out = torch.empty((3 * M, K) if stack else (M, 3 * K), dtype=torch.bfloat16, device=x.device)
-    check(_lib.load().tad_split_bf16x3(x.data_ptr(), out.data_ptr(), M, K, int(role_b), int(stack), _stream()), "tad_split_bf16x3")
+    out = torch.empty((3 * M, K) if stack else (M, 3 * K), dtype=dtype, device=x.device)
+    check(_fn("tad_split_bf16x3", dtype)(x.data_ptr(), out.data_ptr(), M, K, int(role_b), int(stack), _stream()), "tad_split_bf16x3")
     return out
 
 

@@ -84,8 +84,8 @@ def register_mirror(p: torch.Tensor, view: torch.Tensor, transposed: bool = Fals
 
 def _mirror_of(p, transposed: bool = False):
     ent = (_mirrors_t if transposed else _mirrors).get(id(p))
-    if ent is not None and ent[0]() is p and ent[2] == p._version and ent[3] == p.data_ptr():
-        return ent[1]
+    if ent is not None and ent[0]() is p and ent[2] == p._version and ent[3] == p.data_ptr() and ent[1].dtype == K.operand_dtype():
+        return ent[1]  # (a mirror written in the other 16-bit format -- the precision mode changed after the optimizer was built -- is not served)
     return None
 
 
@@ -200,12 +200,20 @@ _PRECISION = "fast"
 
 
 def set_precision(mode: str):
-    """"fast": single-pass bf16 MFMA operands (training / throughput).  "precise": split-bf16 (hi+lo, 3 MFMA products) Linears,
-    f32 attention and f32 activations -- forward only, used for the <= 1e-3 end-to-end parity gate against the fp32 reference."""
+    """Numerics of the MFMA path.
+    "fast":    bfloat16 operands, f32 accumulation / residual stream / statistics -- the benchmarked default.
+    "half":    IEEE-half operands through the same kernels (tad_*_f16): 8x smaller operand rounding at the same MFMA rate.  This is the
+               reference's own arithmetic -- torch.cuda.amp.autocast() is float16 on CUDA (engine_for_finetuning.py:67) -- and like
+               there the backward pass needs loss scaling: engine.NativeScalerWithGradNormCount scales the loss, and the fused AdamW
+               removes the scale and skips overflowed steps (utils.py:386-412).
+    "precise": split-bf16 (hi + lo, three MFMA products) Linears, f32 attention and f32 activations -- the parity gate."""
     global _PRECISION
-    if mode not in ("fast", "precise"):
+    if mode not in ("fast", "half", "precise"):
         raise ValueError(mode)
+    if mode != _PRECISION:
+        invalidate_weight_cache()  # cached operand copies are in the old format
     _PRECISION = mode
+    K.set_operand_dtype(torch.float16 if mode == "half" else torch.bfloat16)
 
 
 def get_precision() -> str:
@@ -363,7 +371,18 @@ def head_dim_of(qkv_w, H):
     return qkv_w.shape[0] // (3 * H)
 
 
+# The attention forward also writes what the 16-bit rounding of its output dropped (77 MB per ViT-B layer at 32 clips), and the
+# backward takes delta = rowsum(dO * O) of the unrounded output: see tad_attn_bwd.  Off: delta from the rounded output, as flash-attn.
+_attn_exact_delta = True
+
+
+def set_attn_exact_delta(on: bool):
+    global _attn_exact_delta
+    _attn_exact_delta = bool(on)
+
+
 def _attn_fwd_core(xn, qkv_w, q_bias, v_bias, B, N, H, scale, train):
+    """returns qkv, attention output, (lse, rounding residual of the output | None)"""
     qb = None if q_bias is None else _f32c(q_bias.detach())
     vb = None if v_bias is None else _f32c(v_bias.detach())
     hd = head_dim_of(qkv_w, H)
@@ -372,19 +391,19 @@ def _attn_fwd_core(xn, qkv_w, q_bias, v_bias, B, N, H, scale, train):
         # the bf16 MFMA GEMMs, the scaled-dot-product core runs through the generic f32 kernels (csrc/precise.hip) on an f32 qkv.
         qkv = K.linear_fwd_qkv(xn, w_bf16(qkv_w, train), qb, vb, out_dtype=torch.float32)
         ao32, lse = K.attn_fwd_f32(qkv, B, N, H, scale, want_lse=train, d=hd)
-        return qkv, K.cast_bf16(ao32), lse
-    qkv = K.linear_fwd_qkv(xn, w_bf16(qkv_w, train), qb, vb, out_dtype=torch.bfloat16)
-    ao, lse = K.attn_fwd(qkv, B, N, H, scale, out_dtype=torch.bfloat16, want_lse=train)
-    return qkv, ao, lse
+        return qkv, K.cast_bf16(ao32), (lse, None)
+    qkv = K.linear_fwd_qkv(xn, w_bf16(qkv_w, train), qb, vb, out_dtype=None)
+    r = K.attn_fwd(qkv, B, N, H, scale, out_dtype=None, want_lse=train, want_lo=train and _attn_exact_delta)
+    return qkv, r[0], (r[1], r[2] if len(r) > 2 else None)
 
 
-def _attn_bwd_core(d_ao, xn, qkv, ao, lse, qkv_w, has_qkv_bias, B, N, H, scale, dx_dtype, qv_params=None):
+def _attn_bwd_core(d_ao, xn, qkv, ao, lse, qkv_w, has_qkv_bias, B, N, H, scale, dx_dtype, qv_params=None, ao_lo=None):
     """returns dxn, dWqkv, dq_bias, dv_bias (None for what went into gradient sinks)"""
     D = xn.shape[1]
     if qkv.dtype == torch.float32:  # generic head dim (see _attn_fwd_core)
         dqkv = K.cast_bf16(K.attn_bwd_f32(qkv, ao.float(), d_ao.float(), lse, B, N, H, scale, d=head_dim_of(qkv_w, H)))
     else:
-        dqkv = K.attn_bwd(qkv, ao, d_ao, lse, B, N, H, scale)
+        dqkv = K.attn_bwd(qkv, ao, d_ao, lse, B, N, H, scale, out_lo=ao_lo)
     dxn = K.linear_bwd_input(dqkv, wT_bf16(qkv_w, True), out_dtype=dx_dtype)
     if has_qkv_bias and qv_params is not None:
         ents = [_sink(qkv_w), _sink(qv_params[0]), _sink(qv_params[1])]
@@ -412,10 +431,10 @@ class AttentionFn(_Fn):
         B, N, C = x.shape
         train = _differentiated(ctx)
         xb = K.cast_bf16(_f32c(x).reshape(B * N, C))
-        qkv, ao, lse = _attn_fwd_core(xb, qkv_w, q_bias, v_bias, B, N, H, scale, train)
+        qkv, ao, (lse, ao_lo) = _attn_fwd_core(xb, qkv_w, q_bias, v_bias, B, N, H, scale, train)
         y, _ = K.linear_fwd(ao, w_bf16(proj_w, train), _f32c(proj_b), out_dtype=torch.float32)
         if train:
-            ctx.save_for_backward(xb, qkv, ao, lse, qkv_w, proj_w)
+            ctx.save_for_backward(xb, qkv, ao, lse, qkv_w, proj_w, ao_lo)
         ctx.meta = (B, N, H, scale, q_bias is not None, proj_b is not None)
         ctx.proj_b = proj_b
         ctx.qv = (q_bias, v_bias)
@@ -423,12 +442,12 @@ class AttentionFn(_Fn):
 
     @staticmethod
     def backward(ctx, dy):
-        xb, qkv, ao, lse, qkv_w, proj_w = ctx.saved_tensors
+        xb, qkv, ao, lse, qkv_w, proj_w, ao_lo = ctx.saved_tensors
         B, N, H, scale, has_qb, has_pb = ctx.meta
         dyb = K.cast_bf16(_f32c(dy).reshape(B * N, -1))
         d_ao = K.linear_bwd_input(dyb, wT_bf16(proj_w, True))
         dWp, dbp = linear_dw(dyb, ao, proj_w, ctx.proj_b)
-        dx, dWqkv, dqb, dvb = _attn_bwd_core(d_ao, xb, qkv, ao, lse, qkv_w, has_qb, B, N, H, scale, torch.float32, ctx.qv)
+        dx, dWqkv, dqb, dvb = _attn_bwd_core(d_ao, xb, qkv, ao, lse, qkv_w, has_qb, B, N, H, scale, torch.float32, ctx.qv, ao_lo=ao_lo)
         return dx.reshape(B, N, -1), dWqkv, dqb, dvb, dWp, dbp, None, None
 
 
@@ -441,7 +460,7 @@ class MlpFn(_Fn):
         shp = x.shape
         train = _differentiated(ctx)
         xb = K.cast_bf16(_f32c(x).reshape(-1, shp[-1]))
-        a, h = K.linear_fwd(xb, w_bf16(fc1_w, train), _f32c(fc1_b), out_dtype=torch.bfloat16, epilogue=EPI_BIAS_GELU, want_preact=train)
+        a, h = K.linear_fwd(xb, w_bf16(fc1_w, train), _f32c(fc1_b), out_dtype=None, epilogue=EPI_BIAS_GELU, want_preact=train)
         y, _ = K.linear_fwd(a, w_bf16(fc2_w, train), _f32c(fc2_b), out_dtype=torch.float32)
         if train:
             ctx.save_for_backward(xb, h, a, fc1_w, fc2_w)
@@ -527,16 +546,16 @@ class BlockFn(_Fn):
         x0 = _f32c(x).reshape(M, D)
         g1, b1, g2, b2 = _f32c(n1w), _f32c(n1b), _f32c(n2w), _f32c(n2b)
         xn1, mean1, rstd1 = K.layernorm_fwd(x0, g1, b1, eps, save_stats=train)
-        qkv, ao, lse = _attn_fwd_core(xn1, qkv_w, q_bias, v_bias, B, N, H, scale, train)
+        qkv, ao, (lse, ao_lo) = _attn_fwd_core(xn1, qkv_w, q_bias, v_bias, B, N, H, scale, train)
         x1, _ = K.linear_fwd(ao, w_bf16(proj_w, train), _f32c(proj_b), out_dtype=torch.float32, epilogue=EPI_BIAS_RESIDUAL, residual=x0,
                              rowscale=_f32c(dp1), rows_per_scale=N)
         xn2, mean2, rstd2 = K.layernorm_fwd(x1, g2, b2, eps, save_stats=train)
-        a, h = K.linear_fwd(xn2, w_bf16(fc1_w, train), _f32c(fc1_b), out_dtype=torch.bfloat16, epilogue=EPI_BIAS_GELU, want_preact=train)
+        a, h = K.linear_fwd(xn2, w_bf16(fc1_w, train), _f32c(fc1_b), out_dtype=None, epilogue=EPI_BIAS_GELU, want_preact=train)
         x2, _ = K.linear_fwd(a, w_bf16(fc2_w, train), _f32c(fc2_b), out_dtype=torch.float32, epilogue=EPI_BIAS_RESIDUAL, residual=x1,
                              rowscale=_f32c(dp2), rows_per_scale=N)
         if train:
             ctx.save_for_backward(x0, g1, mean1, rstd1, xn1, qkv, ao, lse, x1, g2, mean2, rstd2, xn2, h, a, qkv_w, proj_w, fc1_w, fc2_w,
-                                  dp1 if dp1 is None else _f32c(dp1), dp2 if dp2 is None else _f32c(dp2))
+                                  dp1 if dp1 is None else _f32c(dp1), dp2 if dp2 is None else _f32c(dp2), ao_lo)
         ctx.meta = (B, N, D, H, scale, q_bias is not None)
         ctx.biases = (proj_b, fc1_b, fc2_b)
         ctx.norms = (n1w, n1b, n2w, n2b)
@@ -549,7 +568,7 @@ class BlockFn(_Fn):
     @staticmethod
     def backward(ctx, g):
         (x0, g1, mean1, rstd1, xn1, qkv, ao, lse, x1, g2, mean2, rstd2, xn2, h, a, qkv_w, proj_w, fc1_w, fc2_w, dp1,
-         dp2) = ctx.saved_tensors
+         dp2, ao_lo) = ctx.saved_tensors
         proj_b, fc1_b, fc2_b = ctx.biases
         B, N, D, H, scale, has_qb = ctx.meta
         M = B * N
@@ -578,7 +597,7 @@ class BlockFn(_Fn):
         # ---- attention branch
         d_ao = K.linear_bwd_input(gpb, wT_bf16(proj_w, True))
         dWp, _ = linear_dw(gpb, ao, proj_w)
-        dxn1, dWqkv, dqb, dvb = _attn_bwd_core(d_ao, xn1, qkv, ao, lse, qkv_w, has_qb, B, N, H, scale, torch.bfloat16, ctx.qv)
+        dxn1, dWqkv, dqb, dvb = _attn_bwd_core(d_ao, xn1, qkv, ao, lse, qkv_w, has_qb, B, N, H, scale, None, ctx.qv, ao_lo=ao_lo)
         prev = ctx.prev_link
         if prev is not None:
             gin, ginb, dg1, dbeta1, _ = layernorm_bwd_sunk(dxn1, x0, g1, mean1, rstd1, n1w, n1b, dres=gmid, want_bf16=True, rowscale=prev.dp2,

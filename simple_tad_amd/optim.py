@@ -59,12 +59,12 @@ class FusedAdamW(torch.optim.Optimizer):
                              "exp_avg_sq": self.space.view(self.exp_avg_sq, p)}
         self.mirror = self.mirror_t = None
         if mirror:
-            self.mirror = self.space.zeros(torch.bfloat16)
-            K.cast_bf16(self.flat_param, out=self.mirror)
+            self.mirror = self.space.zeros(K.operand_dtype())  # operand copies in the 16-bit format of the precision mode in force
+            K.cast_op16(self.flat_param, out=self.mirror)
             # transposed copies W^T [K,N] (operand of the input-gradient GEMMs), same offsets, refreshed by ONE batched launch
             self._t_params = [p for p in self.space.params if p.dim() >= 2 and p.shape[0] % 8 == 0 and (p.numel() // p.shape[0]) % 8 == 0]
             if self._t_params:
-                self.mirror_t = self.space.zeros(torch.bfloat16)
+                self.mirror_t = self.space.zeros(self.mirror.dtype)
                 self._t_table = K.transpose_table([(self.space.offset[id(p)], p.shape[0], p.numel() // p.shape[0])
                                                    for p in self._t_params]).to(self.space.device)
                 K.transpose_bf16_batched(self.mirror, self.mirror_t, self._t_table)

@@ -175,21 +175,33 @@ class DataParallel(nn.Module):
             if abs(float(probe.item()) - 1.0) > 1e-6:
                 raise RuntimeError(f"DataParallel: ReduceOp.AVG of ones returned {float(probe.item())!r}")
             self._avg_in_collective = True
-        self._announced = {}  # id(param) -> version of p.grad when it was announced
-        self._sunk = set()
+        self._announced = set()
         self._works = []
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in order]
+        # A second gradient for an already announced parameter must not slip through: the kernel-side route is caught in _on_sink,
+        # the autograd route here.  Tensor hooks run BEFORE the accumulation and receive None when a Function returned no gradient
+        # for the parameter (the kernel wrote it through the sink), a tensor when autograd is about to add a real one.
+        self._hooks += [p.register_hook(self._real_grad_guard(p)) for p in order]
         self.space.install_sinks(self._on_sink)  # GPU: dW GEMMs accumulate in place and announce the parameter themselves
         self.require_sync = True
 
+    _TWICE = ("DataParallel: a parameter received a second gradient in one backward pass after its bucket had been announced (weight "
+              "tying / a module used twice per forward); build DataParallel with overlap=False for such models")
+
+    def _guarding(self) -> bool:
+        return self.world > 1 and self.require_sync and self.overlap
+
+    def _real_grad_guard(self, p):
+        def hook(g):
+            if g is not None and self._guarding() and id(p) in self._announced:
+                raise RuntimeError(self._TWICE)
+            return None
+        return hook
+
     def _on_sink(self, p):
         """called by the kernel-side gradient sinks (ops.linear_dw / layernorm_bwd_sunk) right after an in-place write into p.grad"""
-        if self.world > 1 and self.require_sync and self.overlap:
-            if id(p) in self._sunk:
-                raise RuntimeError("DataParallel: a parameter received a second gradient write in one backward pass after its bucket "
-                                   "had been announced (weight tying / a module used twice per forward); build DataParallel with "
-                                   "overlap=False for such models")
-            self._sunk.add(id(p))
+        if self._guarding() and id(p) in self._announced:
+            raise RuntimeError(self._TWICE)  # (either route came first: a sink write or an autograd accumulation)
         self._on_grad(p)
 
     # -- hook: runs on the autograd thread right after p.grad has been accumulated
@@ -201,17 +213,9 @@ class DataParallel(nn.Module):
         # layernorm_bwd_sunk, right after the in-place write) and again by autograd's post-accumulate hook, which torch also runs
         # for inputs whose Function.backward returned None.  Count it once, or a bucket would be exchanged before its last
         # gradient has been written.
-        ver = p.grad._version if p.grad is not None else -1
-        seen = self._announced.get(id(p))
-        if seen is not None:
-            # Kernel-side sink writes go through raw pointers and leave the version counter alone; an autograd accumulation
-            # (``p.grad += dW``: a tied weight whose second use took the non-sink route) bumps it.  If that happens after the bucket
-            # has been handed to the collective, the addition would be lost silently: refuse.
-            if ver != seen:
-                raise RuntimeError("DataParallel: a parameter's gradient was accumulated again after its bucket had been announced "
-                                   "(weight tying / a module used twice per forward); build DataParallel with overlap=False")
+        if id(p) in self._announced:
             return
-        self._announced[id(p)] = ver
+        self._announced.add(id(p))
         b = self.buckets[self._bucket_of[id(p)]]
         b["ready"] += 1
         if b["ready"] == b["n"]:
@@ -237,7 +241,6 @@ class DataParallel(nn.Module):
             w.wait()
         self._works.clear()
         self._announced.clear()
-        self._sunk.clear()
         if self.world == 1 or not self.require_sync:
             return
         for b in self.buckets:  # a parameter that received no gradient this step leaves its bucket incomplete
@@ -254,7 +257,6 @@ class DataParallel(nn.Module):
         receives a gradient in every step, so the trajectories agree (tests/test_optim_gpu.py covers the None case of FusedAdamW)."""
         self.flat_grad.zero_()
         self._announced.clear()
-        self._sunk.clear()
 
     def grad_sumsq_buffer(self):
         return self.flat_grad

@@ -39,18 +39,36 @@ def test_ctypes_binding_matches_header(lib_path):
     from simple_tad_amd import _lib
     assert sorted(_lib.SIGNATURES) == header_symbols()
     lib = _lib.load()
-    assert lib.tad_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.tad_abi_version() == _lib.ABI_VERSION == 3
+
+
+def test_every_operand_entry_point_has_a_half_twin(lib_path):
+    """the IEEE-half twins (tad_*_f16) mirror their bf16 entry points one-to-one: exported, bound with the same signature"""
+    from simple_tad_amd import _lib
+    lib = _lib.load()
+    assert len(_lib.F16_TWINS) == 21
+    for bf, half in _lib.F16_TWINS.items():
+        assert half.endswith("f16") or "f16x3" in half
+        assert _lib.SIGNATURES[bf] == _lib.SIGNATURES[half]
+        assert hasattr(lib, bf) and hasattr(lib, half)
+    buf = ctypes.create_string_buffer(64)
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    # the twin takes TAD_F16 (2) where its sibling takes TAD_BF16 (1) as the 16-bit output type, and refuses the other one
+    assert lib.tad_linear_fwd_f16(p, p, None, p, 1, 0, None, None, None, None, 1, 16, 16, 64, None) == -1
+    assert b"y_dtype" in lib.tad_last_error_string()
+    assert lib.tad_linear_fwd(p, p, None, p, 2, 0, None, None, None, None, 1, 16, 16, 64, None) == -1
+    assert b"y_dtype" in lib.tad_last_error_string()
 
 
 def test_host_validation_without_gpu(lib_path):
     """argument checks run before any launch, so they are testable on CPU"""
     from simple_tad_amd import _lib
     lib = _lib.load()
-    assert lib.tad_attn_fwd(None, None, 1, None, 1, 1, 1, 64, 0.125, None) == -1
+    assert lib.tad_attn_fwd(None, None, 1, None, None, 1, 1, 1, 64, 0.125, None) == -1
     assert b"null" in lib.tad_last_error_string()
     buf = ctypes.create_string_buffer(64)
     p = ctypes.cast(buf, ctypes.c_void_p)
-    assert lib.tad_attn_fwd(p, p, 1, None, 1, 8, 1, 32, 0.125, None) == -1  # head_dim != 64
+    assert lib.tad_attn_fwd(p, p, 1, None, None, 1, 8, 1, 32, 0.125, None) == -1  # head_dim != 64
     assert b"head_dim" in lib.tad_last_error_string()
     assert lib.tad_linear_fwd(p, p, None, p, 1, 0, None, None, None, None, 1, 16, 16, 60, None) == -1  # K % 64
     assert b"K=60" in lib.tad_last_error_string()

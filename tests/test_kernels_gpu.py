@@ -346,7 +346,7 @@ def test_attention_f32_fwd_bwd(K, B, N, H, d):
     check(dqkv.reshape(B, N, -1), ref_dqkv, tol=1e-5, what="attn f32 bwd")
 
 
-# ---- persistent (one workgroup per CU, staggered starts) vs one-workgroup-per-tile scheduling of the Linear GEMMs.
+# ---- persistent (one workgroup per CU walks a tile list) vs one-workgroup-per-tile scheduling of the Linear GEMMs.
 # Neither scheduling (incl. running a Linear as two launches over row ranges) nor the epilogue's store path (straight from the MFMA layout / transposed through the LDS) may change a
 # single bit: same tiles, same K order, same epilogue arithmetic.  Shapes are large enough
 # for the persistent path (>= 2 tiles per CU) and include ragged M / N edges.
@@ -378,11 +378,9 @@ def test_linear_persistent_schedule_is_bit_identical(K, M, N, Kd, mode):
 
     outs = {}
     try:
-        base = dict(persistent=0, stagger_pct=0, stagger_group=1, direct_epilogue=0, split_tail=0, dynamic_tiles=0)
-        for name, cfg in [("tile", {}), ("tile_direct", dict(direct_epilogue=2)), ("persist", dict(persistent=1, stagger_pct=100)),
-                          ("persist_grouped", dict(persistent=1, stagger_pct=50, stagger_group=8, direct_epilogue=2)),
+        base = dict(persistent=0, direct_epilogue=0, split_tail=0)
+        for name, cfg in [("tile", {}), ("tile_direct", dict(direct_epilogue=2)), ("persist", dict(persistent=1)),
                           ("persist_direct", dict(persistent=1, direct_epilogue=2)), ("split", dict(persistent=1, split_tail=2)),
-                          ("persist_dynamic", dict(persistent=1, dynamic_tiles=1)), ("split_dynamic", dict(persistent=1, split_tail=2, dynamic_tiles=1)),
                           ("default", K.LINEAR_TUNING_DEFAULTS)]:
             K.linear_tuning(**{**base, **cfg})
             y, pre = run()
@@ -391,7 +389,7 @@ def test_linear_persistent_schedule_is_bit_identical(K, M, N, Kd, mode):
     finally:
         K.linear_tuning(**K.LINEAR_TUNING_DEFAULTS)
     y0, p0 = outs["tile"]
-    for name in ("tile_direct", "persist", "persist_grouped", "persist_direct", "split", "persist_dynamic", "split_dynamic", "default"):
+    for name in ("tile_direct", "persist", "persist_direct", "split", "default"):
         y1, p1 = outs[name]
         assert torch.equal(y0, y1), f"{name}: output differs from per-tile scheduling"
         if p0 is not None:
@@ -431,23 +429,3 @@ def test_linear_taller_than_the_32bit_epilogue_offsets(K):
     # bf16 output of the same shape stays ONE launch range (1.1 GB < 2 GiB with 2-byte elements): exercised for the cap arithmetic
     yb, _ = K.linear_fwd(x, w, b, out_dtype=torch.bfloat16)
     assert torch.equal(yb[-300:].float(), K.linear_fwd(x[-300:].contiguous(), w, b, out_dtype=torch.bfloat16)[0].float())
-
-
-def test_attention_schedule_variants_are_bit_identical(K):
-    """The scheduling variants of the attention kernels kept as tuning options (tad_attn_tuning: where the next tile's LDS-DMA pieces are
-    issued, a three-deep tile ring in the backward kernels, 64 keys per wave at one wave per SIMD in dK/dV) compute the same arithmetic
-    in the same order: outputs and gradients equal the default kernels' bit for bit, ragged N and dead waves included."""
-    B, N, H = 2, 1568, 2
-    qkv = bf(R.tensor_for("attv.qkv", (B * N, 3 * H * 64))).bfloat16().cuda()
-    dout = bf(R.tensor_for("attv.do", (B * N, H * 64))).bfloat16().cuda()
-    try:
-        K.attn_tuning(dma_mode=0, bwd_stages=2, dkv_keys=32)
-        out0, lse0 = K.attn_fwd(qkv, B, N, H, 0.125)
-        dq0 = K.attn_bwd(qkv, out0, dout, lse0, B, N, H, 0.125)
-        for cfg in (dict(dma_mode=1), dict(bwd_stages=3), dict(dkv_keys=64)):
-            K.attn_tuning(**{**dict(dma_mode=0, bwd_stages=2, dkv_keys=32), **cfg})
-            out, lse = K.attn_fwd(qkv, B, N, H, 0.125)
-            dq = K.attn_bwd(qkv, out0, dout, lse0, B, N, H, 0.125)
-            assert torch.equal(out, out0) and torch.equal(lse, lse0) and torch.equal(dq, dq0), cfg
-    finally:
-        K.attn_tuning(dma_mode=0, bwd_stages=2, dkv_keys=32)
