@@ -14,12 +14,25 @@ Rank 0 prints ONE JSON line.
 `python -m torch.distributed.run` BEFORE anything touches the GPU (the parent only waits for the launcher and exits with its
 code; it never initialises HIP, so no process that holds the GPU is ever replaced).
 
-Fields beside the contract's: `roofline` (dominant kernel gemm_nt: HIP events around every 13th Linear call INSIDE the timed
-region), `roofline_all` (every kernel class, from 3 extra un-timed steps with events around every launch), `fwd_only`
-(BASELINE configs[1], timed after the training region), `precise` (the 1e-3-parity mode: throughput of the same step and
-the logits deviation of both modes against the reference's golden logits), `cpu_baseline` (the oracle on the host cores, last).
+Every performance figure in the line is measured by THIS run.  Fields beside the contract's:
+  roofline       dominant kernel gemm_nt: HIP events around every 13th Linear call INSIDE the timed region.  `traffic` (HBM bytes per
+                 launch from rocprofv3 PMC passes) cannot be taken inside a run: it comes from the committed profile of this same
+                 command and is reported only while the kernel sources still hash to what that profile was taken on, else null.
+  from_profiles  what was read from profiles/ (file, source hash match): traffic, the clock held inside the MFMA loops.
+  roofline_all   every kernel class, from 3 extra un-timed steps with events around every launch.
+  engine_loop    the same step driven by engine.train_one_epoch, i.e. WITH the reference loop's two host syncs per step
+                 (engine_for_finetuning.py:71 loss.item(), :102 torch.cuda.synchronize()).
+  fwd_only       BASELINE configs[1], timed after the training region.
+  half           the step on IEEE-half operands with GradScaler-style loss scaling (the reference's own autocast arithmetic):
+                 throughput, and forward AND backward deviation from the reference's fp64 run (golden G11) beside the bf16 mode's.
+  precise        split-operand Linears + f32 attention: throughput and the same deviation figures.
+  mae_pretrain   BASELINE configs[4] on one GPU: ViT-L/16 encoder on 392 visible tokens + 12-block decoder, tube mask 0.75.
+  torch_route    the reference's operator route as stock torch modules on this GPU (calibration).
+  cpu_baseline   the oracle on the host cores, last.
+  collective     (N > 1) backend, buckets, exposed all-reduce time, per-bucket time, per-rank step times.
 """
 import argparse
+import hashlib
 import json
 import os
 import socket
@@ -30,8 +43,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_BF16_TFLOPS = 2516.6   # 256 CU x 2.4 GHz x 4096 FLOP/clk/CU (MI355X_MICROARCH.md: ~2.5 PF dense)
+PEAK_BF16_TFLOPS = 2516.6   # 256 CU x 2.4 GHz x 4096 FLOP/clk/CU (MI355X_MICROARCH.md: ~2.5 PF dense); the half MFMA rate is the same
 PEAK_HBM_GBS = 8000.0
+NOMINAL_CLOCK_MHZ = 2400.0
 
 
 def parse_args():
@@ -45,12 +59,16 @@ def parse_args():
     ap.add_argument("--model", default="vit_base_patch16_224")
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--mode", default="train", choices=["train", "fwd"])
+    ap.add_argument("--precision", default="fast", choices=["fast", "half"], help="operand format of the TIMED region (default: bf16 = the "
+                    "headline; half is reported in the `half` object of the default run anyway)")
     ap.add_argument("--drop-path", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-all-cores", action="store_true", help="also time the CPU baseline on ALL host cores (measured on the 256-core "
-                    "box of this pool: 198.9 s per batch of 2 against 4.3 s on 32 cores -- oversubscription; off by default)")
+    ap.add_argument("--cpu-all-cores", action="store_true", help="also time the CPU baseline on ALL host cores (a 256-thread pool on a "
+                    "batch of 2 oversubscribes: minutes per batch on the pool's 256-core host; off by default)")
     ap.add_argument("--no-live-profile", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip roofline_all / fwd_only / precise (N=1 extras after the timed region)")
+    ap.add_argument("--no-extras", action="store_true", help="skip everything after the timed region except cpu_baseline")
+    ap.add_argument("--only-extras", default="", help="comma list out of roofline_all,engine_loop,fwd_only,half,precise,mae_pretrain,torch_route "
+                                                      "(default: all)")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel-class table to stderr")
     ap.add_argument("--dry-run", action="store_true", help="launch plumbing only: rendezvous, one all-reduce, rank 0 prints the world size "
                                                           "(no GPU work; runs over gloo on a CPU-only host -- tests/test_bench_launch.py)")
@@ -82,9 +100,36 @@ def flops_per_clip(N, D, L, n_cls=2, k_patch=1536):
     return f_patch + L * f_blk + 2 * D * n_cls, 3 * L * f_blk + 2 * f_patch + 6 * D * n_cls
 
 
+def csrc_sha16():
+    """hash of the kernel sources + C header: ties a figure read from profiles/ to the code it was measured on"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "simple_tad_amd", "csrc")
+    for f in sorted(os.listdir(d)) + [os.path.join("..", "..", "include", "tad_mi355x.h")]:
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def read_profiles():
+    """Figures that need a profiler or an ablation build (HBM traffic per gemm_nt launch from rocprofv3 PMC passes; the clock held inside
+    the MFMA loops from the in-kernel stamps): read from the latest committed profile, each with the source hash it was taken on."""
+    import glob
+    out = {"csrc_sha16": csrc_sha16()}
+    for key, pat, field in (("gemm_nt_traffic_bytes_per_launch", "r*_summary.json", "gemm_nt_traffic_bytes_per_launch"),
+                            ("held_clock_mhz", "r*_clock.json", "held_clock_mhz")):
+        try:
+            latest = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))[-1]
+            d = json.load(open(latest))
+            out[key] = {"value": d.get(field), "file": os.path.relpath(latest, ROOT), "measured_on_csrc_sha16": d.get("csrc_sha16"),
+                        "current": d.get("csrc_sha16") == out["csrc_sha16"]}
+        except Exception as e:  # noqa: BLE001
+            out[key] = {"value": None, "error": repr(e)}
+    return out
+
+
 def cpu_baseline(state_dict, frames, reps=3, all_cores=False):
     """Oracle (pure-torch CPU restatement of the reference path) fwd+bwd, B=2, fp32: 1 warm-up + `reps` timed passes on at most 32
-    host cores (a 256-thread pool on this small batch oversubscribes) and, when the host has more, the same on ALL cores."""
+    host cores (a larger pool on this small batch oversubscribes) and, with --cpu-all-cores, the same on ALL cores."""
     import torch
     from oracle import vit_oracle as O
     P = {k: v.detach().float().cpu().requires_grad_() for k, v in state_dict.items()}
@@ -116,15 +161,67 @@ def cpu_baseline(state_dict, frames, reps=3, all_cores=False):
     out = {"value": round(2 / dt, 4), "unit": "clips/sec", "cores": n32, "kind": "port", "host_cores": ncpu, "reps": r,
            "sample": f"ViT-B/16 16x224x224 fwd+bwd (CE loss), batch 2, fp32, {r} reps after 1 warm-up, oracle/vit_oracle.py "
                      f"on {n32} of {ncpu} host cores; {dt:.2f} s per batch"}
-    if ncpu > n32:
-        if all_cores:
-            r2, dt2 = timed(ncpu)
-            out["all_cores"] = {"value": round(2 / dt2, 4), "cores": ncpu, "reps": r2, "s_per_batch": round(dt2, 2)}
-        else:
-            out["all_cores"] = {"value": 0.0101, "cores": 256, "s_per_batch": 198.92, "measured": "round 2, same workload, torch.set_num_threads(256) "
-                                "on the pool's 256-core host (gpurun_out/r02a/bench.log): the thread pool oversubscribes a batch of 2; "
-                                "re-measure with --cpu-all-cores"}
+    if ncpu > n32 and all_cores:
+        r2, dt2 = timed(ncpu)
+        out["all_cores"] = {"value": round(2 / dt2, 4), "cores": ncpu, "reps": r2, "s_per_batch": round(dt2, 2)}
     return out
+
+
+# --------------------------------------------------------------------------------------------------------------- parity vs golden G11
+def parity_vs_golden(T, dev, modes, loss_scale=4096.0):
+    """Forward AND backward deviation of each precision mode from the reference's own fp64 run of ViT-B/16 16x224x224, B = 2 (fixture
+    data only: the reference never travels to the GPU box).  Gradients, over all 152 tensors: `rms` = error of the stored 256-element
+    slice relative to the tensor's RMS, `sqsum` = error of the tensor's sum of squares, `slice` = relative error of the slice itself
+    (the first row of a qkv weight is a q row, whose gradient at seeded init is ~100x below the tensor's RMS and ill-conditioned)."""
+    import numpy as np
+    import torch
+    import torch.nn.functional as F
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import golden_recipe as R
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g11_vitb_grads.npz"), allow_pickle=False)
+
+    def rel(a, b):
+        a, b = a.double().cpu(), torch.from_numpy(np.asarray(b)).double()
+        return ((a - b).norm() / b.norm()).item()
+
+    res = {}
+    for mode in modes:
+        torch.manual_seed(0)
+        m = T.create_model("vit_base_patch16_224", pretrained=False, num_classes=2, all_frames=16, tubelet_size=2, final_reduction="fc_norm",
+                           use_flash_attn=False, init_scale=1.0, drop_path_rate=0.0)
+        R.rerandomize_1d(m)
+        torch.manual_seed(1)
+        xs = torch.randn(2, 3, 16, 224, 224).to(dev)
+        m = m.to(dev).train()
+        T.set_precision(mode)
+        try:
+            scale = loss_scale if mode == "half" else 1.0
+            f = m.forward_features(xs)
+            lg = m.head(f)
+            loss = F.cross_entropy(lg, torch.tensor([0, 1], device=dev))
+            (loss * scale).backward()
+            torch.cuda.synchronize()
+        finally:
+            T.set_precision("fast")
+        e_rms, e_sq, e_sl = [], [], []
+        for k, p in m.named_parameters():
+            gr = (p.grad / scale).double().cpu()
+            head = torch.from_numpy(g["grad." + k + ".head"]).double()
+            sq = float(g["grad." + k + ".sqsum"])
+            d = (gr.flatten()[: head.numel()] - head).norm()
+            e_sl.append((d / head.norm().clamp_min(1e-300)).item())
+            e_rms.append((d / (head.numel() ** 0.5 * max((sq / gr.numel()) ** 0.5, 1e-300))).item())
+            e_sq.append(abs((gr ** 2).sum().item() - sq) / max(sq, 1e-300))
+        r3 = lambda v: float(f"{v:.3e}")  # noqa: E731
+        res[mode] = {"features_rel_l2": r3(rel(f.detach(), g["features"])), "logits_rel_l2": r3(rel(lg.detach(), g["logits"])),
+                     "loss_abs": r3(abs(loss.item() - float(g["loss"]))),
+                     "grad_rms": {"median": r3(float(np.median(e_rms))), "worst": r3(max(e_rms))},
+                     "grad_sqsum": {"median": r3(float(np.median(e_sq))), "worst": r3(max(e_sq))},
+                     "grad_slice": {"median": r3(float(np.median(e_sl))), "worst": r3(max(e_sl)), "tensors_over_1e-3": int(sum(v > 1e-3 for v in e_sl)),
+                                    "tensors": len(e_sl)}}
+        del m
+        torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -163,6 +260,7 @@ def main():
     dev = torch.device("cuda", local)
     _lib.load()
     info = K.device_info()
+    T.set_precision(args.precision)
 
     torch.manual_seed(0)  # identical init on every rank
     model = T.create_model(args.model, pretrained=False, num_classes=2, all_frames=args.frames, tubelet_size=2,
@@ -181,13 +279,15 @@ def main():
         B = args.global_batch // world
     x = torch.randn(B, 3, args.frames, 224, 224, device=dev)
     y = torch.randint(0, 2, (B,), device=dev)
-    total_steps = args.steps + args.warmup + 64  # (+ the un-timed extra steps after the region)
+    total_steps = args.steps + args.warmup + 128  # (+ the un-timed extra steps after the region)
     lr_sched = E.cosine_scheduler(5e-4 * B * world / 256, 1e-6, 1, max(total_steps, 2), warmup_epochs=0)
 
     dp = opt = scaler = None
     if args.mode == "train":
         model.train()
         dp = DataParallel(model, bucket_mb=64.0)
+        if distributed:
+            dp.enable_timing()
         opt = E.create_optimizer(dp, lr=1e-3, weight_decay=0.05, layer_decay=0.75)
         scaler = E.NativeScalerWithGradNormCount(dp)
         crit = torch.nn.CrossEntropyLoss()
@@ -223,16 +323,18 @@ def main():
                 dp.zero_grad()
                 return loss
 
+            # warm-up AND capture on one stream: kernels.workspace is per (device, stream), so the scratch buffers the graph bakes in are
+            # allocated by the warm-up, outside the graph's private pool; they are held for as long as the graph lives
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(2):
                     eager_body()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
+            side.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, stream=side):
                 static_loss = eager_body()
+            graph_scratch = K.workspace_refs(dev, side)  # noqa: F841  (kept alive with the graph)
 
             def step(it):  # noqa: F811
                 for g, sc in zip(opt.param_groups, scales):
@@ -253,6 +355,8 @@ def main():
 
     for it in range(args.warmup):
         step(it)
+    if dp is not None and dp._timing is not None:
+        dp._timing["steps"].clear()  # (the warm-up steps' records)
     prof = None
     if rank == 0 and not args.no_live_profile:
         prof = K.LaunchProfiler(only=["gemm_nt"], stride=13)
@@ -261,19 +365,28 @@ def main():
     t0 = time.perf_counter()
     for it in range(args.steps):
         last = step(args.warmup + it)
+    torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0  # this rank's own time, before it waits for the others
     barrier()
     dt = time.perf_counter() - t0
     K.set_profiler(None)
+    collective = None
     if distributed:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = t.item()
-    loss_val = float(last.float().mean().item()) if args.mode == "train" else float("nan")
-    collective = None
-    if distributed:
+        own = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        torch.distributed.all_gather(own, torch.tensor([dt_own], dtype=torch.float64, device=dev))
+        per_rank = [1e3 * float(o.item()) / args.steps for o in own]
         collective = {"backend": torch.distributed.get_backend(), "world_size": torch.distributed.get_world_size(),
                       "allreduce_bytes_per_step": 4 * int(dp.flat_grad.numel()) if dp is not None else 0,
-                      "buckets": len(dp.buckets) if dp is not None else 0}
+                      "buckets": len(dp.buckets) if dp is not None else 0,
+                      "rank_ms_per_step": {"min": round(min(per_rank), 3), "max": round(max(per_rank), 3), "all": [round(v, 3) for v in per_rank]},
+                      "linear_schedule": "per-tile grids (DataParallel switches the persistent Linear kernels off at world > 1)"}
+        ts = dp.timing_summary() if dp is not None else None
+        if ts is not None:
+            collective.update(ts)
+    loss_val = float(last.float().mean().item()) if args.mode == "train" else float("nan")
 
     if rank != 0:
         if distributed:
@@ -288,12 +401,13 @@ def main():
         "value": round(clips_per_s, 2), "unit": "clips/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak",
         "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic",
+        "dtype": "bf16" if args.precision == "fast" else "f16", "data": "synthetic",
         "config": {"workload": f"{args.model} {args.frames}x224x224, {B} clips/GPU, " +
                                ("fwd+bwd+AdamW fine-tune step with CE loss on synthetic labels (BASELINE configs[2]/[3])"
                                 if args.mode == "train" else "forward only (BASELINE configs[1])"),
                    "global_batch": B * world, "per_gpu_batch": B, "tokens_per_clip": ntok, "parallelism": f"dp{world}",
-                   "drop_path": args.drop_path if args.mode == "train" else 0.0, "residual_stream": "f32", "operands": "bf16",
+                   "drop_path": args.drop_path if args.mode == "train" else 0.0, "residual_stream": "f32",
+                   "operands": "bf16" if args.precision == "fast" else "f16 + loss scaling",
                    "algorithmic_gflop_per_clip": round(fl / 1e9, 2), "parameters": n_params},
         "frac_of_bf16_mfma_roofline": round(clips_per_s * fl / world / (PEAK_BF16_TFLOPS * 1e12), 4),
         "loss": loss_val,
@@ -301,32 +415,23 @@ def main():
     }
     if collective is not None:
         out["collective"] = collective
-    held = None
-    try:  # the clock the chip holds inside the MFMA loops (profiles/rNN_clock.json, tools/exp_clock.py): fractions against it as well
-        import glob
-        latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_clock.json")))[-1]
-        held = json.load(open(latest)).get("held_clock_mhz")
-        if held:
-            out["frac_of_roofline_at_held_clock"] = round(out["frac_of_bf16_mfma_roofline"] * 2400.0 / float(held), 4)
-            out["held_clock_mhz"] = {"value": held, "source": os.path.relpath(latest, ROOT)}
-    except Exception:  # noqa: BLE001
-        held = None
+    fp = read_profiles()
+    out["from_profiles"] = fp
+    held = fp.get("held_clock_mhz", {})
+    if held.get("value") and held.get("current"):
+        out["from_profiles"]["frac_of_roofline_at_held_clock"] = round(out["frac_of_bf16_mfma_roofline"] * NOMINAL_CLOCK_MHZ / float(held["value"]), 4)
     if prof is not None:
         summ = prof.summary()
         g = summ.get("gemm_nt")
         if g and g["ms"] > 0:
             ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
-            traffic, src = None, None  # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/)
-            try:
-                import glob
-                latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))[-1]
-                traffic = round(json.load(open(latest)).get("gemm_nt_traffic_bytes_per_launch"))
-                src = os.path.relpath(latest, ROOT)
-            except Exception:  # noqa: BLE001
-                traffic = None
-            out["roofline"] = {"kernel": "gemm_nt_kernel (bf16 MFMA GEMM, all Linear fwd / input-grad launches)", "bound": "mfma",
+            tr = fp.get("gemm_nt_traffic_bytes_per_launch", {})
+            out["roofline"] = {"kernel": "gemm_nt_kernel (16-bit-operand MFMA GEMM, all Linear fwd / input-grad launches)", "bound": "mfma",
                                "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
+                               "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                               "traffic": round(tr["value"]) if (tr.get("value") and tr.get("current")) else None,
+                               "traffic_source": (tr.get("file") if tr.get("current") else
+                                                  "none: the committed PMC profile was taken on other kernel sources (from_profiles)"),
                                # a Linear call is one kernel launch, or two under a split plan: times and flops are per KERNEL
                                # launch, as rocprofv3 counts them
                                "calls": prof.seen.get("gemm_nt", g["calls"]), "sampled_calls": g["calls"], "sampled_launches": g["launches"],
@@ -334,11 +439,41 @@ def main():
                                "avg_launch_us": round(1e3 * g["ms"] / g["launches"], 2),
                                "gflop_per_launch": round(g["flops"] / g["launches"] / 1e9, 2)}
 
-    extras = world == 1 and not args.no_extras and args.mode == "train" and args.graph != 1
+    want = set(filter(None, args.only_extras.split(","))) or {"roofline_all", "engine_loop", "fwd_only", "half", "precise", "mae_pretrain", "torch_route"}
+    extras = world == 1 and not args.no_extras and args.mode == "train" and args.graph != 1 and args.precision == "fast"
     it_next = args.warmup + args.steps
-    if extras:
-        # ---- roofline_all: every kernel class, HIP events around every launch of 3 extra steps (the events add ~20 us of queue time per
-        # launch, so these steps are NOT part of `value`)
+
+    def timed_steps(n_warm, n):
+        nonlocal it_next
+        for _ in range(n_warm):
+            step(it_next)
+            it_next += 1
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n):
+            step(it_next)
+            it_next += 1
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t1) / n
+
+    def class_table(summ, nsteps, batch):
+        ra = {}
+        for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
+            if v["ms"] <= 0:
+                continue
+            ent = {"launches_per_step": round(v["launches"] / nsteps, 1), "ms_per_step": round(v["ms"] / nsteps, 3)}
+            if v["flops"] > 0:
+                tf = v["flops"] / (v["ms"] * 1e-3) / 1e12
+                ent.update({"bound": "mfma", "achieved": round(tf, 1), "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4)})
+            else:
+                gbs = v["bytes"] / (v["ms"] * 1e-3) / 1e9
+                ent.update({"bound": "hbm", "achieved": round(gbs, 1), "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)})
+            ra[k] = ent
+        return ra
+
+    if extras and "roofline_all" in want:
+        # ---- every kernel class, HIP events around every launch of 3 extra steps (the events add ~20 us of queue time per launch, so
+        # these steps are NOT part of `value`)
         try:
             pall = K.LaunchProfiler(only=None, stride=1)
             K.set_profiler(pall)
@@ -347,19 +482,7 @@ def main():
                 step(it_next)
                 it_next += 1
             K.set_profiler(None)
-            summ = pall.summary()
-            ra = {}
-            for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
-                if v["ms"] <= 0:
-                    continue
-                ent = {"launches_per_step": round(v["launches"] / nrf, 1), "ms_per_step": round(v["ms"] / nrf, 3)}
-                if v["flops"] > 0:
-                    tf = v["flops"] / (v["ms"] * 1e-3) / 1e12
-                    ent.update({"bound": "mfma", "achieved": round(tf, 1), "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4)})
-                else:
-                    gbs = v["bytes"] / (v["ms"] * 1e-3) / 1e9
-                    ent.update({"bound": "hbm", "achieved": round(gbs, 1), "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)})
-                ra[k] = ent
+            ra = class_table(pall.summary(), nrf, B)
             out["roofline_all"] = ra
             if "adamw" in ra:  # the step with the AdamW update included (`value`) and excluded
                 ms_wo = out["ms_per_step"] - ra["adamw"]["ms_per_step"]
@@ -372,7 +495,30 @@ def main():
             K.set_profiler(None)
             out["roofline_all"] = {"error": repr(e)}
 
-        # ---- fwd_only: BASELINE configs[1] (eval, no_grad, same batch), timed after the training region
+    if extras and "engine_loop" in want:
+        # ---- the reference's loop shape: engine.train_one_epoch = per-step schedule assignment, loss.item() (host sync), backward,
+        # optimizer, zero_grad, torch.cuda.synchronize() (host sync), meters -- row (a)12 of the hot-path table
+        try:
+            nel = 2 + args.steps
+            loader = [(x, y)] * nel
+            t1 = [None]
+
+            def log(epoch, i, stats):
+                if i == 1:  # two warm-up iterations
+                    torch.cuda.synchronize()
+                    t1[0] = time.perf_counter()
+            E.train_one_epoch(dp, crit, loader, opt, dev, 0, scaler, max_norm=0, start_steps=it_next,
+                              lr_schedule_values=[v for v in lr_sched], num_training_steps_per_epoch=nel, log=log)
+            torch.cuda.synchronize()
+            dte = (time.perf_counter() - t1[0]) / (nel - 2)
+            it_next += nel
+            out["engine_loop"] = {"value": round(B / dte, 2), "unit": "clips/sec", "ms_per_step": round(1e3 * dte, 3), "steps": nel - 2,
+                                  "host_syncs_per_step": 2, "through": "simple_tad_amd.engine.train_one_epoch (engine_for_finetuning.py:24-140)"}
+        except Exception as e:  # noqa: BLE001
+            out["engine_loop"] = {"error": repr(e)}
+
+    if extras and "fwd_only" in want:
+        # ---- BASELINE configs[1] (eval, no_grad, same batch), timed after the training region
         try:
             model.eval()
             with torch.no_grad():
@@ -393,9 +539,47 @@ def main():
         except Exception as e:  # noqa: BLE001
             out["fwd_only"] = {"error": repr(e)}
 
-        # ---- precise: the mode that meets north_star's 1e-3 tolerance (split-bf16 Linears, f32 attention / activations): throughput
-        # of the same training step, and the deviation of BOTH modes from the reference's golden logits (tests/golden/g11, the real
-        # reference model in fp64 on ViT-B/16 16x224x224, B = 2) so that the headline number is tied to a measured error
+    # ---- the other precision modes: throughput of the SAME training step, and forward + backward deviation of every mode from the
+    # reference's fp64 run (tests/golden/g11: the real reference model on ViT-B/16 16x224x224, B = 2)
+    par = None
+    if extras and ("half" in want or "precise" in want):
+        try:
+            par = parity_vs_golden(T, dev, ["fast"] + [m for m in ("half", "precise") if m in want])
+        except Exception as e:  # noqa: BLE001
+            par = {"error": repr(e)}
+    against = "tests/golden/g11_vitb_grads.npz: reference modeling_finetune.vit_base_patch16_224, fp64 fwd + CE loss + bwd, B=2, seed-0 init"
+    if extras and "half" in want:
+        try:
+            # (the fused optimizer's operand mirrors are bf16: in half mode they are not served and the forward re-casts the weights,
+            #  which a half-mode optimizer built from the start avoids -- tools/exp_precision.py measures that configuration)
+            from simple_tad_amd.optim import FusedAdamW
+            T.set_precision("half")
+            try:
+                opt_h = E.create_optimizer(dp, lr=1e-3, weight_decay=0.05, layer_decay=0.75)
+                assert isinstance(opt_h, FusedAdamW)
+                sc_h = E.NativeScalerWithGradNormCount(dp)
+                opt_keep, sc_keep = opt, scaler
+                opt, scaler = opt_h, sc_h
+                try:
+                    dth = timed_steps(3, 10)
+                finally:
+                    opt, scaler = opt_keep, sc_keep
+                hs = {"value": round(B / dth, 2), "unit": "clips/sec", "ms_per_step": round(1e3 * dth, 3), "steps": 10, "warmup": 3,
+                      "frac_of_f16_mfma_roofline": round(B / dth * f_fb / (PEAK_BF16_TFLOPS * 1e12), 4), "operands": "IEEE half, f32 accumulation",
+                      "loss_scale": sc_h.state_dict()["scale"], "skipped_steps": sc_h.skipped_steps,
+                      "vs_value": round((B / dth) / out["value"], 4)}
+            finally:
+                T.set_precision("fast")
+                from simple_tad_amd import ops as _ops
+                _ops.invalidate_weight_cache()
+                opt.refresh_mirrors()  # (the half-mode optimizer moved the parameters: the bf16 operand copies are re-derived)
+            out["half"] = hs
+        except Exception as e:  # noqa: BLE001
+            T.set_precision("fast")
+            out["half"] = {"error": repr(e)}
+        if isinstance(par, dict) and "half" in par:
+            out["half"].update({"deviation": par["half"], "bf16_mode_deviation": par.get("fast"), "tolerance": 1e-3, "against": against})
+    if extras and "precise" in want:
         try:
             from simple_tad_amd.modeling_finetune import DropPath
             saved = [(b.drop_path, b.drop_path.drop_prob) for b in model.blocks if isinstance(b.drop_path, DropPath)]
@@ -403,43 +587,47 @@ def main():
                 dpm.drop_prob = 0.0   # (the precise mode has no drop-path; it does not change the work per step)
             T.set_precision("precise")
             try:
-                for _ in range(2):
-                    step(it_next)
-                    it_next += 1
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                npz = 3
-                for _ in range(npz):
-                    step(it_next)
-                    it_next += 1
-                torch.cuda.synchronize()
-                dtp = (time.perf_counter() - t1) / npz
+                dtp = timed_steps(2, 3)
             finally:
                 T.set_precision("fast")
                 for dpm, pr in saved:
                     dpm.drop_prob = pr
-            out["precise"] = {"clips_per_s": round(B / dtp, 2), "ms_per_step": round(1e3 * dtp, 3), "steps": npz, "warmup": 2,
+            out["precise"] = {"clips_per_s": round(B / dtp, 2), "ms_per_step": round(1e3 * dtp, 3), "steps": 3, "warmup": 2,
                               "frac_of_bf16_mfma_roofline": round(B / dtp * f_fb / (PEAK_BF16_TFLOPS * 1e12), 4)}
         except Exception as e:  # noqa: BLE001
+            T.set_precision("fast")
             out["precise"] = {"error": repr(e)}
-        try:
-            out.setdefault("precise", {}).update(parity_vs_golden(T, dev))
-        except Exception as e:  # noqa: BLE001
-            out.setdefault("precise", {})["parity_error"] = repr(e)
+        if isinstance(par, dict) and "precise" in par:
+            out["precise"].update({"deviation": par["precise"], "logits_rel_l2": par["precise"]["logits_rel_l2"],
+                                   "features_rel_l2": par["precise"]["features_rel_l2"], "fast_mode_deviation": par.get("fast"),
+                                   "tolerance": 1e-3, "against": against,
+                                   "reference_bf16_autocast_deviation": {"features_rel_l2": 3.6e-3, "logits_rel_l2": 4.2e-3,
+                                                                         "source": "BASELINE.md section 4"}})
+    if isinstance(par, dict) and "error" in par:
+        out["parity_error"] = par["error"]
 
-        # ---- torch_route: the reference's own operator route (stock torch modules under bf16 autocast, torch's fused attention,
-        # torch.optim.AdamW; tools/bench_torch_eager.py) for the same workload on THIS GPU, beside `value`.  Calibration only.
-        if args.model == "vit_base_patch16_224" and args.frames == 16:
-            try:
-                import importlib.util
-                spec = importlib.util.spec_from_file_location("bench_torch_eager", os.path.join(ROOT, "tools", "bench_torch_eager.py"))
-                bte = importlib.util.module_from_spec(spec)
-                spec.loader.exec_module(bte)
-                r = bte.run("sdpa", B, steps=5, warmup=3, device=dev)
-                r["speedup_of_value"] = round(out["value"] / r["clips_per_s"], 2)
-                out["torch_route"] = r
-            except Exception as e:  # noqa: BLE001
-                out["torch_route"] = {"error": repr(e)}
+    if extras and "mae_pretrain" in want:
+        # ---- BASELINE configs[4] on one GPU: pretrain_videomae_large_patch16_224 (ViT-L/16 encoder on the 392 visible tokens, 12-block
+        # decoder on 1568, jobs/dapt/pretrain_capdata_large.sh:33-36), tube mask 0.75, 32 clips, fwd + bwd + fused AdamW
+        try:
+            out["mae_pretrain"] = mae_step(T, E, K, dev, class_table, batch=B)
+        except Exception as e:  # noqa: BLE001
+            K.set_profiler(None)
+            out["mae_pretrain"] = {"error": repr(e)}
+
+    # ---- torch_route: the reference's own operator route (stock torch modules under bf16 autocast, torch's fused attention,
+    # torch.optim.AdamW; tools/bench_torch_eager.py) for the same workload on THIS GPU, beside `value`.  Calibration only.
+    if extras and "torch_route" in want and args.model == "vit_base_patch16_224" and args.frames == 16:
+        try:
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("bench_torch_eager", os.path.join(ROOT, "tools", "bench_torch_eager.py"))
+            bte = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(bte)
+            r = bte.run("sdpa", B, steps=5, warmup=3, device=dev)
+            r["speedup_of_value"] = round(out["value"] / r["clips_per_s"], 2)
+            out["torch_route"] = r
+        except Exception as e:  # noqa: BLE001
+            out["torch_route"] = {"error": repr(e)}
 
     if world == 1 and not args.no_cpu_baseline and args.model == "vit_base_patch16_224":
         try:
@@ -452,40 +640,64 @@ def main():
         torch.distributed.destroy_process_group()
 
 
-def parity_vs_golden(T, dev):
-    """logits / features rel-L2 of the fast and the precise mode against the reference's own run (fixture data only: the reference
-    never travels to the GPU box)."""
+def mae_step(T, E, K, dev, class_table, batch=32, steps=8, warmup=3, model_name="pretrain_videomae_large_patch16_224", decoder_depth=12,
+             mask_ratio=0.75):
+    """One MAE pre-training step = tube mask -> reconstruction target -> encoder on the visible tokens -> decoder -> MSE -> backward ->
+    fused AdamW (engine_for_pretraining.py:51-71 around modeling_pretrain.py:278-291)."""
     import numpy as np
     import torch
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import golden_recipe as R
-    g = np.load(os.path.join(ROOT, "tests", "golden", "g11_vitb_grads.npz"), allow_pickle=False)
+    import simple_tad_amd.modeling_pretrain  # noqa: F401  (registers the factories)
+    from simple_tad_amd import engine_pretrain as EP, ops
+    from simple_tad_amd.masking_generator import TubeMaskingGenerator
+    from simple_tad_amd.parallel import DataParallel
     torch.manual_seed(0)
-    m = T.create_model("vit_base_patch16_224", pretrained=False, num_classes=2, all_frames=16, tubelet_size=2, final_reduction="fc_norm",
-                       use_flash_attn=False, init_scale=1.0, drop_path_rate=0.0)
-    R.rerandomize_1d(m)
-    torch.manual_seed(1)
-    xs = torch.randn(2, 3, 16, 224, 224).to(dev)
-    m = m.to(dev).eval()
+    model = T.create_model(model_name, pretrained=False, drop_path_rate=0.0, decoder_depth=decoder_depth).to(dev).train()
+    dp = DataParallel(model)
+    opt = E.create_optimizer(dp, lr=3e-4, weight_decay=0.05, betas=(0.9, 0.95))
+    scaler = E.NativeScalerWithGradNormCount(dp)
+    np.random.seed(0)
+    gen = TubeMaskingGenerator((8, 14, 14), mask_ratio)
+    x = torch.randn(batch, 3, 16, 224, 224, device=dev)
+    nprof = 2
+    masks = [torch.from_numpy(np.stack([gen() for _ in range(batch)])).to(dev).bool() for _ in range(steps + warmup + nprof)]
+    n_mask = gen.total_masks
+    params = list(model.parameters())
 
-    def rel(a, b):
-        a, b = a.double().cpu(), torch.from_numpy(b).double()
-        return ((a - b).norm() / b.norm()).item()
+    def step(i):
+        labels = EP.reconstruction_target(x, masks[i], 16, 2, True, n_mask)
+        loss = ops.MseLossFn.apply(dp(x, masks[i], num_masked=n_mask), labels)
+        dp.zero_grad()
+        scaler(loss, opt, parameters=params)
+        return loss
 
-    res = {}
-    with torch.no_grad():
-        for mode in ("fast", "precise"):
-            T.set_precision(mode)
-            try:
-                f = m.forward_features(xs)
-                lg = m.head(f)
-            finally:
-                T.set_precision("fast")
-            res[mode] = {"features_rel_l2": float(f"{rel(f, g['features']):.3e}"), "logits_rel_l2": float(f"{rel(lg, g['logits']):.3e}")}
-    return {"logits_rel_l2": res["precise"]["logits_rel_l2"], "features_rel_l2": res["precise"]["features_rel_l2"],
-            "fast_mode_deviation": res["fast"], "tolerance": 1e-3,
-            "against": "tests/golden/g11_vitb_grads.npz: reference modeling_finetune.vit_base_patch16_224, fp64, B=2, seed-0 init",
-            "reference_bf16_autocast_deviation": {"features_rel_l2": 3.6e-3, "logits_rel_l2": 4.2e-3, "source": "BASELINE.md section 4"}}
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        last = step(warmup + i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    pall = K.LaunchProfiler(only=None, stride=1)
+    K.set_profiler(pall)
+    for i in range(nprof):
+        step(warmup + steps + i)
+    K.set_profiler(None)
+    ra = class_table(pall.summary(), nprof, batch)
+    enc, dec = model.encoder, model.decoder
+    n_vis = 1568 - n_mask
+    blk = lambda n, d: 24.0 * n * d * d + 4.0 * n * n * d  # noqa: E731
+    f_fwd = (2.0 * 1568 * 1536 * enc.embed_dim + len(enc.blocks) * blk(n_vis, enc.embed_dim)
+             + 2.0 * n_vis * enc.embed_dim * dec.embed_dim + len(dec.blocks) * blk(1568, dec.embed_dim) + 2.0 * n_mask * dec.embed_dim * 1536)
+    f_step = 3.0 * f_fwd - 2.0 * 1568 * 1536 * enc.embed_dim  # patch-embed backward is dW only
+    res = {"value": round(batch / dt, 2), "unit": "clips/sec", "ms_per_step": round(1e3 * dt, 3), "steps": steps, "warmup": warmup,
+           "workload": f"{model_name}, decoder depth {decoder_depth}, 16x224x224, {batch} clips, tube mask {mask_ratio}: {n_vis} visible / "
+                       f"{n_mask} masked tokens (BASELINE configs[4] on one GPU)",
+           "algorithmic_gflop_per_clip": round(f_step / 1e9, 1), "frac_of_bf16_mfma_roofline": round(batch * f_step / dt / (PEAK_BF16_TFLOPS * 1e12), 4),
+           "loss": float(last), "parameters": sum(p.numel() for p in params), "roofline_all": ra}
+    del model, dp, opt
+    torch.cuda.empty_cache()
+    return res
 
 
 if __name__ == "__main__":

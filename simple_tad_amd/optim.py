@@ -70,7 +70,17 @@ class FusedAdamW(torch.optim.Optimizer):
                 K.transpose_bf16_batched(self.mirror, self.mirror_t, self._t_table)
             self._publish_mirror()
 
-    # ------------------------------------------------------------------ bf16 operand copies for the forward GEMMs
+    # ------------------------------------------------------------------ 16-bit operand copies for the forward GEMMs
+    def refresh_mirrors(self):
+        """re-derive the operand copies from the master weights (after the parameters were changed by anything but this optimizer's
+        step: another optimizer over the same flat space, a checkpoint load into ``p.data``) and publish them again"""
+        if self.mirror is None:
+            return
+        K.cast_op16(self.flat_param, out=self.mirror)
+        if self.mirror_t is not None:
+            K.transpose_bf16_batched(self.mirror, self.mirror_t, self._t_table)
+        self._publish_mirror()
+
     def _publish_mirror(self):
         for p in self.space.params:
             if p.dim() >= 2:

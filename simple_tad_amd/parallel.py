@@ -177,6 +177,7 @@ class DataParallel(nn.Module):
             self._avg_in_collective = True
         self._announced = set()
         self._works = []
+        self._timing = None  # enable_timing(): per-step records of the exchange
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in order]
         # A second gradient for an already announced parameter must not slip through: the kernel-side route is caught in _on_sink,
         # the autograd route here.  Tensor hooks run BEFORE the accumulation and receive None when a Function returned no gradient
@@ -221,7 +222,8 @@ class DataParallel(nn.Module):
         if b["ready"] == b["n"]:
             b["ready"] = 0
             view = self.flat_grad[b["lo"]:b["hi"]]
-            self._works.append(self._exchange(view, async_op=True))
+            t0 = self._mark()
+            self._works.append((self._exchange(view, async_op=True), self._bucket_of[id(p)], t0))
 
     def _exchange(self, view, async_op):
         """mean over the ranks of one bucket, in place"""
@@ -235,20 +237,75 @@ class DataParallel(nn.Module):
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
 
+    # -- self-diagnosis of the exchange (bench.py `collective`): how long backward's tail waits for the collectives
+    def enable_timing(self, on: bool = True):
+        """Record, per step, when each bucket's all-reduce was launched and when the compute stream could proceed past it, and how
+        long ``finish()`` kept the compute stream waiting (the EXPOSED part of the exchange; everything else ran beside backward).
+        GPU tensors: HIP events on the compute stream (``work.wait()`` makes that stream wait for the collective's stream); CPU
+        tensors (gloo tests): host clocks.  ``timing_summary()`` aggregates; the records cost two events per bucket and step."""
+        self._timing = {"steps": [], "cur": None} if on else None
+
+    def _mark(self):
+        if self._timing is None:
+            return None
+        if self.flat_grad.is_cuda:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(torch.cuda.current_stream())
+            return e
+        import time
+        return time.perf_counter()
+
+    @staticmethod
+    def _elapsed_ms(a, b):
+        return a.elapsed_time(b) if isinstance(a, torch.cuda.Event) else (b - a) * 1e3
+
+    def timing_summary(self):
+        """{exposed_ms (mean per step), bucket_ms [per bucket: launch -> compute stream past it, mean], late_buckets_per_step
+        (buckets exchanged synchronously in finish() because a gradient never arrived), steps}"""
+        if self._timing is None or not self._timing["steps"]:
+            return None
+        if self.flat_grad.is_cuda:
+            torch.cuda.synchronize()
+        steps = self._timing["steps"]
+        nb = len(self.buckets)
+        per_bucket = [[] for _ in range(nb)]
+        exposed, late = [], []
+        for st in steps:
+            exposed.append(self._elapsed_ms(st["finish"][0], st["finish"][1]))
+            late.append(st["late"])
+            for bi, t0, t1 in st["buckets"]:
+                per_bucket[bi].append(self._elapsed_ms(t0, t1))
+        mean = lambda v: (sum(v) / len(v)) if v else None  # noqa: E731
+        return {"steps": len(steps), "exposed_ms": round(mean(exposed), 4), "exposed_ms_max": round(max(exposed), 4),
+                "bucket_ms": [None if not v else round(mean(v), 4) for v in per_bucket],
+                "bucket_mbytes": [round((b["hi"] - b["lo"]) * self.flat_grad.element_size() / 2 ** 20, 1) for b in self.buckets],
+                "late_buckets_per_step": round(mean(late), 2), "overlap": self.overlap, "avg_in_collective": self._avg_in_collective}
+
     def finish(self):
         """Wait for every in-flight bucket (call after backward, before the optimizer step)."""
-        for w in self._works:
+        rec = {"buckets": [], "late": 0, "finish": None} if self._timing is not None else None
+        t_in = self._mark()
+        for w, bi, t0 in self._works:
             w.wait()
+            if rec is not None:
+                rec["buckets"].append((bi, t0, self._mark()))
         self._works.clear()
         self._announced.clear()
         if self.world == 1 or not self.require_sync:
             return
-        for b in self.buckets:  # a parameter that received no gradient this step leaves its bucket incomplete
+        for i, b in enumerate(self.buckets):  # a parameter that received no gradient this step leaves its bucket incomplete
             if b["n"] == 0 and self.overlap:
                 continue  # only never-grad parameters: zeros on every rank
             if b["ready"] or not self.overlap:
                 b["ready"] = 0
+                t0 = self._mark()
                 self._exchange(self.flat_grad[b["lo"]:b["hi"]], async_op=False)
+                if rec is not None:
+                    rec["buckets"].append((i, t0, self._mark()))
+                    rec["late"] += 1
+        if rec is not None:
+            rec["finish"] = (t_in, self._mark())
+            self._timing["steps"].append(rec)
 
     def zero_grad(self, set_to_none: bool = False):
         """Gradients are views into the flat buffer and must stay allocated: zero in place.  Difference from the reference's

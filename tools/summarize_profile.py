@@ -15,9 +15,9 @@ import re
 
 def short(name):
     name = re.sub(r"^void ", "", name)
-    m = re.match(r"(tad::\w+)(<[^>]*>)?", name)
+    m = re.match(r"tad::(?:op_bf16::|(op_f16::))?(\w+)", name)  # (the bf16 / half compilation passes live in inline namespaces)
     if m:
-        return m.group(1)
+        return "tad::" + (m.group(1) or "") + m.group(2)
     m = re.match(r"at::native::(?:\(anonymous namespace\)::)?(\w+)", name)
     return ("torch::" + m.group(1)) if m else name[:60]
 
@@ -34,7 +34,15 @@ def main():
     ap.add_argument("--out", default="profiles")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
-    summary = {"round": a.round}
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.path.join(root, "simple_tad_amd", "csrc")
+    for fn in sorted(os.listdir(d)) + [os.path.join("..", "..", "include", "tad_mi355x.h")]:
+        with open(os.path.join(d, fn), "rb") as fh:
+            h.update(fh.read())
+    # the kernel sources these profiles were taken on: bench.py reports figures read from here only while the sources still match
+    summary = {"round": a.round, "csrc_sha16": h.hexdigest()[:16]}
     if a.kt:
         # Per-dispatch begin/end from the kernel trace (the --stats table of the same run is kept for reference: it is built from
         # the same dispatches, but one first-use dispatch can carry a multi-millisecond outlier there -- see profiles/README.md).
