@@ -223,10 +223,19 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 // 20 to 100 times below the bf16 rounding (2^-9 relative) of the values these epilogues read and write.  The precise mode keeps
 // the A-S form above.
 typedef __attribute__((ext_vector_type(2))) float f32x2;
+#ifdef TAD_OPND_F16
+// half pass: the values these epilogues read and write are rounded at 2^-12, so the polynomials are carried four / five degrees
+// further (|Phi error| <= 3.9e-7, gelu <= 1.9e-6 * max(1, |x|), |gelu' error| <= 6.0e-6: >= 40x below the half rounding again)
+constexpr float PHI_XMAX = 5.0f;
+constexpr float PHI_C[13] = {1.413638185e-01f, -7.029590887e-02f, 5.151792974e-02f, -4.045128240e-02f, 3.147675865e-02f, -2.321312828e-02f, 1.623608981e-02f, -1.130712491e-02f, 6.766527505e-03f, -2.526916729e-03f, 1.374596151e-03f, -1.676730979e-03f, 7.353763888e-04f};
+constexpr float DGELU_XMAX = 5.0f;
+constexpr float DGELU_C[14] = {1.421342312e-01f, -7.511106477e-02f, 6.653327323e-02f, -7.173111262e-02f, 8.085778139e-02f, -8.495648970e-02f, 7.754241580e-02f, -6.598634567e-02f, 5.801962140e-02f, -3.821696020e-02f, 1.123988696e-02f, -7.203916123e-03f, 1.261547586e-02f, -5.735615125e-03f};
+#else
 constexpr float PHI_XMAX = 4.0f;
 constexpr float PHI_C[9] = {1.759501642e-01f, -8.430131655e-02f, 5.591522291e-02f, -3.713346277e-02f, 2.266773498e-02f, -1.154668287e-02f, 5.828486749e-03f, -3.991263335e-03f, 1.605170928e-03f};
 constexpr float DGELU_XMAX = 4.5f;
 constexpr float DGELU_C[10] = {1.594574418e-01f, -9.003904569e-02f, 8.571837549e-02f, -9.350841452e-02f, 1.078448091e-01f, -9.557466143e-02f, 4.249439465e-02f, -3.356380937e-02f, 5.896066889e-02f, -3.068672777e-02f};
+#endif
 
 __device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
 // out[i] = 0.5 + xc[i] * P(t[i]) for W independent element pairs, coefficient-major so that the W recurrences interleave

@@ -42,7 +42,7 @@ def run_trajectory(model, device, dtype, fused_kernel=None):
     return opt, lr_sched, wd_sched, stats
 
 
-def check_logged(stats, g, loss_tol, norm_rtol, acc_flips=0):
+def check_logged(stats, g, loss_tol, norm_rtol, acc_flips=0, loss_scaled=False):
     assert np.allclose(stats["loss"], g["loss"], rtol=0, atol=loss_tol), (stats["loss"], g["loss"])
     got = np.array([np.nan if n is None else n for n in stats["grad_norm"]])
     assert np.array_equal(np.isnan(got), np.isnan(g["grad_norm"]))         # a norm on the last micro-batch of each step only
@@ -50,7 +50,9 @@ def check_logged(stats, g, loss_tol, norm_rtol, acc_flips=0):
     assert np.allclose(got[ok], g["grad_norm"][ok], rtol=norm_rtol), (got, g["grad_norm"])
     assert np.allclose(stats["lr"], g["lr"], rtol=1e-12) and np.allclose(stats["min_lr"], g["min_lr"], rtol=1e-12)
     avg = dict(zip([str(k) for k in g["avg_keys"]], g["avg_vals"]))           # engine_for_finetuning.py:140: {k: meter.global_avg}
-    for k in ("loss", "lr", "min_lr", "grad_norm", "loss_scale"):
+    if loss_scaled:  # half mode: GradScaler's default scale is live here, where the reference's CPU run logs its disabled scaler's 1.0
+        assert stats["averaged"]["loss_scale"] == 65536.0
+    for k in ("loss", "lr", "min_lr", "grad_norm") + (() if loss_scaled else ("loss_scale",)):
         assert abs(stats["averaged"][k] - avg[k]) <= max(loss_tol, norm_rtol * abs(avg[k])), (k, stats["averaged"][k], avg[k])
     # accuracy is discrete: the tiny model's logits are nearly tied (loss ~ ln 2), so the bf16-operand mode may flip an argmax
     n_samples = 2 * len(g["loss"])
@@ -81,7 +83,7 @@ def test_host_logic_reproduces_the_reference_trajectory_around_the_oracle(golden
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["precise", "fast"])
+@pytest.mark.parametrize("mode", ["precise", "fast", "half"])
 def test_hip_path_follows_the_reference_trajectory(golden, mode):
     g = golden("g12_finetune_trajectory")
     m = build("cuda", torch.float32)
@@ -93,9 +95,10 @@ def test_hip_path_follows_the_reference_trajectory(golden, mode):
         T.set_precision("fast")
     from simple_tad_amd.optim import FusedAdamW
     assert isinstance(opt, FusedAdamW)                     # the fused HIP optimizer is what ran
-    # north_star's gate for the precise mode; the fast (bf16-operand) mode is held to its measured deviation at depth 2
-    loss_tol, norm_rtol, step_tol = (2e-5, 1e-3, 1e-3) if mode == "precise" else (3e-3, 2e-2, 1e-1)
-    check_logged(stats, g, loss_tol=loss_tol, norm_rtol=norm_rtol, acc_flips=0 if mode == "precise" else 2)
+    # north_star's gate for the precise mode; the bf16-operand mode is held to 1.5x its measured deviation at depth 2 (update 5.6e-2);
+    # the half mode (loss-scaled backward, scale removed and clipping applied inside the fused AdamW) sits in between
+    loss_tol, norm_rtol, step_tol = {"precise": (2e-5, 1e-3, 1e-3), "fast": (3e-3, 2e-2, 8.4e-2), "half": (4e-4, 3e-3, 4.5e-2)}[mode]
+    check_logged(stats, g, loss_tol=loss_tol, norm_rtol=norm_rtol, acc_flips=0 if mode == "precise" else 2, loss_scaled=mode == "half")
     worst = 0.0
     for k, p in m.named_parameters():
         # what three steps changed, relative to the size of the reference's own change (parameters themselves agree far tighter)
@@ -176,7 +179,7 @@ def test_pretrain_host_logic_and_oracle_reproduce_the_reference_trajectory(golde
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["precise", "fast"])
+@pytest.mark.parametrize("mode", ["precise", "fast", "half"])
 def test_hip_pretrain_engine_follows_the_reference_trajectory(golden, mode):
     from simple_tad_amd import engine_pretrain as EP
     from simple_tad_amd.optim import FusedAdamW
@@ -195,7 +198,9 @@ def test_hip_pretrain_engine_follows_the_reference_trajectory(golden, mode):
         T.set_precision("fast")
     # the loss and the gradient norm sit at the 1e-3 gate; the parameter UPDATE after three Adam steps is held to 1.5e-2 of the update (measured 5.6e-3): Adam
     # divides by sqrt(v), so an element whose gradient is near zero turns a 1e-4-of-the-tensor gradient error into a larger relative step error
-    loss_tol, norm_rtol, step_tol = (2e-6, 1e-3, 1.5e-2) if mode == "precise" else (1e-4, 3e-2, 5e-2)
+    loss_tol, norm_rtol, step_tol = {"precise": (2e-6, 1e-3, 1.5e-2), "fast": (1e-4, 3e-2, 2.4e-2), "half": (2e-5, 4e-3, 5.8e-2)}[mode]
+    # (fast: measured 1.44e-2.  half: 3.9e-2 -- this model's encoder gradients are far below Adam's eps; multiplied by GradScaler's initial
+    #  65536 they still sit in half's subnormal range, as they would under the reference's own fp16 autocast until the scale has grown)
     assert np.allclose(stats["loss"], g["loss"], rtol=0, atol=loss_tol), (stats["loss"], g["loss"])
     assert np.allclose(stats["grad_norm"], g["grad_norm"], rtol=norm_rtol), (stats["grad_norm"], g["grad_norm"])
     assert np.allclose(stats["lr"], lr_sched, rtol=1e-12) and np.allclose(stats["weight_decay"], wd_sched, rtol=1e-12)

@@ -18,9 +18,11 @@ BF16_ULP = 2.0 ** -8
 # Inside the fused attention kernels the softmax probabilities P (and dS in backward) are rounded to bf16 before they
 # enter the second MFMA (exactly what flash-attn, the reference's own attention backend, does: flash_attention_class.py
 # requires fp16/bf16).  That rounding alone is 2^-9 relative per element and does not average out relative to the
-# output (measured rel-L2 ~1.5e-3; the max over ~10^5 outputs of a long sequence reaches ~3e-3), so the fast kernels are
-# held to 4e-3 on both norms.
-ATT_TOL = 4e-3
+# output (measured rel-L2 ~1.5e-3; the max over ~10^5 outputs of a long sequence reaches ~1.7e-3), so the fast kernels are
+# held to 2.5e-3 in rel-L2 and 4.5e-3 in the max norm (1.5x what was measured: 1.7e-3 / 3.1e-3; the IEEE-half twins:
+# tests/test_half_gpu.py, 6e-4).
+ATT_TOL = 2.5e-3
+ATT_TOL_MAX = 4.5e-3
 
 
 @pytest.fixture(scope="module")
@@ -50,9 +52,10 @@ def rell2(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
 
 
-def check(a, b, tol=TOL, what=""):
+def check(a, b, tol=TOL, what="", tol_max=None):
+    """tol bounds the rel-L2 error; the max-norm error is held to tol_max (default: the same tol)"""
     e1, e2 = relmax(a, b), rell2(a, b)
-    assert e1 <= tol and e2 <= tol, f"{what}: max-rel {e1:.3e} l2-rel {e2:.3e} > {tol}"
+    assert e1 <= (tol if tol_max is None else tol_max) and e2 <= tol, f"{what}: max-rel {e1:.3e} l2-rel {e2:.3e} > {tol} (max: {tol_max})"
 
 
 # ------------------------------------------------------------------ casts (bit-exact RNE)
@@ -217,7 +220,7 @@ def test_attention_fwd_bwd(K, B, N, H):
     ref, ref_dqkv = _attn_ref(qkv, B, N, H, scale, dout)
     qd = dev(qkv).to(torch.bfloat16)
     out32, lse = K.attn_fwd(qd, B, N, H, scale, out_dtype=torch.float32)
-    check(out32.reshape(B, N, -1), ref, tol=ATT_TOL, what="attn fwd f32")
+    check(out32.reshape(B, N, -1), ref, tol=ATT_TOL, tol_max=ATT_TOL_MAX, what="attn fwd f32")
     # lse = log sum exp(scale q.k)
     q4 = qkv.double().reshape(B, N, 3, H, 64)
     s = torch.einsum("bnhd,bmhd->bhnm", q4[:, :, 0], q4[:, :, 1]) * scale

@@ -134,8 +134,9 @@ def test_real_shape_logits_vs_reference_golden(golden, tag, name, frames):
         logits = m.head(feats)
     e_f, e_l = rell2(feats, g[f"{tag}.features"]), rell2(logits, g[f"{tag}.logits"])
     print(tag, "features rel-l2", e_f, "logits rel-l2", e_l)
-    # yardstick: torch bf16 autocast of the reference itself = 3.6e-3 / 4.2e-3
-    assert e_f < 8e-3 and e_l < 1e-2
+    # yardstick: torch bf16 autocast of the reference itself = 3.6e-3 / 4.2e-3; measured here 1.9e-3 / 2.0e-3
+    # (ViT-S 8f) and 2.7e-3 / 2.9e-3 (ViT-B 16f): the bound is 1.5x the larger pair
+    assert e_f < 4.5e-3 and e_l < 4.5e-3
     if tag == "s8":
         probs = torch.softmax(logits, -1)
         assert relmax(probs, g["s8.infer_probs"]) < 5e-3  # run_inference_simple's model (softmax baked in)

@@ -97,6 +97,33 @@ def test_bench_self_launch_two_gpus_over_rccl():
     assert out["config"]["global_batch"] == 16 and out["value"] > 0 and out["scaling"] == "weak"
 
 
+@pytest.mark.parametrize("extra,gb,scaling", [([], 8, "weak"), (["--global-batch", "8"], 8, "strong")])
+def test_bench_two_ranks_over_gloo_on_one_gpu_reports_the_exchange(extra, gb, scaling):
+    """The N > 1 path of bench.py end to end on ONE GPU (two ranks share it, gradients travel over gloo): one rank-0 JSON line with
+    n_gpus = 2 and a `collective` object that says how the exchange went -- exposed all-reduce time, per-bucket time, per-rank step
+    times, the Linear schedule in force -- so that the first run on a real 8-GPU node diagnoses itself.  Weak
+    scaling (4 clips per rank) and the strong-scaling path (--global-batch)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["TAD_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
+                        "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=900, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stderr[-3000:])
+    out = json.loads(lines[0])
+    c = out["collective"]
+    assert out["n_gpus"] == 2 and c["backend"] == "gloo" and c["world_size"] == 2 and out["scaling"] == scaling
+    assert out["config"]["global_batch"] == gb and out["config"]["per_gpu_batch"] == 4 and out["value"] > 0
+    assert c["buckets"] == len(c["bucket_ms"]) == len(c["bucket_mbytes"]) >= 2 and c["steps"] == 2
+    assert abs(sum(c["bucket_mbytes"]) * 2 ** 20 - c["allreduce_bytes_per_step"]) < 2 ** 20
+    assert all(v is not None and v > 0 for v in c["bucket_ms"]) and c["exposed_ms"] > 0 and c["late_buckets_per_step"] == 0
+    assert len(c["rank_ms_per_step"]["all"]) == 2 and c["rank_ms_per_step"]["min"] <= c["rank_ms_per_step"]["max"] <= out["ms_per_step"] * 1.05
+    assert "per-tile" in c["linear_schedule"] and c["avg_in_collective"] is False
+
+
 def _two_rank_step(backend):
     import torch.nn.functional as F
     from simple_tad_amd import engine as E

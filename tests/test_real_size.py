@@ -181,7 +181,7 @@ def test_fast_mode_backward_at_real_shape_measured_deviation(golden):
     m = m.cuda().train()
     feats, logits, loss = _vitb_step(m, x, y)
     e_f, e_l = rell2(feats, g["features"]), rell2(logits, g["logits"])
-    assert e_f < 5e-3 and e_l < 5e-3 and abs(loss.item() - float(g["loss"])) < 2e-3
+    assert e_f < 4.2e-3 and e_l < 4.4e-3 and abs(loss.item() - float(g["loss"])) < 8e-4   # measured 2.69e-3 / 2.92e-3 / 4.1e-4
     gn = O.grad_norm([p.grad.float().cpu() for p in m.parameters()])
     assert abs(gn.item() - float(g["grad_norm"])) < 5e-3 * float(g["grad_norm"])
     errs = {k: max(head_err_scaled(p.grad, g, "grad." + k), sq_err(p.grad, g, "grad." + k)) for k, p in m.named_parameters()}
@@ -192,7 +192,48 @@ def test_fast_mode_backward_at_real_shape_measured_deviation(golden):
     print(f"fast ViT-B real shape: features {e_f:.2e} logits {e_l:.2e} loss {loss.item():.6f} grad (slice error / tensor RMS, sqsum) median "
           f"{med:.2e} worst {errs[worst]:.2e} ({worst}); per-slice relative: median {np.median(list(slice_rel.values())):.2e} worst "
           f"{slice_rel[ws]:.2e} ({ws})")
-    assert errs[worst] < 2.5e-2 and med < 8e-3
+    assert errs[worst] < 1.2e-2 and med < 8e-3   # measured: worst 7.9e-3 (slice error / tensor RMS), median of max(slice/RMS, sqsum) 5.2e-3
+
+
+@pytest.mark.gpu
+def test_half_mode_forward_and_backward_at_real_shape_within_1e3(golden):
+    """set_precision("half") = the reference's own autocast arithmetic (float16 operands, f32 accumulation, loss-scaled backward) on the
+    SAME kernels at the SAME speed class as the benchmarked bf16 mode: at the benchmark's model shape the outputs sit 3-5x inside
+    north_star's 1e-3, and every one of the 162 gradient tensors is within 1e-3 of the reference in its sum of squares and, for the
+    stored slice, relative to the tensor's RMS.  What half operands cannot give is 1e-3 relative to EVERY stored slice itself: the
+    median slice is at 4.8e-4, a dozen sit between 1e-3 and 1.3e-2 -- the q rows of late qkv weights, whose gradient at seeded init is
+    ~100x below their tensor's RMS and ill-conditioned ~x50 against operand rounding in ANY arithmetic (2^-12 * 50 = 1.3e-2 here,
+    2^-17 * 50 = 8.8e-4 in the precise mode, 2^-9 * 50 = 1.1e-1 in bf16), and a few MLP weights just above the line.  Counted and bounded."""
+    import simple_tad_amd as T
+    g = golden("g11_vitb_grads")
+    m, x, y = build_vitb()
+    m = m.cuda().train()
+    scale = 4096.0
+    T.set_precision("half")
+    try:
+        feats = m.forward_features(x.cuda())
+        logits = m.head(feats)
+        loss = F.cross_entropy(logits, y.cuda())
+        (loss * scale).backward()
+    finally:
+        T.set_precision("fast")
+    e_f, e_l = rell2(feats, g["features"]), rell2(logits, g["logits"])
+    assert e_f < 5.4e-4 and e_l < 3.0e-4 and abs(loss.item() - float(g["loss"])) < 1e-4, (e_f, e_l, loss.item())   # measured 3.58e-4 / 1.96e-4 / 3.6e-5
+    grads = {k: p.grad / scale for k, p in m.named_parameters()}
+    assert all(bool(torch.isfinite(v).all()) for v in grads.values())
+    gn = O.grad_norm([v.float().cpu() for v in grads.values()])
+    assert abs(gn.item() - float(g["grad_norm"])) < 4e-4 * float(g["grad_norm"])                                     # measured 2.3e-4
+    rms = {k: head_err_scaled(v, g, "grad." + k) for k, v in grads.items()}
+    sq = {k: sq_err(v, g, "grad." + k) for k, v in grads.items()}
+    sl = {k: head_err(v, g, "grad." + k) for k, v in grads.items()}
+    over = sorted(k for k, v in sl.items() if v > 1e-3)
+    print(f"half ViT-B real shape: features {e_f:.2e} logits {e_l:.2e} | slice/RMS median {np.median(list(rms.values())):.2e} worst "
+          f"{max(rms.values()):.2e} | sqsum worst {max(sq.values()):.2e} | slice-relative median {np.median(list(sl.values())):.2e} worst "
+          f"{max(sl.values()):.2e}, over 1e-3: {over}")
+    assert max(rms.values()) < 1e-3 and max(sq.values()) < 1e-3            # measured 9.6e-4 (blocks.9.attn.q_bias) / 6.0e-4
+    assert float(np.median(list(sl.values()))) < 7.2e-4                      # measured 4.8e-4
+    assert len(over) <= 16, over                                             # measured 12 of 162 (bf16 mode: all 162)
+    assert max(sl.values()) < 2e-2                                           # measured 1.27e-2, a q row (bf16 mode: 1.1e-1)
 
 
 @pytest.mark.gpu
@@ -223,8 +264,11 @@ def test_vitl_mae_step_at_real_size_vs_reference_golden(golden):
 def test_fast_mode_error_budget_per_operator(golden):
     """Which operator carries the fast mode's end-to-end deviation: one ViT-B block at the real shape (B = 2, N = 1568, D = 768) in
     precise mode, then with exactly ONE operator class switched to its bf16-MFMA kernel (inputs / outputs of the others stay f32 /
-    split-bf16).  Every single contribution must stay below 1e-3 per block; the printed table is the error budget quoted in
-    DESIGN.md section 4."""
+    split-bf16).  The attention branch's three operators each stay below 1.5e-4 of the block's residual contribution; the two MLP
+    Linears carry the deviation (2.9e-3 / 2.3e-3: the bf16 rounding of the 3072-wide hidden activation).  Bounds are 1.5x what was
+    measured on MI355X; the printed table is the error budget quoted in DESIGN.md section 4.  (Seeded random-init weights, where the
+    softmax is near-uniform and averages operand rounding over 1568 keys: the budget of a trained checkpoint may shift towards the
+    attention branch -- none is available offline.)"""
     from simple_tad_amd import kernels as K, ops
     from simple_tad_amd._lib import EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL
     m, x, _ = build_vitb()
@@ -272,5 +316,6 @@ def test_fast_mode_error_budget_per_operator(golden):
         budget["all five"] = ((run({"qkv", "attn", "proj", "fc1", "fc2"}) - ref).double().norm() / denom).item()
     print("fast-mode error budget of one ViT-B block (rel-L2 of the block's residual contribution):",
           ", ".join(f"{k} {v:.2e}" for k, v in budget.items()))
+    bound = {"qkv": 1.5e-4, "attn": 1.5e-4, "proj": 1.5e-4, "fc1": 4.4e-3, "fc2": 3.5e-3, "all five": 5.0e-3}
     for op, e in budget.items():
-        assert e < (6e-3 if op == "all five" else 4e-3), (op, e)
+        assert e < bound[op], (op, e, bound[op])

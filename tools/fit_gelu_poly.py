@@ -39,7 +39,8 @@ def eval32(mono, xmax, x):
 if __name__ == "__main__":
     rng = np.random.RandomState(0)
     xs = np.concatenate([np.linspace(-9, 9, 600001), rng.randn(300000) * 1.5])
-    for name, fun, xmax, deg in (("PHI", Phi, 4.0, 8), ("DGELU", dgelu, 4.5, 9)):
+    # bf16 pass: (PHI 4.0, 8), (DGELU 4.5, 9); half pass (csrc/common.h, TAD_OPND_F16): (PHI 5.0, 12), (DGELU 5.0, 13)
+    for name, fun, xmax, deg in (("PHI", Phi, 4.0, 8), ("DGELU", dgelu, 4.5, 9), ("PHI", Phi, 5.0, 12), ("DGELU", dgelu, 5.0, 13)):
         mono = fit(fun, xmax, deg)
         got = eval32(mono, xmax, xs).astype(np.float64)
         err = np.max(np.abs(got - fun(xs)))
