@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 #   TAD_BUILD_LIB=libtad_spread.so TAD_BUILD_DEFINES="-DTAD_DMA_SPREAD=1" python -m simple_tad_amd.build --force
 # and TAD_LIB=<path> selects the library a process loads (_lib.py).
 LIB = os.path.join(HERE, os.environ.get("TAD_BUILD_LIB", "libtad_mi355x.so"))
-SOURCES = ["capi.hip", "elementwise.hip", "layernorm.hip", "gemm.hip", "attn_fwd.hip", "attn_bwd.hip", "precise.hip", "optim.hip", "mae.hip", "metrics.hip", "collective.hip"]
+SOURCES = ["capi.hip", "elementwise.hip", "layernorm.hip", "gemm.hip", "attn_fwd.hip", "attn_bwd.hip", "attn_f32.hip", "precise.hip", "optim.hip", "mae.hip", "metrics.hip", "collective.hip"]
 # Sources that touch 16-bit GEMM / attention operands are compiled a second time with -DTAD_OPND_F16: the same kernels for IEEE half
 # operands, exported as tad_*_f16 (csrc/common.h, csrc/opnd_f16_names.h; include/tad_mi355x.h "IEEE half operand twins").
 F16_SOURCES = ["elementwise.hip", "layernorm.hip", "gemm.hip", "attn_fwd.hip", "attn_bwd.hip", "optim.hip"]

@@ -2,7 +2,7 @@
 // not for throughput.
 //
 //  * (the operand split x = hi + lo behind the precise Linear is tad_split_bf16x3 / tad_split_f16x3, elementwise.hip)
-//  * attn_fwd_f32_kernel: plain f32 (VALU FMA) flash-style attention for packed f32 qkv, 64 query rows per workgroup.
+//  * (f32 attention: csrc/attn_f32.hip, exact-f32 MFMA)
 #include "common.h"
 
 TAD_NAMESPACE_BEGIN
@@ -27,296 +27,6 @@ __global__ void im2col_tubelets_f32_kernel(const float* __restrict__ x, float* _
     const int64_t n = ((int64_t)(b * Tp + tp) * Hp + hp) * Wp + wp;
     const int k = ((c * tub + kt) * p + kh) * p + kw;
     *reinterpret_cast<float4*>(cols + n * K + k) = reinterpret_cast<const float4*>(x)[i];
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// f32 attention, any head dim HD that is a multiple of 16 (64: the precise mode of the small / base / large models; 80: the "huge"
-// configurations, modeling_finetune.py:390-398 / modeling_pretrain.py:364-386, which have no MFMA kernel).
-// Forward.  Workgroup = 256 threads = 64 query rows of one (batch, head); thread (ty = tid>>4, tx = tid&15) owns query rows
-// 4ty..4ty+3 and, per 64-key tile, keys 4tx..4tx+3 (scores) / head-dim columns CPT*tx .. CPT*tx+CPT-1 (output), CPT = HD / 16.
-template <int HD>
-__global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out, float* __restrict__ lse,
-                                                           int N, int H, float scale) {
-  constexpr int CPT = HD / 16;
-  __shared__ float Qs[64][HD + 1], Ks[64][HD + 1], Vs[64][HD + 1], Ps[64][65];
-  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-  const int head = blockIdx.y, b = blockIdx.z, q0 = blockIdx.x * 64;
-  const int64_t tok = (int64_t)3 * H * HD;
-  const float* base = qkv + (int64_t)b * N * tok + head * HD;
-  for (int i = tid; i < 64 * HD; i += 256) {
-    const int r = i / HD, c = i - r * HD;
-    const int q = min(q0 + r, N - 1);
-    Qs[r][c] = base[(int64_t)q * tok + c] * scale;
-  }
-  float m_run[4], l_run[4], o[4][CPT];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    m_run[i] = -1e30f; l_run[i] = 0.f;
-#pragma unroll
-    for (int j = 0; j < CPT; ++j) o[i][j] = 0.f;
-  }
-  for (int kv0 = 0; kv0 < N; kv0 += 64) {
-    __syncthreads();
-    for (int i = tid; i < 64 * HD; i += 256) {
-      const int r = i / HD, c = i - r * HD;
-      const int key = min(kv0 + r, N - 1);
-      Ks[r][c] = base[(int64_t)key * tok + (int64_t)H * HD + c];
-      Vs[r][c] = base[(int64_t)key * tok + (int64_t)2 * H * HD + c];
-    }
-    __syncthreads();
-    float s[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) s[i][j] = 0.f;
-    for (int d = 0; d < HD; ++d) {
-      float qa[4], kb[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { qa[i] = Qs[4 * ty + i][d]; kb[i] = Ks[4 * tx + i][d]; }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) s[i][j] = fmaf(qa[i], kb[j], s[i][j]);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float mx = -1e30f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (kv0 + 4 * tx + j >= N) s[i][j] = -1e30f;
-        mx = fmaxf(mx, s[i][j]);
-      }
-#pragma unroll
-      for (int off = 1; off < 16; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));  // the 16 lanes tx = 0..15 share query rows
-      const float m_new = fmaxf(m_run[i], mx);
-      const float alpha = __expf(m_run[i] - m_new);
-      float ps = 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float pv = __expf(s[i][j] - m_new);
-        ps += pv;
-        Ps[4 * ty + i][4 * tx + j] = pv;
-      }
-#pragma unroll
-      for (int off = 1; off < 16; off <<= 1) ps += __shfl_xor(ps, off, 64);
-      l_run[i] = l_run[i] * alpha + ps;
-      m_run[i] = m_new;
-#pragma unroll
-      for (int j = 0; j < CPT; ++j) o[i][j] *= alpha;
-    }
-    __syncthreads();
-    for (int k = 0; k < 64; ++k) {
-      float pa[4], vb[CPT];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) pa[i] = Ps[4 * ty + i][k];
-#pragma unroll
-      for (int j = 0; j < CPT; ++j) vb[j] = Vs[k][CPT * tx + j];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < CPT; ++j) o[i][j] = fmaf(pa[i], vb[j], o[i][j]);
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int q = q0 + 4 * ty + i;
-    if (q >= N) continue;
-    const float inv = 1.f / l_run[i];
-    float* op = out + (((int64_t)b * N + q) * H + head) * HD + CPT * tx;
-#pragma unroll
-    for (int j = 0; j < CPT; ++j) op[j] = o[i][j] * inv;
-    if (tx == 0 && lse) lse[((int64_t)b * H + head) * N + q] = m_run[i] + __logf(l_run[i]);
-  }
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// f32 attention backward (verification mode / head dims without an MFMA kernel): delta, dQ pass (per 64 query rows) and dK/dV pass
-// (per 64 keys); same thread layout as the forward kernel.  No atomics.
-template <int HD>
-__global__ void attn_delta_f32_kernel(const float* __restrict__ o, const float* __restrict__ dout, float* __restrict__ delta, int B, int N,
-                                      int H) {
-  constexpr int CPT = HD / 16;
-  const int64_t rows = (int64_t)B * N * H;
-  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t row = gid >> 4;
-  const int sub = (int)(gid & 15);
-  float s = 0.f;
-  if (row < rows) {
-#pragma unroll
-    for (int j = 0; j < CPT; ++j) s = fmaf(o[row * HD + sub * CPT + j], dout[row * HD + sub * CPT + j], s);
-  }
-#pragma unroll
-  for (int off = 1; off < 16; off <<= 1) s += __shfl_xor(s, off, 64);
-  if (row < rows && sub == 0) {
-    const int h = (int)(row % H);
-    const int64_t bq = row / H;
-    delta[((bq / N) * H + h) * N + (bq % N)] = s;
-  }
-}
-
-template <int HD>
-__global__ __launch_bounds__(256) void attn_bwd_dq_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
-                                                              const float* __restrict__ lse, const float* __restrict__ delta,
-                                                              float* __restrict__ dqkv, int N, int H, float scale) {
-  constexpr int CPT = HD / 16;
-  __shared__ float Qs[64][HD + 1], Gs[64][HD + 1], Ks[64][HD + 1], Vs[64][HD + 1], Ds[64][65];
-  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-  const int head = blockIdx.y, b = blockIdx.z, q0 = blockIdx.x * 64;
-  const int64_t tok = (int64_t)3 * H * HD;
-  const float* base = qkv + (int64_t)b * N * tok + head * HD;
-  for (int i = tid; i < 64 * HD; i += 256) {
-    const int r = i / HD, c = i - r * HD;
-    const int q = min(q0 + r, N - 1);
-    Qs[r][c] = base[(int64_t)q * tok + c] * scale;
-    Gs[r][c] = dout[(((int64_t)b * N + q) * H + head) * HD + c];
-  }
-  float lq[4], dq_[4], acc[4][CPT];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int q = min(q0 + 4 * ty + i, N - 1);
-    lq[i] = lse[((int64_t)b * H + head) * N + q];
-    dq_[i] = delta[((int64_t)b * H + head) * N + q];
-#pragma unroll
-    for (int j = 0; j < CPT; ++j) acc[i][j] = 0.f;
-  }
-  for (int kv0 = 0; kv0 < N; kv0 += 64) {
-    __syncthreads();
-    for (int i = tid; i < 64 * HD; i += 256) {
-      const int r = i / HD, c = i - r * HD;
-      const int key = min(kv0 + r, N - 1);
-      Ks[r][c] = base[(int64_t)key * tok + (int64_t)H * HD + c];
-      Vs[r][c] = base[(int64_t)key * tok + (int64_t)2 * H * HD + c];
-    }
-    __syncthreads();
-    float s[4][4], dp[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { s[i][j] = 0.f; dp[i][j] = 0.f; }
-    for (int d = 0; d < HD; ++d) {
-      float qa[4], ga[4], kb[4], vb[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { qa[i] = Qs[4 * ty + i][d]; ga[i] = Gs[4 * ty + i][d]; kb[i] = Ks[4 * tx + i][d]; vb[i] = Vs[4 * tx + i][d]; }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { s[i][j] = fmaf(qa[i], kb[j], s[i][j]); dp[i][j] = fmaf(ga[i], vb[j], dp[i][j]); }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float pv = (kv0 + 4 * tx + j < N) ? __expf(s[i][j] - lq[i]) : 0.f;
-        Ds[4 * ty + i][4 * tx + j] = pv * (dp[i][j] - dq_[i]);
-      }
-    __syncthreads();
-    for (int k = 0; k < 64; ++k) {
-      float da[4], kb[CPT];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) da[i] = Ds[4 * ty + i][k];
-#pragma unroll
-      for (int j = 0; j < CPT; ++j) kb[j] = Ks[k][CPT * tx + j];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < CPT; ++j) acc[i][j] = fmaf(da[i], kb[j], acc[i][j]);
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int q = q0 + 4 * ty + i;
-    if (q >= N) continue;
-    float* op = dqkv + ((int64_t)b * N + q) * tok + head * HD + CPT * tx;
-#pragma unroll
-    for (int j = 0; j < CPT; ++j) op[j] = acc[i][j] * scale;
-  }
-}
-
-template <int HD>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
-                                                               const float* __restrict__ lse, const float* __restrict__ delta,
-                                                               float* __restrict__ dqkv, int N, int H, float scale) {
-  constexpr int CPT = HD / 16;
-  __shared__ float Ks[64][HD + 1], Vs[64][HD + 1], Qs[64][HD + 1], Gs[64][HD + 1], Pt[64][65], Dt[64][65];
-  __shared__ float Ls[64], Es[64];
-  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-  const int head = blockIdx.y, b = blockIdx.z, k0 = blockIdx.x * 64;
-  const int64_t tok = (int64_t)3 * H * HD;
-  const float* base = qkv + (int64_t)b * N * tok + head * HD;
-  for (int i = tid; i < 64 * HD; i += 256) {
-    const int r = i / HD, c = i - r * HD;
-    const int key = min(k0 + r, N - 1);
-    Ks[r][c] = base[(int64_t)key * tok + (int64_t)H * HD + c];
-    Vs[r][c] = base[(int64_t)key * tok + (int64_t)2 * H * HD + c];
-  }
-  float dk[4][CPT], dv[4][CPT];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < CPT; ++j) { dk[i][j] = 0.f; dv[i][j] = 0.f; }
-  for (int q0 = 0; q0 < N; q0 += 64) {
-    __syncthreads();
-    for (int i = tid; i < 64 * HD; i += 256) {
-      const int r = i / HD, c = i - r * HD;
-      const int q = min(q0 + r, N - 1);
-      Qs[r][c] = base[(int64_t)q * tok + c] * scale;
-      Gs[r][c] = dout[(((int64_t)b * N + q) * H + head) * HD + c];
-    }
-    if (tid < 64) {
-      const int q = min(q0 + tid, N - 1);
-      Ls[tid] = lse[((int64_t)b * H + head) * N + q];
-      Es[tid] = delta[((int64_t)b * H + head) * N + q];
-    }
-    __syncthreads();
-    float s[4][4], dp[4][4];  // [key i][query j]
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { s[i][j] = 0.f; dp[i][j] = 0.f; }
-    for (int d = 0; d < HD; ++d) {
-      float ka[4], va[4], qb[4], gb[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { ka[i] = Ks[4 * ty + i][d]; va[i] = Vs[4 * ty + i][d]; qb[i] = Qs[4 * tx + i][d]; gb[i] = Gs[4 * tx + i][d]; }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { s[i][j] = fmaf(ka[i], qb[j], s[i][j]); dp[i][j] = fmaf(va[i], gb[j], dp[i][j]); }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int ql = 4 * tx + j;
-        const float pv = (q0 + ql < N) ? __expf(s[i][j] - Ls[ql]) : 0.f;
-        Pt[4 * ty + i][ql] = pv;
-        Dt[4 * ty + i][ql] = pv * (dp[i][j] - Es[ql]);
-      }
-    __syncthreads();
-    for (int q = 0; q < 64; ++q) {
-      float pa[4], da[4], gb[CPT], qb[CPT];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { pa[i] = Pt[4 * ty + i][q]; da[i] = Dt[4 * ty + i][q]; }
-#pragma unroll
-      for (int j = 0; j < CPT; ++j) { gb[j] = Gs[q][CPT * tx + j]; qb[j] = Qs[q][CPT * tx + j]; }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < CPT; ++j) { dv[i][j] = fmaf(pa[i], gb[j], dv[i][j]); dk[i][j] = fmaf(da[i], qb[j], dk[i][j]); }
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int key = k0 + 4 * ty + i;
-    if (key >= N) continue;
-    float* okp = dqkv + ((int64_t)b * N + key) * tok + (int64_t)H * HD + head * HD + CPT * tx;
-    // Qs carried the softmax scale already: dK = dS^T (scale*Q)
-#pragma unroll
-    for (int j = 0; j < CPT; ++j) {
-      okp[j] = dk[i][j];
-      okp[(int64_t)H * HD + j] = dv[i][j];
-    }
   }
 }
 
@@ -412,34 +122,7 @@ int tad_im2col_tubelets_f32(const float* x, float* cols, int B, int C, int T, in
   return check_launch("im2col_f32");
 }
 
-int tad_attn_fwd_f32(const float* qkv, float* out, float* lse, int B, int N, int H, int d, float scale, tad_stream_t stream) {
-  TAD_REQUIRE(qkv && out, "attn_fwd_f32: null pointer");
-  TAD_REQUIRE(d == 64 || d == 80, "attn_fwd_f32: head_dim must be 64 or 80 (got %d)", d);
-  TAD_REQUIRE(B > 0 && N > 0 && H > 0 && H <= 65535 && B <= 65535 && scale > 0.f, "attn_fwd_f32: bad shape");
-  const dim3 grid((N + 63) / 64, H, B);
-  if (d == 64) hipLaunchKernelGGL(attn_fwd_f32_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, qkv, out, lse, N, H, scale);
-  else hipLaunchKernelGGL(attn_fwd_f32_kernel<80>, grid, dim3(256), 0, (hipStream_t)stream, qkv, out, lse, N, H, scale);
-  return check_launch("attn_fwd_f32");
-}
 
-int tad_attn_bwd_f32(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, float* delta, int B, int N, int H,
-                     int d, float scale, tad_stream_t stream) {
-  TAD_REQUIRE(qkv && out && dout && lse && dqkv && delta, "attn_bwd_f32: null pointer");
-  TAD_REQUIRE((d == 64 || d == 80) && B > 0 && N > 0 && H > 0 && H <= 65535 && B <= 65535 && scale > 0.f,
-              "attn_bwd_f32: bad shape (head_dim 64 or 80)");
-  hipStream_t st = (hipStream_t)stream;
-  const int64_t rows = (int64_t)B * N * H;
-  const dim3 dgrid((unsigned)((rows * 16 + 255) / 256)), grid((N + 63) / 64, H, B);
-#define BWD_F32(HD_)                                                                                                     \
-  {                                                                                                                      \
-    hipLaunchKernelGGL(attn_delta_f32_kernel<HD_>, dgrid, dim3(256), 0, st, out, dout, delta, B, N, H);                  \
-    hipLaunchKernelGGL(attn_bwd_dq_f32_kernel<HD_>, grid, dim3(256), 0, st, qkv, dout, lse, delta, dqkv, N, H, scale);   \
-    hipLaunchKernelGGL(attn_bwd_dkv_f32_kernel<HD_>, grid, dim3(256), 0, st, qkv, dout, lse, delta, dqkv, N, H, scale);  \
-  }
-  if (d == 64) BWD_F32(64) else BWD_F32(80)
-#undef BWD_F32
-  return check_launch("attn_bwd_f32");
-}
 
 int tad_gelu_f32(const float* h, float* a, int64_t n, tad_stream_t stream) {
   TAD_REQUIRE(h && a && n > 0, "gelu_f32: bad args");
