@@ -440,7 +440,9 @@ def main():
                                "gflop_per_launch": round(g["flops"] / g["launches"] / 1e9, 2)}
 
     want = set(filter(None, args.only_extras.split(","))) or {"roofline_all", "engine_loop", "fwd_only", "half", "precise", "mae_pretrain", "torch_route"}
-    extras = world == 1 and not args.no_extras and args.mode == "train" and args.graph != 1 and args.precision == "fast"
+    extras = world == 1 and not args.no_extras and args.mode == "train" and args.graph != 1
+    if args.precision != "fast":  # the other modes' objects compare against the bf16 headline: only the per-class table makes sense here
+        want &= {"roofline_all"}
     it_next = args.warmup + args.steps
 
     def timed_steps(n_warm, n):

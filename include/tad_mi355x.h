@@ -204,8 +204,10 @@ int tad_colsum_bf16(const uint16_t* a, float* out, int accumulate, void* ws, siz
 /* y_bf16 = bf16(rowscale[m/rows_per_scale] * gamma[n] * x_f32)  (backward of the residual-branch scale) */
 int tad_scale_cast_bf16(const float* x, uint16_t* y, const float* gamma, const float* rowscale,
                         int rows_per_scale, int64_t M, int N, tad_stream_t stream);
-/* sum of squares of an f32 vector, accumulated into *out (f32, device) -- get_grad_norm_ (utils.py:415-427) */
-int tad_sumsq_f32(const float* x, int64_t n, float* out, tad_stream_t stream);
+/* sum of squares of an f32 vector, accumulated into *out (f32, device) -- get_grad_norm_ (utils.py:415-427).  Deterministic: block
+ * partials in ws (tad_sumsq_workspace_bytes()), added in a fixed order; no atomics. */
+size_t tad_sumsq_workspace_bytes(void);
+int tad_sumsq_f32(const float* x, int64_t n, float* out, void* ws, size_t ws_bytes, tad_stream_t stream);
 
 /* Batched bf16 transpose: every [R,C] matrix of a flat buffer -> [C,R] at the same offset of a second flat buffer, one launch (the
  * transposed operand copies W^T that the input-gradient GEMMs of all Linear layers read; refreshed once per optimizer step).

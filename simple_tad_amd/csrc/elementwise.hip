@@ -423,8 +423,12 @@ __global__ void scale_cast_kernel(const float* __restrict__ x, uint16_t* __restr
   }
 }
 
-// ---------------------------------------------------------------- sum of squares
-__global__ void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+// ---------------------------------------------------------------- sum of squares (deterministic: no atomics)
+// Pass 1: every block leaves the sum of its grid-strided share in partial[block]; pass 2: one block adds the partials in a fixed order
+// and accumulates into *out.  (Round 2 added the block sums with atomicAdd: the gradient norm then differed in its last bits from run
+// to run, and with it the clipping coefficient and every parameter after the first clipped step.)
+constexpr int SUMSQ_MAX_BLOCKS = 1024;
+__global__ void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ partial) {
   __shared__ float red[4];
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   float s = 0.f;
@@ -432,7 +436,16 @@ __global__ void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __re
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void sumsq_finish_kernel(const float* __restrict__ partial, int nblocks, float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nblocks; i += 256) s += partial[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *out += (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // host-callable launcher shared with other translation units
@@ -703,10 +716,16 @@ int tad_scale_cast_bf16(const float* x, uint16_t* y, const float* gamma, const f
 }
 
 #ifndef TAD_OPND_F16  // format-independent: one copy for the library (bf16 pass)
-int tad_sumsq_f32(const float* x, int64_t n, float* out, tad_stream_t stream) {
-  TAD_REQUIRE(x && out && n >= 0, "sumsq: bad args");
+size_t tad_sumsq_workspace_bytes(void) { return (size_t)SUMSQ_MAX_BLOCKS * sizeof(float); }
+
+int tad_sumsq_f32(const float* x, int64_t n, float* out, void* ws, size_t ws_bytes, tad_stream_t stream) {
+  TAD_REQUIRE(x && out && ws && n >= 0, "sumsq: bad args");
+  TAD_REQUIRE(ws_bytes >= tad_sumsq_workspace_bytes(), "sumsq: workspace too small");
   if (n == 0) return TAD_OK;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(capped_grid(n, 256 * 8)), dim3(256), 0, (hipStream_t)stream, x, n, out);
+  int blocks = capped_grid(n, 256 * 8);
+  if (blocks > SUMSQ_MAX_BLOCKS) blocks = SUMSQ_MAX_BLOCKS;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n, (float*)ws);
+  hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)ws, blocks, out);
   return check_launch("sumsq");
 }
 #endif

@@ -132,8 +132,11 @@ class NativeScalerWithGradNormCount:
     scaling is live exactly when the kernels run on IEEE-half operands (``set_precision("half")``) and a no-op (scale 1.0) for the
     bfloat16 and precise modes, whose range is f32's.  GradScaler's defaults and rules: scale 65536, halved after a step whose
     gradients held an inf / NaN (that step is skipped), doubled after 2000 consecutive good steps.  The scale is removed inside the
-    fused AdamW (its ``grad_scale`` operand, together with the clipping coefficient), so no extra pass touches the gradients; as in
-    GradScaler.step, "found inf" is read on the host (one scalar) before the optimizer runs."""
+    fused AdamW (its ``grad_scale`` operand, together with the clipping coefficient), so no extra pass touches the gradients.
+    GradScaler.step reads "found inf" on the host before it calls the optimizer -- a host sync between backward and the optimizer that
+    leaves the GPU idle while the host queues the next launches.  With the fused AdamW the decision is taken ON THE DEVICE instead
+    (``*grad_scale == 0`` skips the update inside the kernel) and the host reads the flag one step late, at the start of the next
+    call -- before the scale is used again, so scale, skipped steps and the optimizer's step counts end up exactly as GradScaler's."""
     state_dict_key = "amp_scaler"
 
     def __init__(self, model: Optional[torch.nn.Module] = None, enabled: Optional[bool] = None, init_scale: float = 65536.0,
@@ -144,6 +147,19 @@ class NativeScalerWithGradNormCount:
         self.growth_factor, self.backoff_factor, self.growth_interval = float(growth_factor), float(backoff_factor), int(growth_interval)
         self.growth_tracker = 0
         self.skipped_steps = 0
+        self._pending = None  # (found-inf flag on the device, optimizer) of the last fused step, not yet read
+
+    def _settle(self):
+        """read the previous fused step's found-inf flag (computed a whole step ago: the GPU is long past it, no bubble) and bring the
+        scale and, after a skipped step, the optimizer's step counts up to date"""
+        if self._pending is None:
+            return
+        flag, optimizer = self._pending
+        self._pending = None
+        found_inf = bool(flag.item())
+        self._update_scale(found_inf)
+        if found_inf:
+            optimizer.rollback_step()
 
     def scaling(self) -> bool:
         return (ops.get_precision() == "half") if self.enabled is None else bool(self.enabled)
@@ -164,6 +180,7 @@ class NativeScalerWithGradNormCount:
         if dp is not None:
             dp.require_sync = bool(update_grad)  # gradient accumulation: exchange only on the last micro-step
         scaling = self.scaling()
+        self._settle()
         (loss * self.scale if scaling else loss).backward(create_graph=create_graph)
         if not update_grad:
             return None
@@ -178,12 +195,11 @@ class NativeScalerWithGradNormCount:
             if clip or scaling:
                 acc = torch.zeros(1, dtype=torch.float32, device=optimizer.flat_grad.device)
                 norm = K.sumsq(optimizer.flat_grad, acc).sqrt()[0] * inv
-                if scaling:
-                    found_inf = not bool(torch.isfinite(norm).item())
-                    self._update_scale(found_inf)
-                    if found_inf:  # GradScaler.step: the optimizer is not called for this step
-                        return norm
                 coef = (torch.clamp(clip_grad / (norm + 1e-6), max=1.0) if clip else torch.ones_like(norm)) * inv
+                if scaling:  # an overflowed step is skipped inside the kernel (grad_scale 0); the flag is read at the next call
+                    bad = ~torch.isfinite(norm)
+                    coef = torch.where(bad, torch.zeros_like(coef), coef)
+                    self._pending = (bad, optimizer)
                 optimizer.step(grad_scale=coef.reshape(1).float())
             else:
                 norm = optimizer.step(want_sumsq=True).sqrt()
@@ -211,6 +227,7 @@ class NativeScalerWithGradNormCount:
 
     def state_dict(self):
         """GradScaler.state_dict()'s keys; ``scale`` reads 1.0 while no scaling is applied (what the engines log as loss_scale)"""
+        self._settle()
         return {"scale": self.scale if self.scaling() else 1.0, "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
                 "growth_interval": self.growth_interval, "_growth_tracker": self.growth_tracker}
 

@@ -584,7 +584,9 @@ def meanpool_bwd(dy, N: int, want_bf16=False):
 
 def sumsq(x, out):
     _req(x, torch.float32, "sumsq.x")
-    check(_lib.load().tad_sumsq_f32(x.data_ptr(), x.numel(), out.data_ptr(), _stream()), "tad_sumsq_f32")
+    lib = _lib.load()
+    ws = workspace(lib.tad_sumsq_workspace_bytes(), x.device)
+    check(lib.tad_sumsq_f32(x.data_ptr(), x.numel(), out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "tad_sumsq_f32")
     return out
 
 

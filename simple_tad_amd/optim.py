@@ -53,6 +53,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self.chunk_group = cg.to(self.space.device)
         self.sumsq_partials = torch.zeros(chunks, dtype=torch.float32, device=self.space.device)
         self.steps = 0
+        self._last_updated = None
         self._ragged = False  # True once parameters carry different update counts (some step ran without their gradient)
         for p in plist:  # torch.optim.AdamW's state layout; the moment tensors alias the flat buffers
             self.state[p] = {"step": torch.tensor(0.0), "exp_avg": self.space.view(self.exp_avg, p),
@@ -149,6 +150,7 @@ class FusedAdamW(torch.optim.Optimizer):
                      param_bf16=self.mirror, grad_scale=grad_scale, sumsq_partials=self.sumsq_partials if want_sumsq else None)
         for p in updated:
             self.state[p]["step"] += 1
+        self._last_updated = updated
         ops.invalidate_weight_cache()
         if self.mirror is not None:
             if self.mirror_t is not None:
@@ -157,6 +159,15 @@ class FusedAdamW(torch.optim.Optimizer):
         if want_sumsq:
             return self.sumsq_partials.sum()
         return loss
+
+    def rollback_step(self):
+        """The last ``step`` turned out to have been skipped ON THE DEVICE (its ``grad_scale`` was 0: the loss scaler found an inf, and
+        the kernel left parameters, moments and operand copies untouched): take its update count back, as torch.optim never counted it."""
+        if self._last_updated:
+            for p in self._last_updated:
+                self.state[p]["step"] -= 1
+            self.steps -= 1
+            self._last_updated = None
 
     def zero_grad(self, set_to_none: bool = False):
         """Gradients are views into the flat buffer and stay allocated: zero in place (one memset)."""

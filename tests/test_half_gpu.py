@@ -280,3 +280,42 @@ def test_half_mode_training_step_follows_the_oracle_with_loss_scaling():
     print("tiny model, |loss - oracle| and grad-norm deviation: ", res)
     assert res["half"][0] < 2e-4 and res["half"][1] < 1e-3
     assert res["half"][1] < res["fast"][1]
+
+
+def test_overflowed_step_is_skipped_on_the_device_and_settled_one_call_later():
+    """GradScaler's rules without its host sync: a loss scale that overflows half makes the gradients inf, the fused AdamW kernel skips
+    the update by itself (grad_scale 0), and the NEXT call halves the scale and takes the optimizer's step count back before anything
+    uses them -- state identical to torch's GradScaler.step / update pair (utils.py:386-412)."""
+    import simple_tad_amd as T
+    from simple_tad_amd import engine
+    import torch.nn.functional as F
+    torch.manual_seed(0)
+    m = T.VisionTransformer(img_size=32, patch_size=16, embed_dim=128, depth=2, num_heads=2, all_frames=4, tubelet_size=2, num_classes=2,
+                            mlp_ratio=4, qkv_bias=True, init_scale=1.0).cuda().train()
+    x, y = torch.randn(4, 3, 4, 32, 32).cuda(), torch.tensor([0, 1, 1, 0]).cuda()
+    T.set_precision("half")
+    try:
+        opt = engine.create_optimizer(m, lr=1e-3, weight_decay=0.05)
+        sc = engine.NativeScalerWithGradNormCount(m, init_scale=2.0 ** 40, growth_interval=2)
+        before = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        n1 = sc(F.cross_entropy(m(x), y), opt, parameters=list(m.parameters()))
+        opt.zero_grad()
+        torch.cuda.synchronize()
+        assert not math.isfinite(float(n1))
+        assert all(torch.equal(v, before[k]) for k, v in m.state_dict().items()), "an overflowed step must leave the parameters untouched"
+        assert float(opt.exp_avg.abs().max()) == 0.0 and opt.steps == 1 and sc.scale == 2.0 ** 40   # (not settled yet)
+        # scale too large again -> second skip; the first one is settled at the start of this call
+        n2 = sc(F.cross_entropy(m(x), y), opt, parameters=list(m.parameters()))
+        opt.zero_grad()
+        assert sc.scale == 2.0 ** 39 and sc.skipped_steps == 1 and opt.steps == 1
+        assert sc.state_dict()["scale"] == 2.0 ** 38 and sc.skipped_steps == 2 and opt.steps == 0 and not math.isfinite(float(n2))
+        assert all(int(opt.state[p]["step"]) == 0 for p in m.parameters())
+        sc.scale = 1024.0  # a workable scale: the step goes through, and two good steps double it (growth_interval 2)
+        for i in range(2):
+            n = sc(F.cross_entropy(m(x), y), opt, parameters=list(m.parameters()))
+            opt.zero_grad()
+            assert math.isfinite(float(n))
+        assert sc.state_dict()["scale"] == 2048.0 and opt.steps == 2 and sc.skipped_steps == 2
+        assert any(not torch.equal(v, before[k]) for k, v in m.state_dict().items())
+    finally:
+        T.set_precision("fast")
