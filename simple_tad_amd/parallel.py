@@ -104,8 +104,12 @@ class DataParallel(nn.Module):
     """Replicated-model data parallelism with bucketed, overlapped gradient all-reduce."""
 
     def __init__(self, module: nn.Module, bucket_mb: float = 64.0, process_group=None, broadcast: bool = True, overlap: bool = True,
-                 reduce_avg: Optional[bool] = None):
-        """``overlap=False``: exchange every bucket in ``finish()`` after backward instead of as soon as its last gradient lands --
+                 reduce_avg: Optional[bool] = None, tail_mb: Optional[float] = 16.0):
+        """``tail_mb``: the buckets that complete LAST (block 0 and the patch embedding: backward produces gradients head first) are cut
+        to this size.  Every earlier bucket's all-reduce runs beside the rest of backward; the last one has nothing left to hide behind,
+        so its size IS the exposed time of the exchange (a ring all-reduce is per-link bound on xGMI: ~64 MiB takes ~1.1 ms at 8
+        ranks, 16 MiB a quarter of that).  None: uniform buckets.
+        ``overlap=False``: exchange every bucket in ``finish()`` after backward instead of as soon as its last gradient lands --
         required for models that use a parameter more than once per backward (weight tying, a module called twice per forward):
         the overlapped exchange announces a parameter after its FIRST gradient write and raises if it sees a second one."""
         super().__init__()
@@ -139,14 +143,22 @@ class DataParallel(nn.Module):
         offs = [self.space.offset[id(p)] for p in order]
         # buckets = contiguous ranges of the flat buffer
         limit = int(bucket_mb * (1 << 20) / self.flat_grad.element_size())
+        tail = int(tail_mb * (1 << 20) / self.flat_grad.element_size()) if tail_mb else 0
+        total = self.space.total
         self.buckets: List[dict] = []
-        start, count = 0, 0
+        start, count, was_tail = 0, 0, False
         for i, (p, o) in enumerate(zip(order, offs)):
             end = o + FlatSpace.padded(p)
+            # the last 2 x tail elements of the buffer go out in buckets of `tail` elements: close the running bucket where that region starts
+            in_tail = bool(tail) and tail < limit and total - o <= 2 * tail
+            if in_tail and not was_tail and o > start:
+                self.buckets.append({"lo": start, "hi": o, "n": count, "ready": 0})
+                start, count = o, 0
+            was_tail = in_tail
             # a parameter marked as never receiving a gradient (a learnable pos_embed that is added detached) stays in the flat
             # layout with a zero gradient but is not waited for: its bucket is announced by the others
             count += 0 if getattr(p, "_tad_never_grad", False) else 1
-            if end - start >= limit or i == len(order) - 1:
+            if end - start >= (tail if in_tail else limit) or i == len(order) - 1:
                 self.buckets.append({"lo": start, "hi": end, "n": count, "ready": 0})
                 start, count = end, 0
         self._bucket_of = {}
