@@ -84,7 +84,8 @@ int tad_patch_embed_fwd(const float* x, const uint16_t* w_bf16, const float* bia
  * reference's normalisation v = (u8/255 - mean[c]) / std[c] in f32 (run_inference.py:15-34 prepare_image; dota.py:443-460
  * tensor_normalize) -- bit-identical to tad_im2col_tubelets on the normalised f32 clip.  mean3 / std3: HOST arrays in RGB order;
  * bgr != 0: channel c is stored at position 2-c (cv2 frames, replaces cv2.cvtColor(BGR2RGB)); t_offset: frame t of the clip is
- * slot (t + t_offset) % T of the buffer (ring buffer for the sliding window of run_inference.py:86-93). */
+ * slot (t + t_offset) % T of the buffer (ring buffer for the sliding window of run_inference.py:86-93).  Any even patch size: rows have
+ * the stride tad_patch_embed_ldk(3, tubelet, patch) (= K for multiples of 8; /14: 1216, padding columns zeroed). */
 int tad_im2col_tubelets_u8(const uint8_t* frames, uint16_t* cols, int B, int T, int H, int W, int tubelet, int patch,
                            const float* mean3, const float* std3, int bgr, int t_offset, tad_stream_t stream);
 /* GEMM part of tad_patch_embed_fwd on an existing patch matrix: out = cols * w^T + bias (+ pos broadcast over the batch) */

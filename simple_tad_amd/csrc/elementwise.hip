@@ -134,6 +134,48 @@ __global__ void im2col_tubelets_u8_kernel(const uint8_t* __restrict__ frames, ui
   }
 }
 
+// The same for even patch sizes that are not multiples of 8 (/14): one thread = 2 pixels = 6 contiguous bytes in, three 4-byte pairs out
+// (a pair never straddles a patch: p and w are even); rows have stride ldk = K rounded up to 64 and the thread that owns k = 0 of a
+// token zeroes the padding columns, as im2col_tubelets_pairs_kernel does for the f32 clip.
+__global__ void im2col_tubelets_u8_pairs_kernel(const uint8_t* __restrict__ frames, uint16_t* __restrict__ cols, int B, int T, int H, int W,
+                                                int tub, int p, int ldk, float m0, float m1, float m2, float s0, float s1, float s2, int bgr,
+                                                int t_offset) {
+  const int W2 = W >> 1;
+  const int64_t total = (int64_t)B * T * H * W2;
+  const int Hp = H / p, Wp = W / p, Tp = T / tub;
+  const int K = 3 * tub * p * p;
+  const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    int64_t r = i;
+    const int w2 = (int)(r % W2); r /= W2;
+    const int h = (int)(r % H); r /= H;
+    const int t = (int)(r % T); r /= T;
+    const int b = (int)r;
+    int slot = t + t_offset;
+    slot = slot >= T ? slot - T : slot;
+    const uint8_t* src = frames + ((((int64_t)b * T + slot) * H + h) * W + (int64_t)w2 * 2) * 3;  // 6 bytes, 2-byte aligned
+    const uint16_t* s2p = reinterpret_cast<const uint16_t*>(src);
+    const uint32_t lo = (uint32_t)s2p[0] | ((uint32_t)s2p[1] << 16);  // bytes 0..3
+    const uint32_t hi = (uint32_t)s2p[2];                             // bytes 4..5
+    const int w = w2 * 2;
+    const int tp = t / tub, kt = t - tp * tub, hp = h / p, kh = h - hp * p, wp = w / p, kw = w - wp * p;
+    const int64_t n = ((int64_t)b * Tp + tp) * Hp * Wp + (int64_t)hp * Wp + wp;
+    uint16_t* row = cols + n * ldk;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int cm = bgr ? 2 - c : c;
+      const int b0 = cm, b1 = 3 + cm;  // byte positions of the two pixels' channel
+      const float u0 = (float)((lo >> (b0 * 8)) & 0xffu);
+      const float u1 = (float)(((b1 < 4 ? lo >> (b1 * 8) : hi >> ((b1 - 4) * 8))) & 0xffu);
+      const int k = ((c * tub + kt) * p + kh) * p + kw;
+      *reinterpret_cast<uint32_t*>(row + k) = pack_op16x2((u0 / 255.0f - mean[c]) / sd[c], (u1 / 255.0f - mean[c]) / sd[c]);
+    }
+    if (kt == 0 && kh == 0 && kw == 0)  // (k = 0 of channel 0)
+      for (int z = K; z < ldk; z += 2) *reinterpret_cast<uint32_t*>(row + z) = 0u;
+  }
+}
+
 // ---------------------------------------------------------------- tubelet im2col
 // x [B,C,T,H,W] f32 -> cols [B*N, K] bf16, token n = (t'*H' + h')*W' + w', k = ((c*tub+kt)*p+kh)*p+kw.
 // One thread moves 8 consecutive w (32 B in, 16 B out); threads walk x in memory order -> coalesced reads.
@@ -643,10 +685,17 @@ int tad_im2col_tubelets_u8(const uint8_t* frames, uint16_t* cols, int B, int T, 
   TAD_REQUIRE(frames && cols && mean3 && std3, "im2col_u8: null pointer");
   TAD_REQUIRE(B > 0 && tubelet > 0 && patch > 0 && T % tubelet == 0 && H % patch == 0 && W % patch == 0,
               "im2col_u8: T/H/W must be multiples of tubelet/patch (got T=%d H=%d W=%d tub=%d p=%d)", T, H, W, tubelet, patch);
-  TAD_REQUIRE(patch % 8 == 0, "im2col_u8: patch size must be a multiple of 8 (got %d)", patch);
+  TAD_REQUIRE(patch % 2 == 0, "im2col_u8: patch size must be even (got %d)", patch);
   TAD_REQUIRE(t_offset >= 0 && t_offset < T, "im2col_u8: t_offset=%d outside [0, %d)", t_offset, T);
   TAD_REQUIRE(std3[0] != 0.f && std3[1] != 0.f && std3[2] != 0.f, "im2col_u8: zero std");
   TAD_REQUIRE((((uintptr_t)frames) & 3) == 0 && (((uintptr_t)cols) & 15) == 0, "im2col_u8: misaligned buffers");
+  if (patch % 8) {  // rows of stride tad_patch_embed_ldk, zero-padded (ViT-L/14: K = 1176 -> 1216)
+    const int ldk = tad_patch_embed_ldk(3, tubelet, patch);
+    const int64_t pairs = (int64_t)B * T * H * (W / 2);
+    hipLaunchKernelGGL(im2col_tubelets_u8_pairs_kernel, dim3(capped_grid(pairs, 256)), dim3(256), 0, (hipStream_t)stream, frames, cols, B, T,
+                       H, W, tubelet, patch, ldk, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], bgr ? 1 : 0, t_offset);
+    return check_launch("im2col_tubelets_u8");
+  }
   const int64_t total = (int64_t)B * T * H * (W / 8);
   hipLaunchKernelGGL(im2col_tubelets_u8_kernel, dim3(capped_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, frames, cols, B, T, H,
                      W, tubelet, patch, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], bgr ? 1 : 0, t_offset);

@@ -288,7 +288,7 @@ def im2col_tubelets_u8(frames: torch.Tensor, tubelet: int, patch: int, mean, std
         raise _lib.TadError(f"im2col_u8: frames must be [B,T,H,W,3] uint8, got {tuple(frames.shape)}")
     B, T, H, W, _ = frames.shape
     ntok = (T // tubelet) * (H // patch) * (W // patch)
-    cols = torch.empty((B * ntok, 3 * tubelet * patch * patch), dtype=dtype or _op16, device=frames.device)
+    cols = torch.empty((B * ntok, patch_embed_ldk(3, tubelet, patch)), dtype=dtype or _op16, device=frames.device)
     m = (C.c_float * 3)(*[float(v) for v in mean])
     s = (C.c_float * 3)(*[float(v) for v in std])
     with _timed("im2col_u8", 0.0, float(frames.numel()) + 2.0 * cols.numel()):

@@ -350,9 +350,9 @@ class PatchEmbedU8Fn(_Fn):
         _need_gpu(frames, "PatchEmbed")
         fr = frames if frames.is_contiguous() else frames.contiguous()
         B, T, H, W, _ = fr.shape
-        cols = K.im2col_tubelets_u8(fr, tubelet, patch, mean, std, bgr, t_offset)
+        cols = K.im2col_tubelets_u8(fr, tubelet, patch, mean, std, bgr, t_offset)   # row stride tad_patch_embed_ldk (zero-padded for /14)
         ntok = (T // tubelet) * (H // patch) * (W // patch)
-        out = K.patch_embed_gemm(cols, w_bf16(weight, _differentiated(ctx)), _f32c(bias), _f32c(pos), ntok)
+        out = K.patch_embed_gemm(cols, K.pad_k(w_bf16(weight, _differentiated(ctx)), cols.shape[1]), _f32c(bias), _f32c(pos), ntok)
         ctx.save_for_backward(cols)
         ctx.params = (weight, bias)
         return out
@@ -362,6 +362,10 @@ class PatchEmbedU8Fn(_Fn):
         (cols,) = ctx.saved_tensors
         weight, bias = ctx.params
         dyb = K.cast_bf16(_f32c(dy).reshape(-1, dy.shape[-1]))
+        kw = weight.numel() // weight.shape[0]
+        if cols.shape[1] != kw:  # padded K (see PatchEmbedFn.backward)
+            dWp, db = K.linear_bwd_weight(dyb, cols, want_bias=bias is not None)
+            return None, dWp[:, :kw].reshape(weight.shape), db, None, None, None, None, None, None, None
         dW, db = linear_dw(dyb, cols, weight, bias)
         return None, (None if dW is None else dW.reshape(weight.shape)), db, None, None, None, None, None, None, None
 

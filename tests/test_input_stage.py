@@ -112,3 +112,41 @@ def test_model_on_uint8_frames_and_sliding_window():
     m.zero_grad()
     m(xf.cuda()).sum().backward()
     assert torch.equal(g_u8, m.patch_embed.proj.weight.grad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bgr", [False, True])
+def test_u8_patch_matrix_for_patch_14_bit_exact_and_model_equal(bgr):
+    """Patch sizes that are even but not multiples of 8 (BASELINE configs[4] says ViT-L/14): the uint8 input stage writes the same
+    zero-padded patch matrix (row stride tad_patch_embed_ldk: 1176 -> 1216) as the f32 path does from the reference's normalised clip,
+    bit for bit, and the model's logits and patch-embed gradient on uint8 frames equal the float path's."""
+    import simple_tad_amd as T
+    from simple_tad_amd import kernels as K
+    B, T_, H, W = 2, 4, 28, 42
+    frames = R.uint8_for("u8p14.frames", (B, T_, H, W, 3))
+    ref = torch.stack([torch.stack([O.prepare_image(frames[b, t].numpy() if bgr else frames[b, t].numpy()[..., ::-1], MEAN, STD)
+                                    for t in range(T_)], dim=1) for b in range(B)])
+    want = K.im2col_tubelets(ref.cuda().contiguous(), 2, 14)
+    got = K.im2col_tubelets_u8(frames.cuda(), 2, 14, MEAN, STD, bgr=bgr)
+    assert got.shape == want.shape == (B * 2 * 2 * 3, 1216) and torch.equal(got.view(torch.int16), want.view(torch.int16))
+    assert float(got[:, 1176:].float().abs().max()) == 0.0
+    off = 1
+    assert torch.equal(K.im2col_tubelets_u8(torch.roll(frames, shifts=off, dims=1).cuda(), 2, 14, MEAN, STD, bgr=bgr, t_offset=off), got)
+    # the half format takes the same route
+    assert torch.equal(K.im2col_tubelets_u8(frames.cuda(), 2, 14, MEAN, STD, bgr=bgr, dtype=torch.float16),
+                       K.im2col_tubelets(ref.cuda().contiguous(), 2, 14, dtype=torch.float16))
+    if bgr:
+        return
+    torch.manual_seed(0)
+    m = T.VisionTransformer(img_size=28, patch_size=14, embed_dim=128, depth=1, num_heads=2, mlp_ratio=4, qkv_bias=True, all_frames=4,
+                            tubelet_size=2, num_classes=2, init_scale=1.0).cuda().train()
+    m.patch_embed.set_input_normalization(MEAN, STD, bgr=False)
+    clip = R.uint8_for("u8p14.clip", (2, 4, 28, 28, 3))
+    xf = torch.stack([O.tensor_normalize(clip[b], MEAN, STD).permute(3, 0, 1, 2) for b in range(2)]).contiguous()
+    y8 = m(clip.cuda())
+    y8.sum().backward()
+    g8 = m.patch_embed.proj.weight.grad.clone()
+    m.zero_grad()
+    yf = m(xf.cuda())
+    yf.sum().backward()
+    assert torch.equal(y8, yf) and torch.equal(g8, m.patch_embed.proj.weight.grad)
