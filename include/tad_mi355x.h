@@ -274,13 +274,17 @@ int tad_threshold_histogram(const float* probs, const int32_t* labels, const flo
 int tad_split_bf16x3(const float* x, uint16_t* out, int64_t M, int K, int role_b, int stack, tad_stream_t stream);
 int tad_im2col_tubelets_f32(const float* x, float* cols, int B, int C, int T, int H, int W, int tubelet, int patch,
                             tad_stream_t stream);
-/* qkv [B,N,3,H,64] f32 -> out [B,N,H,64] f32, lse [B,H,N] (nullable) */
-int tad_attn_fwd_f32(const float* qkv, float* out, float* lse, int B, int N, int H, int d, float scale, tad_stream_t stream);
+/* f32 attention on the matrix pipe (exact-f32 MFMA), head dim d = 64 or 80: qkv [B,N,3,H,d] f32 -> out [B,N,H,d] f32, lse [B,H,N]
+ * (nullable).  dropout_p in [0, 1): nn.Dropout on the softmax matrix (modeling_finetune.py:99-101; flash_attention_class.py:59-61) --
+ * element (b, h, query, key) is kept iff lowbias32(row * 0x9E3779B1 + key * 0x85EBCA77 + seed) >= dropout_p * 2^32 with
+ * row = (b H + h) N + query, kept probabilities scaled by 1 / (1 - dropout_p); the backward regenerates the same bits from (p, seed). */
+int tad_attn_fwd_f32(const float* qkv, float* out, float* lse, int B, int N, int H, int d, float scale, float dropout_p, uint32_t seed,
+                     tad_stream_t stream);
 
 /* precise-mode backward pieces: f32 attention backward (dqkv [B,N,3,H,64] f32 fully overwritten; delta [B,H,N] scratch),
  * erf-GELU forward / backward on f32, column sums of an f32 matrix (bias gradients). */
 int tad_attn_bwd_f32(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, float* delta,
-                     int B, int N, int H, int d, float scale, tad_stream_t stream);
+                     int B, int N, int H, int d, float scale, float dropout_p, uint32_t seed, tad_stream_t stream);
 int tad_gelu_f32(const float* h, float* a, int64_t n, tad_stream_t stream);
 int tad_gelu_bwd_f32(const float* dy, const float* h, float* dh, int64_t n, tad_stream_t stream);
 int tad_colsum_f32(const float* a, float* out, int64_t M, int N, tad_stream_t stream);

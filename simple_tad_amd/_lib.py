@@ -63,8 +63,8 @@ SIGNATURES = {
     "tad_threshold_histogram": (_i, [_vp, _vp, _vp, _i, _i64, _vp, _vp]),
     "tad_split_bf16x3": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp]),
     "tad_im2col_tubelets_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    "tad_attn_fwd_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
-    "tad_attn_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "tad_attn_fwd_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, C.c_uint32, _vp]),
+    "tad_attn_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, C.c_uint32, _vp]),
     "tad_gelu_f32": (_i, [_vp, _vp, _i64, _vp]),
     "tad_gelu_bwd_f32": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "tad_colsum_f32": (_i, [_vp, _vp, _i64, _i, _vp]),

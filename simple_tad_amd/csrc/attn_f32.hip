@@ -42,6 +42,20 @@ __device__ __forceinline__ float swap_sum(float x) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// Attention dropout (nn.Dropout on the softmax matrix, modeling_finetune.py:99-101; flash_attention_class.py:59-61 passes dropout_p in
+// training): element (b, h, query, key) is kept iff hash(row, key, seed) >= p * 2^32, row = (b H + h) N + query, and kept
+// probabilities are scaled by 1 / (1 - p).  A counter-based hash instead of a stored N x N mask: the three kernels regenerate the
+// same bits, and so does the oracle (oracle/vit_oracle.py: attention_dropout_keep) -- parity by injected mask, as for drop-path.
+struct Drop {
+  uint32_t thr, seed;
+  float inv_keep;
+};
+__device__ __forceinline__ bool drop_keep(const Drop& d, uint32_t row, uint32_t key) {
+  uint32_t x = row * 0x9E3779B1u + key * 0x85EBCA77u + d.seed;
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return x >= d.thr;
+}
+
 // stage 32 rows x HD floats (row `first + r` of a [rows][row_stride] f32 tensor, clamped to `last`) into tile[32][STRIDE], times mul
 template <int HD>
 __device__ __forceinline__ void stage_rows(float* tile, const float* src, int64_t row_stride, int first, int last, float mul, int tid) {
@@ -82,9 +96,9 @@ __device__ __forceinline__ void mfma_cols(f32x16 (&out)[AttnF32<HD>::NDT], const
 }
 
 // ------------------------------------------------------------------------------------------------------------------------- forward
-template <int HD>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_fwd_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out, float* __restrict__ lse,
-                                                              int N, int H, float scale) {
+                                                              int N, int H, float scale, const Drop drop) {
   using C = AttnF32<HD>;
   __shared__ __attribute__((aligned(16))) float Kt[32 * C::STRIDE], Vt[32 * C::STRIDE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ql = lane & 31, h = lane >> 5;
@@ -126,8 +140,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_f32_kernel(const float* __res
       s[r] = fast_exp2(s[r] - m_new);
       ps += s[r];
     }
-    l_run = l_run * alpha + swap_sum(ps);
+    l_run = l_run * alpha + swap_sum(ps);   // the normaliser is the sum of the UN-dropped probabilities
     m_run = m_new;
+    if (DROP) {
+      const uint32_t row = (uint32_t)((b * H + head) * N + qrow);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = drop_keep(drop, row, (uint32_t)(kv0 + acc_row(r, h))) ? s[r] * drop.inv_keep : 0.f;
+    }
 #pragma unroll
     for (int dt = 0; dt < C::NDT; ++dt)
 #pragma unroll
@@ -149,10 +168,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_f32_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------------------------------------------------------------- dQ (+ delta)
-template <int HD>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
                                                                  const float* __restrict__ dout, const float* __restrict__ lse,
-                                                                 float* __restrict__ delta, float* __restrict__ dqkv, int N, int H, float scale) {
+                                                                 float* __restrict__ delta, float* __restrict__ dqkv, int N, int H, float scale,
+                                                                 const Drop drop) {
   using C = AttnF32<HD>;
   __shared__ __attribute__((aligned(16))) float Kt[32 * C::STRIDE], Vt[32 * C::STRIDE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ql = lane & 31, h = lane >> 5;
@@ -192,7 +212,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_f32_kernel(const float* __
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float p = (kv0 + acc_row(r, h) < N) ? fast_exp2(s[r] - lse2) : 0.f;
-      s[r] = p * (dp[r] - dlt);  // dS^T
+      float dpr = dp[r];  // d(loss) / d(dropped probability); through the dropout: x mask / (1 - p)
+      if (DROP) dpr = drop_keep(drop, (uint32_t)((b * H + head) * N + qrow), (uint32_t)(kv0 + acc_row(r, h))) ? dpr * drop.inv_keep : 0.f;
+      s[r] = p * (dpr - dlt);  // dS^T
     }
     mfma_cols<HD>(dq, Kt, s, ql, h);
   }
@@ -209,10 +231,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_f32_kernel(const float* __
 }
 
 // ------------------------------------------------------------------------------------------------------------------------- dK, dV
-template <int HD>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                   const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                  float* __restrict__ dqkv, int N, int H, float scale) {
+                                                                  float* __restrict__ dqkv, int N, int H, float scale, const Drop drop) {
   using C = AttnF32<HD>;
   __shared__ __attribute__((aligned(16))) float Qt[32 * C::STRIDE], Gt[32 * C::STRIDE], Ls[32], Ds[32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kl = lane & 31, h = lane >> 5;
@@ -257,8 +279,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_f32_kernel(const float* _
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float p = fast_exp2(s[4 * r4 + e] - la[e]);
-        s[4 * r4 + e] = p;                              // P
-        dp[4 * r4 + e] = p * (dp[4 * r4 + e] - da[e]);  // dS
+        float pd = p, dpr = dp[4 * r4 + e];
+        if (DROP) {
+          const bool keep = drop_keep(drop, (uint32_t)((b * H + head) * N + min(qt0 + 8 * r4 + 4 * h + e, N - 1)), (uint32_t)krow);
+          pd = keep ? p * drop.inv_keep : 0.f;
+          dpr = keep ? dpr * drop.inv_keep : 0.f;
+        }
+        s[4 * r4 + e] = pd;                     // dropped P (what multiplied V in the forward)
+        dp[4 * r4 + e] = p * (dpr - da[e]);     // dS
       }
     }
     mfma_cols<HD>(dv, Gt, s, kl, h);    // dV^T += dO^T P
@@ -287,31 +315,49 @@ using namespace tad;
 
 extern "C" {
 
-int tad_attn_fwd_f32(const float* qkv, float* out, float* lse, int B, int N, int H, int d, float scale, tad_stream_t stream) {
+static bool make_drop(float p, uint32_t seed, Drop* d) {
+  if (!(p >= 0.f && p < 1.f)) return false;
+  d->thr = (uint32_t)((double)p * 4294967296.0);
+  d->seed = seed;
+  d->inv_keep = 1.f / (1.f - p);
+  return true;
+}
+
+int tad_attn_fwd_f32(const float* qkv, float* out, float* lse, int B, int N, int H, int d, float scale, float dropout_p, uint32_t seed,
+                     tad_stream_t stream) {
   TAD_REQUIRE(qkv && out, "attn_fwd_f32: null pointer");
   TAD_REQUIRE(d == 64 || d == 80, "attn_fwd_f32: head_dim must be 64 or 80 (got %d)", d);
-  TAD_REQUIRE(B > 0 && N > 0 && H > 0 && H <= 65535 && B <= 65535, "attn_fwd_f32: bad shape");
+  TAD_REQUIRE(B > 0 && N > 0 && H > 0 && H <= 65535 && B <= 65535 && (int64_t)B * H * N < (1ll << 32), "attn_fwd_f32: bad shape");
   TAD_REQUIRE(scale > 0.f, "attn_fwd_f32: scale must be positive");
+  Drop drop;
+  TAD_REQUIRE(make_drop(dropout_p, seed, &drop), "attn_fwd_f32: dropout_p=%g outside [0, 1)", (double)dropout_p);
   const dim3 grid((N + 127) / 128, H, B);
-  if (d == 64) hipLaunchKernelGGL((attn_fwd_f32_kernel<64>), grid, dim3(256), 0, (hipStream_t)stream, qkv, out, lse, N, H, scale);
-  else hipLaunchKernelGGL((attn_fwd_f32_kernel<80>), grid, dim3(256), 0, (hipStream_t)stream, qkv, out, lse, N, H, scale);
+#define FWD(HD_, DR_) hipLaunchKernelGGL((attn_fwd_f32_kernel<HD_, DR_>), grid, dim3(256), 0, (hipStream_t)stream, qkv, out, lse, N, H, scale, drop)
+  if (d == 64) { if (dropout_p > 0.f) FWD(64, true); else FWD(64, false); }
+  else { if (dropout_p > 0.f) FWD(80, true); else FWD(80, false); }
+#undef FWD
   return check_launch("attn_fwd_f32");
 }
 
 int tad_attn_bwd_f32(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, float* delta, int B, int N, int H,
-                     int d, float scale, tad_stream_t stream) {
+                     int d, float scale, float dropout_p, uint32_t seed, tad_stream_t stream) {
   TAD_REQUIRE(qkv && out && dout && lse && dqkv && delta, "attn_bwd_f32: null pointer");
   TAD_REQUIRE(d == 64 || d == 80, "attn_bwd_f32: head_dim must be 64 or 80 (got %d)", d);
-  TAD_REQUIRE(B > 0 && N > 0 && H > 0 && H <= 65535 && B <= 65535, "attn_bwd_f32: bad shape");
+  TAD_REQUIRE(B > 0 && N > 0 && H > 0 && H <= 65535 && B <= 65535 && (int64_t)B * H * N < (1ll << 32), "attn_bwd_f32: bad shape");
   TAD_REQUIRE(scale > 0.f, "attn_bwd_f32: scale must be positive");
+  Drop drop;
+  TAD_REQUIRE(make_drop(dropout_p, seed, &drop), "attn_bwd_f32: dropout_p=%g outside [0, 1)", (double)dropout_p);
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((N + 127) / 128, H, B);
-  if (d == 64) hipLaunchKernelGGL((attn_bwd_dq_f32_kernel<64>), grid, dim3(256), 0, st, qkv, out, dout, lse, delta, dqkv, N, H, scale);
-  else hipLaunchKernelGGL((attn_bwd_dq_f32_kernel<80>), grid, dim3(256), 0, st, qkv, out, dout, lse, delta, dqkv, N, H, scale);
+#define DQ(HD_, DR_) hipLaunchKernelGGL((attn_bwd_dq_f32_kernel<HD_, DR_>), grid, dim3(256), 0, st, qkv, out, dout, lse, delta, dqkv, N, H, scale, drop)
+#define DKV(HD_, DR_) hipLaunchKernelGGL((attn_bwd_dkv_f32_kernel<HD_, DR_>), grid, dim3(256), 0, st, qkv, dout, lse, delta, dqkv, N, H, scale, drop)
+  const bool dr = dropout_p > 0.f;
+  if (d == 64) { if (dr) DQ(64, true); else DQ(64, false); } else { if (dr) DQ(80, true); else DQ(80, false); }
   int rc = check_launch("attn_bwd_dq_f32");
   if (rc) return rc;
-  if (d == 64) hipLaunchKernelGGL((attn_bwd_dkv_f32_kernel<64>), grid, dim3(256), 0, st, qkv, dout, lse, delta, dqkv, N, H, scale);
-  else hipLaunchKernelGGL((attn_bwd_dkv_f32_kernel<80>), grid, dim3(256), 0, st, qkv, dout, lse, delta, dqkv, N, H, scale);
+  if (d == 64) { if (dr) DKV(64, true); else DKV(64, false); } else { if (dr) DKV(80, true); else DKV(80, false); }
+#undef DQ
+#undef DKV
   return check_launch("attn_bwd_dkv_f32");
 }
 

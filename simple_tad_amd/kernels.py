@@ -732,19 +732,20 @@ def im2col_tubelets_f32(x, tubelet: int, patch: int):
     return cols
 
 
-def attn_fwd_f32(qkv, B: int, N: int, H: int, scale: float, want_lse=False, d: int = 64):
-    """f32 attention (precise mode; head dims without an MFMA kernel: d = 80)"""
+def attn_fwd_f32(qkv, B: int, N: int, H: int, scale: float, want_lse=False, d: int = 64, drop_p: float = 0.0, seed: int = 0):
+    """f32 attention on the matrix pipe (precise mode; head dims without a 16-bit kernel: d = 80; attention dropout: drop_p, seed)"""
     _req(qkv, torch.float32, "attn_f32.qkv")
     if qkv.numel() != B * N * 3 * H * d:
         raise _lib.TadError("attn_fwd_f32: qkv element count mismatch")
     out = torch.empty((B * N, H * d), dtype=torch.float32, device=qkv.device)
     lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device) if want_lse else None
     with _timed("attn_f32", 4.0 * B * H * N * N * d, 4.0 * 4 * B * N * H * d):
-        check(_lib.load().tad_attn_fwd_f32(qkv.data_ptr(), out.data_ptr(), _p(lse), B, N, H, int(d), float(scale), _stream()), "tad_attn_fwd_f32")
+        check(_lib.load().tad_attn_fwd_f32(qkv.data_ptr(), out.data_ptr(), _p(lse), B, N, H, int(d), float(scale), float(drop_p),
+                                           int(seed) & 0xffffffff, _stream()), "tad_attn_fwd_f32")
     return out, lse
 
 
-def attn_bwd_f32(qkv, out, dout, lse, B: int, N: int, H: int, scale: float, d: int = 64):
+def attn_bwd_f32(qkv, out, dout, lse, B: int, N: int, H: int, scale: float, d: int = 64, drop_p: float = 0.0, seed: int = 0):
     for t, n in ((qkv, "qkv"), (out, "out"), (dout, "dout"), (lse, "lse")):
         _req(t, torch.float32, "attn_bwd_f32." + n)
     if qkv.numel() != B * N * 3 * H * d or out.numel() != B * N * H * d or dout.numel() != out.numel():
@@ -753,7 +754,7 @@ def attn_bwd_f32(qkv, out, dout, lse, B: int, N: int, H: int, scale: float, d: i
     delta = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
     with _timed("attn_f32", 8.0 * B * H * N * N * d, 4.0 * 8 * B * N * H * d):
         check(_lib.load().tad_attn_bwd_f32(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), delta.data_ptr(),
-                                           B, N, H, int(d), float(scale), _stream()), "tad_attn_bwd_f32")
+                                           B, N, H, int(d), float(scale), float(drop_p), int(seed) & 0xffffffff, _stream()), "tad_attn_bwd_f32")
     return dqkv
 
 

@@ -129,21 +129,29 @@ class Attention(nn.Module):
 
     def _check(self):
         if self.head_dim not in (64, 80):
-            raise TadError(f"Attention: head_dim {self.head_dim} has no kernel (64: fused bf16 MFMA kernels; 80: generic f32 kernels)")
+            raise TadError(f"Attention: head_dim {self.head_dim} has no kernel (64: fused 16-bit MFMA kernels; 64 / 80: exact-f32 MFMA kernels)")
+
+    def _dropout(self):
+        """(p, seed) of attention dropout for this forward (modeling_finetune.py:99-101; the flash path passes dropout_p in training,
+        flash_attention_class.py:59-61): active in training only; the seed of the kernels' counter-based mask is drawn from torch's
+        default generator, so runs are reproducible under torch.manual_seed.  The reference's jobs all use attn_drop_rate = 0."""
         if self.training and self.attn_drop.p > 0:
-            raise TadError("Attention: attn_drop > 0 in training is not supported by the fused kernel (reference jobs use 0)")
+            return float(self.attn_drop.p), int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        return 0.0, 0
 
     def forward(self, x):
         self._check()
         if ops.get_precision() == "precise":
             ops._need_gpu(x, "Attention")
             ops._no_grad_only(x, self.qkv.weight)
+            if self.training and self.attn_drop.p > 0:
+                raise TadError('precision "precise" has no attention dropout (verification runs use attn_drop_rate = 0)')
             B, N, C = x.shape
             y = ops.precise_attention(x.detach().float().reshape(B * N, C).contiguous(), B, N, self.qkv.weight, self.q_bias, self.v_bias,
                                       self.proj.weight, self.proj.bias, self.num_heads, self.scale)
             return self.proj_drop(y.reshape(B, N, -1))
         x = ops.AttentionFn.apply(x, self.qkv.weight, self.q_bias, self.v_bias, self.proj.weight, self.proj.bias, self.num_heads,
-                                  self.scale)
+                                  self.scale, *self._dropout())
         return self.proj_drop(x)
 
 
@@ -169,7 +177,7 @@ class Block(nn.Module):
     def _fusable(self):
         return (self.gamma_1 is None and isinstance(self.norm1, nn.LayerNorm) and isinstance(self.norm2, nn.LayerNorm)
                 and self.norm1.elementwise_affine and self.norm2.elementwise_affine and self.norm1.eps == self.norm2.eps
-                and not (self.training and (self.mlp.drop.p > 0 or self.attn.proj_drop.p > 0)))
+                and not (self.training and (self.mlp.drop.p > 0 or self.attn.proj_drop.p > 0 or self.attn.attn_drop.p > 0)))
 
     def forward(self, x):
         if self._fusable() and ops.get_precision() == "precise":

@@ -385,27 +385,29 @@ def set_attn_exact_delta(on: bool):
     _attn_exact_delta = bool(on)
 
 
-def _attn_fwd_core(xn, qkv_w, q_bias, v_bias, B, N, H, scale, train):
-    """returns qkv, attention output, (lse, rounding residual of the output | None)"""
+def _attn_fwd_core(xn, qkv_w, q_bias, v_bias, B, N, H, scale, train, drop=(0.0, 0)):
+    """returns qkv, attention output, (lse, rounding residual of the output | None).  drop = (p, seed) of attention dropout."""
     qb = None if q_bias is None else _f32c(q_bias.detach())
     vb = None if v_bias is None else _f32c(v_bias.detach())
     hd = head_dim_of(qkv_w, H)
-    if hd != 64:
-        # Head dims without an MFMA attention kernel (80: the "huge" configurations, modeling_finetune.py:390-398): the Linears stay on
-        # the bf16 MFMA GEMMs, the scaled-dot-product core runs through the generic f32 kernels (csrc/precise.hip) on an f32 qkv.
+    if hd != 64 or drop[0] > 0.0:
+        # Head dims without a 16-bit attention kernel (80: the "huge" configurations, modeling_finetune.py:390-398) and attention dropout
+        # (attn_drop > 0 in training, :99-101): the Linears stay on the 16-bit MFMA GEMMs, the scaled-dot-product core runs through the
+        # exact-f32 MFMA kernels (csrc/attn_f32.hip) on an f32 qkv.
         qkv = K.linear_fwd_qkv(xn, w_bf16(qkv_w, train), qb, vb, out_dtype=torch.float32)
-        ao32, lse = K.attn_fwd_f32(qkv, B, N, H, scale, want_lse=train, d=hd)
+        ao32, lse = K.attn_fwd_f32(qkv, B, N, H, scale, want_lse=train, d=hd, drop_p=drop[0], seed=drop[1])
         return qkv, K.cast_bf16(ao32), (lse, None)
     qkv = K.linear_fwd_qkv(xn, w_bf16(qkv_w, train), qb, vb, out_dtype=None)
     r = K.attn_fwd(qkv, B, N, H, scale, out_dtype=None, want_lse=train, want_lo=train and _attn_exact_delta)
     return qkv, r[0], (r[1], r[2] if len(r) > 2 else None)
 
 
-def _attn_bwd_core(d_ao, xn, qkv, ao, lse, qkv_w, has_qkv_bias, B, N, H, scale, dx_dtype, qv_params=None, ao_lo=None):
+def _attn_bwd_core(d_ao, xn, qkv, ao, lse, qkv_w, has_qkv_bias, B, N, H, scale, dx_dtype, qv_params=None, ao_lo=None, drop=(0.0, 0)):
     """returns dxn, dWqkv, dq_bias, dv_bias (None for what went into gradient sinks)"""
     D = xn.shape[1]
     if qkv.dtype == torch.float32:  # generic head dim (see _attn_fwd_core)
-        dqkv = K.cast_bf16(K.attn_bwd_f32(qkv, ao.float(), d_ao.float(), lse, B, N, H, scale, d=head_dim_of(qkv_w, H)))
+        dqkv = K.cast_bf16(K.attn_bwd_f32(qkv, ao.float(), d_ao.float(), lse, B, N, H, scale, d=head_dim_of(qkv_w, H), drop_p=drop[0],
+                                          seed=drop[1]))
     else:
         dqkv = K.attn_bwd(qkv, ao, d_ao, lse, B, N, H, scale, out_lo=ao_lo)
     dxn = K.linear_bwd_input(dqkv, wT_bf16(qkv_w, True), out_dtype=dx_dtype)
@@ -430,12 +432,13 @@ class AttentionFn(_Fn):
     """Attention.forward (modeling_finetune.py:86-134): qkv Linear, scaled-dot-product space-time attention, proj."""
 
     @staticmethod
-    def forward(ctx, x, qkv_w, q_bias, v_bias, proj_w, proj_b, H, scale):
+    def forward(ctx, x, qkv_w, q_bias, v_bias, proj_w, proj_b, H, scale, drop_p=0.0, drop_seed=0):
         _need_gpu(x, "Attention")
         B, N, C = x.shape
         train = _differentiated(ctx)
+        ctx.drop = (float(drop_p), int(drop_seed))
         xb = K.cast_bf16(_f32c(x).reshape(B * N, C))
-        qkv, ao, (lse, ao_lo) = _attn_fwd_core(xb, qkv_w, q_bias, v_bias, B, N, H, scale, train)
+        qkv, ao, (lse, ao_lo) = _attn_fwd_core(xb, qkv_w, q_bias, v_bias, B, N, H, scale, train, ctx.drop)
         y, _ = K.linear_fwd(ao, w_bf16(proj_w, train), _f32c(proj_b), out_dtype=torch.float32)
         if train:
             ctx.save_for_backward(xb, qkv, ao, lse, qkv_w, proj_w, ao_lo)
@@ -451,8 +454,9 @@ class AttentionFn(_Fn):
         dyb = K.cast_bf16(_f32c(dy).reshape(B * N, -1))
         d_ao = K.linear_bwd_input(dyb, wT_bf16(proj_w, True))
         dWp, dbp = linear_dw(dyb, ao, proj_w, ctx.proj_b)
-        dx, dWqkv, dqb, dvb = _attn_bwd_core(d_ao, xb, qkv, ao, lse, qkv_w, has_qb, B, N, H, scale, torch.float32, ctx.qv, ao_lo=ao_lo)
-        return dx.reshape(B, N, -1), dWqkv, dqb, dvb, dWp, dbp, None, None
+        dx, dWqkv, dqb, dvb = _attn_bwd_core(d_ao, xb, qkv, ao, lse, qkv_w, has_qb, B, N, H, scale, torch.float32, ctx.qv, ao_lo=ao_lo,
+                                             drop=ctx.drop)
+        return dx.reshape(B, N, -1), dWqkv, dqb, dvb, dWp, dbp, None, None, None, None
 
 
 class MlpFn(_Fn):

@@ -432,3 +432,52 @@ def test_linear_taller_than_the_32bit_epilogue_offsets(K):
     # bf16 output of the same shape stays ONE launch range (1.1 GB < 2 GiB with 2-byte elements): exercised for the cap arithmetic
     yb, _ = K.linear_fwd(x, w, b, out_dtype=torch.bfloat16)
     assert torch.equal(yb[-300:].float(), K.linear_fwd(x[-300:].contiguous(), w, b, out_dtype=torch.bfloat16)[0].float())
+
+
+# ------------------------------------------------------------------ attention dropout (modeling_finetune.py:99-101; flash_attention_class.py:59-61)
+@pytest.mark.parametrize("d,H", [(64, 2), (80, 2)])
+def test_attention_dropout_f32_vs_oracle_with_the_injected_mask(K, d, H):
+    """attn_drop inside attention: the kernels' counter-based keep mask, regenerated by the oracle (attention_dropout_keep) and injected
+    into the reference formula softmax(q k^T) -> dropout -> @ v, forward and backward; ragged N; and the mask's statistics."""
+    B, N, p, seed = 2, 200, 0.25, 1234567
+    scale = d ** -0.5
+    qkv = R.tensor_for(f"attdrop.qkv{d}", (B, N, 3 * H * d), scale=1.0)
+    dout = R.tensor_for(f"attdrop.do{d}", (B, N, H * d))
+    qd = qkv.double().requires_grad_()
+    ref = O.attention_core(qd, H, scale, drop_p=p, seed=seed)
+    ref.backward(dout.double())
+    out, lse = K.attn_fwd_f32(dev(qkv.reshape(B * N, -1)), B, N, H, scale, want_lse=True, d=d, drop_p=p, seed=seed)
+    check(out.reshape(B, N, -1), ref, tol=1e-5, what="attn dropout fwd")
+    dqkv = K.attn_bwd_f32(dev(qkv.reshape(B * N, -1)), out, dev(dout.reshape(B * N, -1)), lse, B, N, H, scale, d=d, drop_p=p, seed=seed)
+    check(dqkv.reshape(B, N, -1), qd.grad, tol=2e-5, what="attn dropout bwd")
+    # p = 0 is the plain kernel; another seed is another mask
+    out0, _ = K.attn_fwd_f32(dev(qkv.reshape(B * N, -1)), B, N, H, scale, want_lse=True, d=d)
+    check(out0.reshape(B, N, -1), O.attention_core(qkv.double(), H, scale), tol=1e-5, what="attn p=0")
+    out2, _ = K.attn_fwd_f32(dev(qkv.reshape(B * N, -1)), B, N, H, scale, want_lse=True, d=d, drop_p=p, seed=seed + 1)
+    assert not torch.equal(out, out2)
+    keep = O.attention_dropout_keep(4, 3, 512, p, seed).float()
+    assert abs(keep.mean().item() - (1 - p)) < 2e-3 and abs(keep.mean(-1).std().item() - (p * (1 - p) / 512) ** 0.5) < 3e-3
+
+
+def test_attention_dropout_in_the_model_is_reproducible_and_off_in_eval():
+    import simple_tad_amd as T
+    torch.manual_seed(0)
+    m = T.VisionTransformer(img_size=32, patch_size=16, embed_dim=128, depth=2, num_heads=2, mlp_ratio=4, qkv_bias=True, all_frames=4,
+                            tubelet_size=2, num_classes=2, init_scale=1.0, attn_drop_rate=0.2).cuda()
+    x = torch.randn(2, 3, 4, 32, 32).cuda()
+    m.train()
+    torch.manual_seed(5); a = m(x); a.sum().backward()
+    ga = m.blocks[0].attn.qkv.weight.grad.clone()
+    m.zero_grad()
+    torch.manual_seed(5); b = m(x); b.sum().backward()
+    assert torch.equal(a, b) and torch.equal(ga, m.blocks[0].attn.qkv.weight.grad) and bool(torch.isfinite(ga).all())
+    torch.manual_seed(6); c = m(x)
+    assert not torch.equal(a, c)                     # another seed, another mask
+    m.eval()
+    with torch.no_grad():
+        e1, e2 = m(x), m(x)
+    m0 = T.VisionTransformer(img_size=32, patch_size=16, embed_dim=128, depth=2, num_heads=2, mlp_ratio=4, qkv_bias=True, all_frames=4,
+                             tubelet_size=2, num_classes=2, init_scale=1.0, attn_drop_rate=0.0).cuda().eval()
+    m0.load_state_dict(m.state_dict())
+    with torch.no_grad():
+        assert torch.equal(e1, e2) and torch.equal(e1, m0(x))   # no dropout in eval: the fused 16-bit path, same bits as a model without it
