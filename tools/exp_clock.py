@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """The clock the chip holds INSIDE the MFMA loops (MI355X_MICROARCH.md 'DVFS give-back' item 6).
 
-Needs an ablation build (TAD_BUILD_ABLATION=1 python -m simple_tad_amd.build --force): only that build carries the stamps.
+Needs an ablation build next to the production one (only that build carries the stamps):
+    TAD_BUILD_LIB=libtad_ablation.so TAD_BUILD_ABLATION=1 python -m simple_tad_amd.build --force
+    TAD_LIB=simple_tad_amd/libtad_ablation.so python tools/exp_clock.py --out profiles/r03_clock.json
 For each probe: >= 2 s of back-to-back launches on random data, then ONE stamped launch; every workgroup records s_memtime (shader
 clock) and s_memrealtime (100 MHz) at the start and the end of its loop (gemm_nt 256x256: around the K loop of each tile; attention
 dK/dV: around the tile loop); clock = d(memtime) / d(memrealtime) x 100 MHz, median over workgroups / tiles.
 
-    python tools/exp_clock.py --out profiles/r02_clock.json
 """
 import argparse
 import json
@@ -95,6 +96,13 @@ res["attn_bwd_dkv_tile_loop"] = {"workgroups": int(ok.sum()), "soak_launches": l
 print("attn_bwd_dkv", res["attn_bwd_dkv_tile_loop"], flush=True)
 clocks = [v["clock_mhz_median"] for k, v in res.items() if isinstance(v, dict) and "clock_mhz_median" in v]
 res["held_clock_mhz"] = round(float(np.median(clocks)), 1)
+import hashlib  # noqa: E402
+_h = hashlib.sha256()
+_d = os.path.join(ROOT, "simple_tad_amd", "csrc")
+for _f in sorted(os.listdir(_d)) + [os.path.join("..", "..", "include", "tad_mi355x.h")]:
+    with open(os.path.join(_d, _f), "rb") as _fh:
+        _h.update(_fh.read())
+res["csrc_sha16"] = _h.hexdigest()[:16]  # bench.py quotes this clock only while the kernel sources still match
 res["peak_bf16_tflops_at_held_clock"] = round(256 * 4096 * res["held_clock_mhz"] * 1e6 / 1e12, 1)
 print(json.dumps(res))
 if a.out:
