@@ -261,18 +261,16 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
     if (t + 1 < nt) dq_tile(std::integral_constant<int, 1>{}, t + 1);
   }
 
-  if (qvalid) {
-    uint16_t* op = dqkv + ((int64_t)b * N + qrow) * tok + head * BHD;  // q slot (index 0 of the "3" axis)
+  if (wave_live) {  // (the tile ring is free: the loop ended on a barrier) whole rows through the LDS, see store_rows_via_lds
+    uint2 pk[2][4];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
-        const int d = dt * 32 + 8 * r4 + 4 * h5;
-        uint2 pk;
-        pk.x = pack_op16x2(dq[dt][4 * r4 + 0] * scale, dq[dt][4 * r4 + 1] * scale);
-        pk.y = pack_op16x2(dq[dt][4 * r4 + 2] * scale, dq[dt][4 * r4 + 3] * scale);
-        *reinterpret_cast<uint2*>(op + d) = pk;
+        pk[dt][r4].x = pack_op16x2(dq[dt][4 * r4 + 0] * scale, dq[dt][4 * r4 + 1] * scale);
+        pk[dt][r4].y = pack_op16x2(dq[dt][4 * r4 + 2] * scale, dq[dt][4 * r4 + 3] * scale);
       }
+    store_rows_via_lds(lds + wave * ROW_PATCH_BYTES, pk, dqkv + ((int64_t)b * N + q0) * tok + head * BHD /* q slot */, tok, N - q0, lane);
   }
 }
 
@@ -481,22 +479,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
     stamps[(size_t)blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime();
   }
 #endif
-  if (kvalid) {
-    uint16_t* okp = dqkv + ((int64_t)b * N + krow) * tok + (int64_t)H * BHD + head * BHD;
-    uint16_t* ovp = okp + (int64_t)H * BHD;
+  if (wave_live) {  // (the tile ring is free: the loop ended on a barrier) whole rows through the LDS, see store_rows_via_lds
+    uint16_t* okp = dqkv + ((int64_t)b * N + key0) * tok + (int64_t)H * BHD + head * BHD;
+    uint2 pk[2][4];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
-        const int d = dt * 32 + 8 * r4 + 4 * h5;
-        uint2 pk, pv;
-        pk.x = pack_op16x2(dk[dt][4 * r4 + 0] * scale, dk[dt][4 * r4 + 1] * scale);
-        pk.y = pack_op16x2(dk[dt][4 * r4 + 2] * scale, dk[dt][4 * r4 + 3] * scale);
-        pv.x = pack_op16x2(dv[dt][4 * r4 + 0], dv[dt][4 * r4 + 1]);
-        pv.y = pack_op16x2(dv[dt][4 * r4 + 2], dv[dt][4 * r4 + 3]);
-        *reinterpret_cast<uint2*>(okp + d) = pk;
-        *reinterpret_cast<uint2*>(ovp + d) = pv;
+        pk[dt][r4].x = pack_op16x2(dk[dt][4 * r4 + 0] * scale, dk[dt][4 * r4 + 1] * scale);
+        pk[dt][r4].y = pack_op16x2(dk[dt][4 * r4 + 2] * scale, dk[dt][4 * r4 + 3] * scale);
       }
+    store_rows_via_lds(lds + wave * ROW_PATCH_BYTES, pk, okp, tok, N - key0, lane);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        pk[dt][r4].x = pack_op16x2(dv[dt][4 * r4 + 0], dv[dt][4 * r4 + 1]);
+        pk[dt][r4].y = pack_op16x2(dv[dt][4 * r4 + 2], dv[dt][4 * r4 + 3]);
+      }
+    store_rows_via_lds(lds + wave * ROW_PATCH_BYTES, pk, okp + (int64_t)H * BHD, tok, N - key0, lane);
   }
 }
 

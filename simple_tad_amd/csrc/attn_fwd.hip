@@ -223,32 +223,36 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
   const float l_tot = l_run;  // already the full row sum (see FWD_TILE)
   const float inv = 1.f / l_tot;
   const int qrow = q0 + ql;
-  if (qrow < N) {
+  if (OUT_BF16) {
+    if (wave_live) {  // (the tile ring is free: the loop ended on a barrier) whole rows through the LDS, see store_rows_via_lds
+      const int64_t obase0 = (((int64_t)b * N + q0) * H + head) * HD;
+      uint2 pk[2][4], lo[2][4];
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const float v0 = o[dt][4 * r4 + 0] * inv, v1 = o[dt][4 * r4 + 1] * inv, v2 = o[dt][4 * r4 + 2] * inv, v3 = o[dt][4 * r4 + 3] * inv;
+          pk[dt][r4].x = pack_op16x2(v0, v1);
+          pk[dt][r4].y = pack_op16x2(v2, v3);
+          // what the 16-bit rounding dropped (see tad_attn_fwd: the backward's delta is taken of out + out_lo)
+          lo[dt][r4].x = pack_op16x2(v0 - op16_lo_f32(pk[dt][r4].x), v1 - op16_hi_f32(pk[dt][r4].x));
+          lo[dt][r4].y = pack_op16x2(v2 - op16_lo_f32(pk[dt][r4].y), v3 - op16_hi_f32(pk[dt][r4].y));
+        }
+      store_rows_via_lds(lds + wave * ROW_PATCH_BYTES, pk, (uint16_t*)out + obase0, (int64_t)H * HD, N - q0, lane);
+      if (out_lo) store_rows_via_lds(lds + wave * ROW_PATCH_BYTES, lo, out_lo + obase0, (int64_t)H * HD, N - q0, lane);
+    }
+  } else if (qrow < N) {
     const int64_t obase = (((int64_t)b * N + qrow) * H + head) * HD;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
         const int d = dt * 32 + 8 * r4 + 4 * h5;
-        const float v0 = o[dt][4 * r4 + 0] * inv, v1 = o[dt][4 * r4 + 1] * inv, v2 = o[dt][4 * r4 + 2] * inv,
-                    v3 = o[dt][4 * r4 + 3] * inv;
-        if (OUT_BF16) {
-          uint2 pk;
-          pk.x = pack_op16x2(v0, v1);
-          pk.y = pack_op16x2(v2, v3);
-          *reinterpret_cast<uint2*>((uint16_t*)out + obase + d) = pk;
-          if (out_lo) {  // what the 16-bit rounding dropped (see tad_attn_fwd: the backward's delta is taken of out + out_lo)
-            uint2 lo;
-            lo.x = pack_op16x2(v0 - op16_lo_f32(pk.x), v1 - op16_hi_f32(pk.x));
-            lo.y = pack_op16x2(v2 - op16_lo_f32(pk.y), v3 - op16_hi_f32(pk.y));
-            *reinterpret_cast<uint2*>(out_lo + obase + d) = lo;
-          }
-        } else {
-          *reinterpret_cast<float4*>((float*)out + obase + d) = make_float4(v0, v1, v2, v3);
-        }
+        *reinterpret_cast<float4*>((float*)out + obase + d) =
+            make_float4(o[dt][4 * r4 + 0] * inv, o[dt][4 * r4 + 1] * inv, o[dt][4 * r4 + 2] * inv, o[dt][4 * r4 + 3] * inv);
       }
-    if (h5 == 0 && lse) lse[((int64_t)b * H + head) * N + qrow] = m_run * scale + __logf(l_tot);
   }
+  if (qrow < N && h5 == 0 && lse) lse[((int64_t)b * H + head) * N + qrow] = m_run * scale + __logf(l_tot);
 }
 
 TAD_NAMESPACE_END
