@@ -231,11 +231,12 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
       }
       // dS^T = P^T o (dP^T - delta); keys >= N contribute nothing
       if (kv0 + 64 > N) {  // ragged last tile only: keys >= N get P = 0
+        // (one lane value against 16 literals: see attn_bwd_dkv_kernel)
+        int lim = N - (kv0 + kt * 32) - 4 * h5;
+        asm volatile("" : "+v"(lim));
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int kg = kv0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h5;
-          if (kg >= N) s[r] = -1e30f;
-        }
+        for (int r = 0; r < 16; ++r)
+          if ((r & 3) + 8 * (r >> 2) >= lim) s[r] = -1e30f;
       }
       f32x16 ds;
 #pragma unroll
@@ -377,13 +378,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
     stamps[(size_t)blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
   }
 #endif
-  int cur = 0;  // ring slot of tile t
-  for (int t = 0; t < nt; ++t) {
-    const bool more = t + 1 < nt;  // is there a tile to request during this one?
-    const int nbuf = cur ^ 1;      // its ring slot ...
-    const int nq0 = (t + 1) * 64;  // ... and first query row
+  // the tile loop runs in pairs so that the ring slot is a literal in each copy of the body (as in the dQ kernel): every LDS address is
+  // then a lane constant + immediate instead of ~25 v_add per half tile
+  auto dkv_tile = [&](auto BUFC, int t) {
+    constexpr int BUF = decltype(BUFC)::value;
+    constexpr int SO = BUF * STAGE;   // byte offset of the ring slot, folded into the instruction immediates
+    const bool more = t + 1 < nt;     // is there a tile to request during this one?
+    constexpr int nbuf = BUF ^ 1;     // its ring slot ...
+    const int nq0 = (t + 1) * 64;     // ... and first query row
     if (more && DMA_MODE == 0) LOAD_QDO(nbuf, nq0);
-    const uint32_t so = (uint32_t)(cur * STAGE);
     if (wave_live)  // (see the dQ kernel: waves whose 32 keys all lie past the sequence only stage tiles)
     static_for<0, 2>([&](auto qtc) {
       constexpr int qt = decltype(qtc)::value;
@@ -394,22 +397,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
       op16x8 qa[4], da[4];
       static_for<0, 4>([&](auto r4c) {
         constexpr int r4 = decltype(r4c)::value;
-        si[r4] = lds_read_b128<f32x4, (qt * 32 + 8 * r4) * 4>(rca + so);
-        di[r4] = lds_read_b128<f32x4, 256 + (qt * 32 + 8 * r4) * 4>(rca + so);
+        si[r4] = lds_read_b128<f32x4, SO + (qt * 32 + 8 * r4) * 4>(rca);
+        di[r4] = lds_read_b128<f32x4, SO + 256 + (qt * 32 + 8 * r4) * 4>(rca);
       });
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        qa[ks] = lds_read_b128<op16x8, HT>(rfa[ks] + so);
-        da[ks] = lds_read_b128<op16x8, TILE_BYTES + HT>(rfa[ks] + so);
+        qa[ks] = lds_read_b128<op16x8, SO + HT>(rfa[ks]);
+        da[ks] = lds_read_b128<op16x8, SO + TILE_BYTES + HT>(rfa[ks]);
       }
       // batch 2 / 3: transposed fragments for the dV / dK products of rows 0..15 / 16..31 of the half tile
       s16x4 dol[2][2], doh[2][2], qtl[2][2], qth[2][2];  // [s2][dt]
 #define TR_ISSUE(s2_)                                                                         \
   _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) {                                          \
-    dol[s2_][dt] = lds_tr16_b64<TILE_BYTES + HT + 16 * (s2_) * 128>(qtr[dt][0] + so);         \
-    doh[s2_][dt] = lds_tr16_b64<TILE_BYTES + HT + 16 * (s2_) * 128>(qtr[dt][1] + so);         \
-    qtl[s2_][dt] = lds_tr16_b64<HT + 16 * (s2_) * 128>(qtr[dt][0] + so);                      \
-    qth[s2_][dt] = lds_tr16_b64<HT + 16 * (s2_) * 128>(qtr[dt][1] + so);                      \
+    dol[s2_][dt] = lds_tr16_b64<SO + TILE_BYTES + HT + 16 * (s2_) * 128>(qtr[dt][0]);         \
+    doh[s2_][dt] = lds_tr16_b64<SO + TILE_BYTES + HT + 16 * (s2_) * 128>(qtr[dt][1]);         \
+    qtl[s2_][dt] = lds_tr16_b64<SO + HT + 16 * (s2_) * 128>(qtr[dt][0]);                      \
+    qth[s2_][dt] = lds_tr16_b64<SO + HT + 16 * (s2_) * 128>(qtr[dt][1]);                      \
   }
 #define TR_MFMA(s2_, YOUNGER, pf_, dsf_)                                                                                       \
   lds_wait<YOUNGER>(dol[s2_][0], doh[s2_][0], qtl[s2_][0], qth[s2_][0], dol[s2_][1], doh[s2_][1], qtl[s2_][1], qth[s2_][1]);   \
@@ -429,9 +432,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[r] = si[r >> 2][r & 3]; dp[r] = di[r >> 2][r & 3]; }
       if (t * 64 + 32 * qt + 32 > N) {  // ragged half tile (N % 32 != 0): rows >= N get exp2(c*(s - 3e30)) = 0 and delta = 0
+        // (one lane value against 16 literals: written as `row0 + literal + 4 h5 >= N` the compiler computed the 16 row indices in
+        // front of this branch, i.e. in every half tile)
+        int lim = N - (t * 64 + 32 * qt) - 4 * h5;
+        asm volatile("" : "+v"(lim));
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          if (t * 64 + 32 * qt + (r & 3) + 8 * (r >> 2) + 4 * h5 >= N) { s[r] = -3.0e30f; dp[r] = 0.f; }
+          if ((r & 3) + 8 * (r >> 2) >= lim) { s[r] = -3.0e30f; dp[r] = 0.f; }
       }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -470,7 +477,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
     });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    cur ^= 1;
+  };
+  for (int t = 0; t < nt; t += 2) {
+    dkv_tile(std::integral_constant<int, 0>{}, t);
+    if (t + 1 < nt) dkv_tile(std::integral_constant<int, 1>{}, t + 1);
   }
 
 #ifdef TAD_GEMM_ABLATION

@@ -155,12 +155,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
         s[kt] = TAD_MFMA_32x32x16(kf, qf[ks], s[kt]);                                      \
       }                                                                                                                   \
     }                                                                                                                     \
-    if (kv0 + KV_TILE > N) { /* ragged last tile: mask keys >= N */                                                       \
+    if (kv0 + KV_TILE > N) { /* ragged last tile: mask keys >= N (one lane value against 32 literals: written with the key   \
+                                index on the left the compiler computes all 32 indices in front of this branch) */        \
+      int lim = N - kv0 - 4 * h5;                                                                                         \
+      asm volatile("" : "+v"(lim));                                                                                       \
       _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                                    \
-          _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                \
-        const int key = kv0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h5;                                                  \
-        if (key >= N) s[kt][r] = -1e30f;                                                                                  \
-      }                                                                                                                   \
+          _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                                  \
+        if (kt * 32 + (r & 3) + 8 * (r >> 2) >= lim) s[kt][r] = -1e30f;                                                   \
     }                                                                                                                     \
     float mloc = s[0][0];                                                                                                 \
     _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                                      \
