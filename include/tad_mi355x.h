@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TAD_ABI_VERSION 3
+#define TAD_ABI_VERSION 4
 
 enum tad_status {
   TAD_OK = 0,
@@ -131,8 +131,11 @@ int tad_linear_bwd_input(const uint16_t* dy, const uint16_t* wT, void* dx, int d
  * N = 3 * all_head_dim; q_bias / v_bias [N/3] f32 (both or neither).  Forward: y = x W^T + bias.  Weight gradient: as
  * tad_linear_bwd_weight, with the column sums of the first / last third of dy going to dq_bias / dv_bias (workspace: the same
  * tad_linear_bwd_weight_workspace_bytes). */
+/* q_prescale (> 0; 1 = the plain Linear): the q third of y (columns [0, N/3)) is multiplied by it before the one rounding to
+ * y_dtype.  With q_prescale = scale * log2(e) the attention kernels (q_prescaled != 0 below) get their scores from the matrix pipe
+ * in log2 units and spend no vector instruction on the softmax scale (modeling_finetune.py:96: `q = q * self.scale`, done here). */
 int tad_linear_fwd_qkv(const uint16_t* x, const uint16_t* w, const float* q_bias, const float* v_bias, void* y,
-                       int y_dtype, int64_t M, int N, int K, tad_stream_t stream);
+                       int y_dtype, float q_prescale, int64_t M, int N, int K, tad_stream_t stream);
 int tad_linear_bwd_weight_qkv(const uint16_t* dy, const uint16_t* x, float* dW, float* dq_bias, float* dv_bias,
                               int accumulate, void* ws, size_t ws_bytes, int64_t M, int N, int K,
                               tad_stream_t stream);
@@ -164,12 +167,15 @@ int tad_linear_bwd_weight(const uint16_t* dy, const uint16_t* x, float* dW, floa
  * qkv [B,N,3,H,d] bf16 packed (the qkv Linear's output, column order [3][H][d]); d must be 64.
  * out [B,N,H,d] in out_dtype; lse [B,H,N] f32 = log(sum_j exp(scale * q.k_j)) (natural log).
  * out_lo (nullable, 16-bit outputs only): [B,N,H,d] = what the rounding of out dropped (out + out_lo carries 16 / 22 significant
- * bits), for tad_attn_bwd's delta. */
+ * bits), for tad_attn_bwd's delta.
+ * q_prescaled != 0: the q third of qkv already carries the factor scale * log2(e) (tad_linear_fwd_qkv's q_prescale); `scale` is
+ * still the softmax scale.  0: plain q, as flash_attn_varlen_qkvpacked_func takes it (the kernels then scale their Q fragments
+ * themselves: a second 16-bit rounding of q). */
 int tad_attn_fwd(const uint16_t* qkv, void* out, int out_dtype, uint16_t* out_lo, float* lse, int B, int N, int H, int d,
-                 float scale, tad_stream_t stream);
+                 float scale, int q_prescaled, tad_stream_t stream);
 /* dqkv [B,N,3,H,d] bf16 (fully overwritten).  delta: scratch of tad_attn_bwd_scratch_bytes(B, N, H) bytes = 2*B*H*N floats (the
- * first kernel leaves -rowsum(dout*out) in [0, BHN) and -lse/scale in [BHN, 2 BHN) for the second one, which takes them as the
- * initial values of its accumulators). */
+ * first kernel leaves -rowsum(dout*out) in [0, BHN) and -lse/scale (-lse*log2(e) with q_prescaled) in [BHN, 2 BHN) for the second
+ * one, which takes them as the initial values of its accumulators).  The q slot of dqkv is the gradient of the PLAIN q in either case. */
 /* Knob of the three attention kernels.  "dma_mode": 0 = production; 2 / 3 = timing-only ablations (wrong results) that only
  * ablation builds (TAD_BUILD_ABLATION=1) accept. */
 int tad_attn_tuning(const char* key, int value);
@@ -182,7 +188,7 @@ int tad_attn_debug_stamps(void* buf);
  * is what cancels against the dP the kernels recompute (without it the q / k gradients of near-uniform attention rows carry the
  * rounding of out amplified by |delta| / |dP - delta|). */
 int tad_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* out_lo, const uint16_t* dout, const float* lse,
-                 uint16_t* dqkv, float* delta, int B, int N, int H, int d, float scale,
+                 uint16_t* dqkv, float* delta, int B, int N, int H, int d, float scale, int q_prescaled,
                  tad_stream_t stream);
 
 /* ---- token mean-pool x.mean(1) (modeling_finetune.py:325-326) -------------------------
@@ -344,7 +350,7 @@ int tad_linear_fwd_f16(const uint16_t* x, const uint16_t* w, const float* bias, 
                        const float* residual, const float* gamma, const float* rowscale, int rows_per_scale, int64_t M, int N, int K,
                        tad_stream_t stream);
 int tad_linear_fwd_qkv_f16(const uint16_t* x, const uint16_t* w, const float* q_bias, const float* v_bias, void* y, int y_dtype,
-                           int64_t M, int N, int K, tad_stream_t stream);
+                           float q_prescale, int64_t M, int N, int K, tad_stream_t stream);
 int tad_linear_bwd_input_f16(const uint16_t* dy, const uint16_t* wT, void* dx, int dx_dtype, const uint16_t* gelu_preact, int64_t M,
                              int N, int K, tad_stream_t stream);
 int tad_linear_bwd_weight_f16(const uint16_t* dy, const uint16_t* x, float* dW, float* db, int accumulate, void* ws, size_t ws_bytes,
@@ -352,9 +358,9 @@ int tad_linear_bwd_weight_f16(const uint16_t* dy, const uint16_t* x, float* dW, 
 int tad_linear_bwd_weight_qkv_f16(const uint16_t* dy, const uint16_t* x, float* dW, float* dq_bias, float* dv_bias, int accumulate,
                                   void* ws, size_t ws_bytes, int64_t M, int N, int K, tad_stream_t stream);
 int tad_attn_fwd_f16(const uint16_t* qkv, void* out, int out_dtype, uint16_t* out_lo, float* lse, int B, int N, int H, int d,
-                     float scale, tad_stream_t stream);
+                     float scale, int q_prescaled, tad_stream_t stream);
 int tad_attn_bwd_f16(const uint16_t* qkv, const uint16_t* out, const uint16_t* out_lo, const uint16_t* dout, const float* lse,
-                     uint16_t* dqkv, float* delta, int B, int N, int H, int d, float scale, tad_stream_t stream);
+                     uint16_t* dqkv, float* delta, int B, int N, int H, int d, float scale, int q_prescaled, tad_stream_t stream);
 int tad_meanpool_bwd_f16(const float* dy, float* dx, uint16_t* dx_f16, int B, int N, int D, tad_stream_t stream);
 int tad_adamw_step_f16(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint16_t* param_f16,
                        const uint8_t* chunk_group, int64_t n, const float* group_lr, const float* group_wd, int n_groups,

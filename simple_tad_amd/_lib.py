@@ -31,18 +31,18 @@ SIGNATURES = {
     "tad_layernorm_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _sz, _i64, _i, _vp]),
     "tad_linear_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp]),
     "tad_linear_tuning": (_i, [C.c_char_p, _i]),
-    "tad_linear_fwd_qkv": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp]),
+    "tad_linear_fwd_qkv": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _i64, _i, _i, _vp]),
     "tad_linear_bwd_weight_qkv": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _i64, _i, _i, _vp]),
     "tad_linear_debug_stamps": (_i, [_vp]),
     "tad_linear_kernel_launches": (C.c_longlong, []),
     "tad_linear_bwd_input": (_i, [_vp, _vp, _vp, _i, _vp, _i64, _i, _i, _vp]),
     "tad_linear_bwd_weight_workspace_bytes": (_sz, [_i64, _i, _i]),
     "tad_linear_bwd_weight": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _sz, _i64, _i, _i, _vp]),
-    "tad_attn_fwd": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "tad_attn_fwd": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "tad_attn_tuning": (_i, [C.c_char_p, _i]),
     "tad_attn_bwd_scratch_bytes": (_sz, [_i, _i, _i]),
     "tad_attn_debug_stamps": (_i, [_vp]),
-    "tad_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "tad_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "tad_meanpool_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "tad_meanpool_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "tad_colsum_workspace_bytes": (_sz, [_i64, _i]),
@@ -94,7 +94,7 @@ F16_TWINS = {
 for _bf, _h in F16_TWINS.items():
     SIGNATURES[_h] = SIGNATURES[_bf]
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 ADAMW_CHUNK = 4096
 ADAMW_MAX_GROUPS = 128
 POOL_SPLIT = 8

@@ -24,6 +24,9 @@
 TAD_NAMESPACE_BEGIN
 
 constexpr int BHD = 64;
+#ifndef TAD_DQ_BATCH
+#define TAD_DQ_BATCH 0  // dQ kernel: 1 = row fragments of a half tile requested in one batch (asm reads) -- measured SLOWER (backward pair 846 -> 866 us, round 4); 0 = plain loads
+#endif
 constexpr float LOG2E = 1.44269504088896340736f;
 
 // 16-byte chunk swizzle for 128-byte rows, conflict-free for row reads (32 consecutive rows, chunk 2ks+h) and for
@@ -80,7 +83,8 @@ __device__ __forceinline__ op16x8 pack8(const f32x16& a, int s2) {
 // the tile waits for all of it).  2 / 3 exist in ablation builds only (timing experiments, wrong results): 2 = no DMA inside the loop,
 // 3 = dK/dV kernel without its transposed LDS reads.  The variants round 2 measured and dropped (pieces spread into the tile, a
 // three-deep tile ring, 64 keys per wave at one wave per SIMD) are archived under experiments/r02_variants.
-template <int DMA_MODE>
+// QS: the q third of qkv carries the factor scale * log2(e) (see attn_fwd.hip); without it the factor is applied to the f32 scores.
+template <bool QS, int DMA_MODE>
 __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out,
                                                           const uint16_t* __restrict__ out_lo,
                                                           const uint16_t* __restrict__ dout, const float* __restrict__ lse,
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
     if (qvalid && h5 == 0) {
       const int64_t idx = ((int64_t)b * H + head) * N + qrow;
       delta[idx] = -dlt;
-      delta[(int64_t)B * H * N + idx] = -lse[idx] / scale;
+      delta[(int64_t)B * H * N + idx] = QS ? -lse2 : -lse[idx] / scale;
     }
   }
 
@@ -194,6 +198,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
   uint32_t ktr[2][2];  // K^T fragment addresses (tile 0 of buffer 0), [d tile][first / second read]
   tr_dual_addr(lds_addr(lds), 0, lane, ktr[0]);
   tr_dual_addr(lds_addr(lds), 32, lane, ktr[1]);
+  uint32_t rfa[4];     // row fragments (row lane&31 of a half tile, chunk 2ks + h5) of the K tile in slot 0; V tile: + TILE_BYTES
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) rfa[ks] = lds_addr(lds) + (uint32_t)(ql * 128 + (((2 * ks + h5) ^ sw_dual(ql)) << 4));
   auto dq_tile = [&](auto BUFC, int t) {
     constexpr int BUF = decltype(BUFC)::value;
     const int kv0 = t * 64;
@@ -209,18 +216,41 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
     static_for<0, 2>([&](auto ktc) {
       constexpr int kt = decltype(ktc)::value;
       if (kv0 + 32 * kt >= N) return;  // a half tile past the sequence (N = 1568: the second half of the last tile) contributes nothing
-      // K^T fragments for the dQ product, issued now and waited for after the exponentials (asm reads: see common.h)
-      s16x4 tl[2][2], th[2][2];  // [s2][dt]
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          tl[s2][dt] = s2 == 0 ? lds_tr16_b64<BUF * 2 * TILE_BYTES + (kt * 32) * 128>(ktr[dt][0])
-                               : lds_tr16_b64<BUF * 2 * TILE_BYTES + (kt * 32 + 16) * 128>(ktr[dt][0]);
-          th[s2][dt] = s2 == 0 ? lds_tr16_b64<BUF * 2 * TILE_BYTES + (kt * 32) * 128>(ktr[dt][1])
-                               : lds_tr16_b64<BUF * 2 * TILE_BYTES + (kt * 32 + 16) * 128>(ktr[dt][1]);
-        }
+      s16x4 tl[2][2], th[2][2];  // K^T fragments for the dQ product, [s2][dt] (asm reads: see common.h)
+#define DQ_TR_ISSUE()                                                                                        \
+  _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2)                                                           \
+      _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) {                                                     \
+    tl[s2][dt] = s2 == 0 ? lds_tr16_b64<BUF * 2 * TILE_BYTES + (kt * 32) * 128>(ktr[dt][0])                  \
+                         : lds_tr16_b64<BUF * 2 * TILE_BYTES + (kt * 32 + 16) * 128>(ktr[dt][0]);            \
+    th[s2][dt] = s2 == 0 ? lds_tr16_b64<BUF * 2 * TILE_BYTES + (kt * 32) * 128>(ktr[dt][1])                  \
+                         : lds_tr16_b64<BUF * 2 * TILE_BYTES + (kt * 32 + 16) * 128>(ktr[dt][1]);            \
+  }
       f32x16 s, dp;
+#if TAD_DQ_BATCH
+      // The eight row fragments of the half tile (K and V rows of key lane&31) are requested in one batch of asm reads with counted
+      // waits: from plain loads the two chains ran read, read -> s_waitcnt -> two MFMAs four times per half tile, one exposed LDS
+      // latency each.  The K^T fragments of the dQ product are requested behind the chains (into the registers the row fragments
+      // leave) and waited for after the exponentials.  delta is subtracted in the vector pipe: as the initial accumulator it kept a
+      // 16-register block of -delta alive through the whole kernel, which the batch needs.
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+      {
+        op16x8 kr[4], vr[4];
+        static_for<0, 4>([&](auto kc) {
+          constexpr int ks = decltype(kc)::value;
+          kr[ks] = lds_read_b128<op16x8, BUF * 2 * TILE_BYTES + kt * 32 * 128>(rfa[ks]);
+          vr[ks] = lds_read_b128<op16x8, BUF * 2 * TILE_BYTES + TILE_BYTES + kt * 32 * 128>(rfa[ks]);
+        });
+        static_for<0, 4>([&](auto kc) {
+          constexpr int ks = decltype(kc)::value;
+          lds_wait<6 - 2 * ks>(kr[ks], vr[ks]);
+          s = TAD_MFMA_32x32x16(kr[ks], qf[ks], s);
+          dp = TAD_MFMA_32x32x16(vr[ks], dof[ks], dp);
+        });
+      }
+      DQ_TR_ISSUE();
+#else
+      DQ_TR_ISSUE();  // issued now and waited for after the exponentials
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = -dlt; }
       const int key = kt * 32 + ql;
@@ -229,6 +259,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
         s = TAD_MFMA_32x32x16(row_frag_dual(kl, key, ks, h5), qf[ks], s);
         dp = TAD_MFMA_32x32x16(row_frag_dual(vl, key, ks, h5), dof[ks], dp);
       }
+#endif
+#undef DQ_TR_ISSUE
       // dS^T = P^T o (dP^T - delta); keys >= N contribute nothing
       if (kv0 + 64 > N) {  // ragged last tile only: keys >= N get P = 0
         // (one lane value against 16 literals: see attn_bwd_dkv_kernel)
@@ -240,7 +272,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
       }
       f32x16 ds;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(s[r] * c - lse2) * dp[r];
+      for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(QS ? s[r] - lse2 : fmaf(s[r], c, -lse2)) * (TAD_DQ_BATCH ? dp[r] - dlt : dp[r]);  // (QS: scores in log2 units)
       lds_wait<4>(tl[0][0], th[0][0], tl[0][1], th[0][1]);
       {
         const op16x8 dsf = pack8(ds, 0);
@@ -276,7 +308,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
-template <int DMA_MODE>
+template <bool QS, int DMA_MODE>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
                                                            const float* __restrict__ rowc_g, uint16_t* __restrict__ dqkv, int N, int H, int B,
                                                            float scale, unsigned long long* stamps) {
@@ -449,7 +481,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
       f32x16 pm, ds;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        pm[r] = fast_exp2(s[r] * c);
+        pm[r] = QS ? fast_exp2(s[r]) : fast_exp2(s[r] * c);  // QS: q . k is in log2 units already
         ds[r] = pm[r] * dp[r];
       }
       if constexpr (DMA_MODE != 3) {
@@ -496,8 +528,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
-        pk[dt][r4].x = pack_op16x2(dk[dt][4 * r4 + 0] * scale, dk[dt][4 * r4 + 1] * scale);
-        pk[dt][r4].y = pack_op16x2(dk[dt][4 * r4 + 2] * scale, dk[dt][4 * r4 + 3] * scale);
+        // dK = scale * dS^T Q; with QS the tile held Q' = Q * scale * log2(e)
+        const float ks_ = QS ? 0.69314718055994530942f : scale;
+        pk[dt][r4].x = pack_op16x2(dk[dt][4 * r4 + 0] * ks_, dk[dt][4 * r4 + 1] * ks_);
+        pk[dt][r4].y = pack_op16x2(dk[dt][4 * r4 + 2] * ks_, dk[dt][4 * r4 + 3] * ks_);
       }
     store_rows_via_lds(lds + wave * ROW_PATCH_BYTES, pk, okp, tok, N - key0, lane);
 #pragma unroll
@@ -560,7 +594,7 @@ extern "C" size_t tad_attn_bwd_scratch_bytes(int B, int N, int H) {
 #endif
 
 extern "C" int tad_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* out_lo, const uint16_t* dout, const float* lse,
-                            uint16_t* dqkv, float* delta, int B, int N, int H, int d, float scale, tad_stream_t stream) {
+                            uint16_t* dqkv, float* delta, int B, int N, int H, int d, float scale, int q_prescaled, tad_stream_t stream) {
   TAD_REQUIRE(qkv && out && dout && lse && dqkv && delta, "attn_bwd: null pointer");
   TAD_REQUIRE(d == BHD, "attn_bwd: head_dim must be 64 (got %d)", d);
   TAD_REQUIRE(B > 0 && N > 0 && H > 0 && H <= 65535 && B <= 65535, "attn_bwd: bad shape");
@@ -570,14 +604,15 @@ extern "C" int tad_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)(((N + 127) / 128) * H * B)), block(256);
   const int mode = attn_dma_mode;
-#define LAUNCH_BWD(M_)                                                                                                       \
+#define LAUNCH_BWD_(Q_, M_)                                                                                                  \
   {                                                                                                                          \
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<M_>), grid, block, 0, st, qkv, out, out_lo, dout, lse, delta, dqkv, N, H, B, scale);      \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<Q_, M_>), grid, block, 0, st, qkv, out, out_lo, dout, lse, delta, dqkv, N, H, B, scale);  \
     int rc = check_launch("attn_bwd_dq");                                                                                    \
     if (rc) return rc;                                                                                                       \
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<M_>), grid, block, 0, st, qkv, dout, delta, dqkv, N, H, B, scale, attn_stamps);  \
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<Q_, M_>), grid, block, 0, st, qkv, dout, delta, dqkv, N, H, B, scale, attn_stamps);  \
     return check_launch("attn_bwd_dkv");                                                                                     \
   }
+#define LAUNCH_BWD(M_) { if (q_prescaled) LAUNCH_BWD_(true, M_) else LAUNCH_BWD_(false, M_) }
 #ifdef TAD_GEMM_ABLATION
   if (mode == 2) LAUNCH_BWD(2)
   if (mode == 3) LAUNCH_BWD(3)  // (dQ kernel: as mode 0; dK/dV kernel: no transposed LDS reads)
@@ -585,4 +620,5 @@ extern "C" int tad_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint
   (void)mode;
   LAUNCH_BWD(0)
 #undef LAUNCH_BWD
+#undef LAUNCH_BWD_
 }

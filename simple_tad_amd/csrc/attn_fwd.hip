@@ -18,7 +18,16 @@ constexpr int HD = 64;      // head dim
 constexpr int KV_TILE = 64; // keys per LDS tile
 constexpr int Q_WAVE = 32;  // query rows per wave
 constexpr int Q_BLOCK = 128;
-constexpr float RESCALE_THR = 8.0f;
+constexpr float RESCALE_THR = 8.0f;  // log2 units
+#ifndef TAD_FWD_ROWSUM_VALU
+#define TAD_FWD_ROWSUM_VALU 0  // 1: row sums of P as f32 adds of the unrounded exponentials + one half swap per tile, instead of 4 MFMAs
+#endif
+#ifndef TAD_FWD_ABL
+#define TAD_FWD_ABL 0  // timing-only ablations of the forward tile body (experiments; WRONG results): bit 0 no exponentials, 1 no row
+                       // maximum, 2 no P V products / V reads / row sums, 3 no K Q^T products / K reads, 4 no DMA and no barrier in
+                       // the loop, 5 no V reads (P V products fed from the K fragments' registers)
+#endif
+
 
 __device__ __forceinline__ int swk(int key) { return (key >> 1) & 7; }
 __device__ __forceinline__ int swv(int key) { return ((key >> 1) & 1) << 2; }
@@ -36,12 +45,15 @@ __device__ __forceinline__ float half_swap_sum(float x) {
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 
 // DMA_MODE: see attn_bwd.hip (0: next tile's LDS-DMA pieces at the top of the tile; 2: timing-only ablation, ablation builds)
-template <bool OUT_BF16, int DMA_MODE>
+// QS: the q third of qkv already carries the factor scale * log2(e) (tad_linear_fwd_qkv's q_prescale): the scores leave the matrix
+// pipe in log2 units.  Without it (plain q, flash-attn's contract) the factor is applied to the f32 scores: one v_fma per score where the
+// pre-scaled form has a v_sub, same numerics as rounds 1-3.
+template <bool OUT_BF16, bool QS, int DMA_MODE>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, void* __restrict__ out,
                                                        uint16_t* __restrict__ out_lo, float* __restrict__ lse, int N, int H, int B,
                                                        float scale) {
-  __shared__ __attribute__((aligned(1024))) char lds[2 * 2 * KV_TILE * HD * 2];  // [buf][K|V][64 keys][128 B]
   constexpr int TILE_BYTES = KV_TILE * HD * 2;                                  // 8 KiB
+  __shared__ __attribute__((aligned(1024))) char lds[2 * 2 * TILE_BYTES];       // [buf][K|V][64 keys][128 B]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // 1-D grid, XCD-aware: the query blocks of one (batch, head) pair re-read the same K/V (400 KB); dealt round-robin over the
@@ -106,7 +118,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
 
   // V^T fragment addressing (transposed reads): 16-lane group G = lane>>4, lane li in group
   const int G = lane >> 4, li = lane & 15;
@@ -121,6 +132,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
     const int col = dt * 32 + v_dc, key = 4 * v_h + v_q;
     v_rd[dt] = lds_addr(lds) + (uint32_t)(key * 128 + (((col >> 3) ^ swv(key)) << 4) + (col & 7) * 2);
   }
+
+  // lane-constant LDS addresses of the K row fragments (key lane&31 of a 32-key block, chunk 2ks + h5) in buffer 0, block 0: the
+  // swizzle only looks at key bits 1..3, so block kt and the buffer are plain byte offsets
+  uint32_t k_rd[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) k_rd[ks] = lds_addr(lds) + (uint32_t)(ql * 128 + (((2 * ks + h5) ^ swk(ql)) << 4));
 
   // Row sums of P^T out of the matrix pipe instead of 32 v_add per lane and tile (the kernel is VALU-issue bound, and the sum then uses
   // the same bf16-rounded P as the PV product) -- as ONE v_mfma_f32_16x16x32_bf16 per P fragment (half the matrix time and a quarter
@@ -137,87 +154,146 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
     for (int e = 0; e < 8; ++e) sel[e] = (op16_t)(on ? 1.0f : 0.0f);
   }
 
-  // One K/V tile of 64 keys out of LDS buffer BUF (a literal: every LDS address below is then lane-constant + immediate).
-#define FWD_TILE(BUF, T)                                                                                                  \
-  {                                                                                                                       \
-    const int kv0 = (T) * KV_TILE;                                                                                        \
-    const bool more_ = (T) + 1 < nt;                                                                                      \
-    if (more_ && DMA_MODE == 0) DMA_TILE((BUF) ^ 1, kv0 + KV_TILE);                                                        \
-    const char* kl = lds + (BUF) * 2 * TILE_BYTES;                                                                        \
-    const char* vl = kl + TILE_BYTES;                                                                                     \
-    if (wave_live) { /* waves whose 32 query rows all lie past the sequence only help staging the tiles */               \
-    f32x16 s[2];                                                                                                          \
-    _Pragma("unroll") for (int kt = 0; kt < 2; ++kt) {                                                                    \
-      _Pragma("unroll") for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;                                                      \
-      const int key = kt * 32 + ql;                                                                                       \
-      _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                                  \
-        const op16x8 kf = *reinterpret_cast<const op16x8*>(kl + key * 128 + (((2 * ks + h5) ^ swk(key)) << 4));           \
-        s[kt] = TAD_MFMA_32x32x16(kf, qf[ks], s[kt]);                                      \
-      }                                                                                                                   \
-    }                                                                                                                     \
-    if (kv0 + KV_TILE > N) { /* ragged last tile: mask keys >= N (one lane value against 32 literals: written with the key   \
-                                index on the left the compiler computes all 32 indices in front of this branch) */        \
-      int lim = N - kv0 - 4 * h5;                                                                                         \
-      asm volatile("" : "+v"(lim));                                                                                       \
-      _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                                    \
-          _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                                  \
-        if (kt * 32 + (r & 3) + 8 * (r >> 2) >= lim) s[kt][r] = -1e30f;                                                   \
-    }                                                                                                                     \
-    float mloc = s[0][0];                                                                                                 \
-    _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                                      \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[kt][r]);                                      \
-    /* deferred rescale: keep the old running max while the tile max exceeds it by < RESCALE_THR (log2 units): P may reach   \
-       2^THR instead of 1 (harmless in f32/bf16) and the O-wide multiply disappears from almost every tile.  The decision    \
-       precedes the exponentiation of this tile (textbook order). */                                                      \
-    const float m_tile = half_swap_max(mloc);                                                                             \
-    if (__any((m_tile - m_run) * c > RESCALE_THR)) {                                                                      \
-      const float m_new = fmaxf(m_run, m_tile);                                                                           \
-      const float alpha = fast_exp2((m_run - m_new) * c);                                                                 \
-      m_run = m_new;                                                                                                      \
-      l_run *= alpha;                                                                                                     \
-      _Pragma("unroll") for (int dt = 0; dt < 2; ++dt)                                                                    \
-          _Pragma("unroll") for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;                                               \
-    }                                                                                                                     \
-    const float mc = m_run * c;                                                                                           \
-    op16x8 pf[2][2];                                                                                                      \
-    _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                                      \
-        _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2)                                                                  \
-            _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                                 \
-                pf[kt][s2][j] = (op16_t)fast_exp2(s[kt][8 * s2 + j] * c - mc);                                            \
-    f32x4 rs = {0.f, 0.f, 0.f, 0.f};                                                                                      \
-    /* V^T fragments through the asm reads of common.h (the builtin made the compiler drain the DMA of the next tile here):  \
-       group g = 2 kt + s2 covers keys 16g .. 16g+15; the reads of group g+1 are issued before the MFMAs of group g */     \
-    s16x4 vlo[2][2], vhi[2][2]; /* [group parity][dt] */                                                                  \
-    _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) {                                                                    \
-      vlo[0][dt] = lds_tr16_b64<(BUF) * 2 * TILE_BYTES + TILE_BYTES>(v_rd[dt]);                                           \
-      vhi[0][dt] = lds_tr16_b64<(BUF) * 2 * TILE_BYTES + TILE_BYTES + 8 * 128>(v_rd[dt]);                                 \
-    }                                                                                                                     \
-    static_for<0, 4>([&](auto gc) {                                                                                       \
-      constexpr int g_ = decltype(gc)::value, par = g_ & 1;                                                               \
-      if constexpr (g_ < 3) {                                                                                             \
-        _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) {                                                                \
-          vlo[par ^ 1][dt] = lds_tr16_b64<(BUF) * 2 * TILE_BYTES + TILE_BYTES + (g_ + 1) * 16 * 128>(v_rd[dt]);           \
-          vhi[par ^ 1][dt] = lds_tr16_b64<(BUF) * 2 * TILE_BYTES + TILE_BYTES + (g_ + 1) * 16 * 128 + 8 * 128>(v_rd[dt]); \
-        }                                                                                                                 \
-      }                                                                                                                   \
-      rs = TAD_MFMA_16x16x32(sel, pf[g_ >> 1][g_ & 1], rs);                                \
-      lds_wait<(g_ < 3 ? 4 : 0)>(vlo[par][0], vhi[par][0], vlo[par][1], vhi[par][1]);                                     \
-      _Pragma("unroll") for (int dt = 0; dt < 2; ++dt)                                                                    \
-        o[dt] = TAD_MFMA_32x32x16(join_tr(vlo[par][dt], vhi[par][dt]), pf[g_ >> 1][g_ & 1], o[dt]); \
-    });                                                                                                                   \
-    l_run += rs[0]; /* the lane's own query: see `sel` */                                                                 \
-    }                                                                                                                     \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                      \
-    __syncthreads();                                                                                                      \
-  }
-
+  // One K/V tile of 64 keys out of LDS ring slot BUF (a literal: every LDS address below is then lane-constant + immediate).
+  //
+  // All eight K fragments of a tile are requested in one batch (asm reads, counted waits): compiled from plain loads the chain ran
+  // read -> s_waitcnt -> MFMA eight times per tile, one exposed LDS latency each (a wave spent 31 % of its life at s_waitcnt, round-3
+  // PMC).  Their 32 registers are the ones the P / V fragments use later in the tile.
+  //
+  // Round 4 tried to take the offset subtraction out of the vector pipe as well (accumulators started from a per-wave LDS table of
+  // -m; or offset 0 with a separately compiled general body): 32 of ~110 vector instructions per tile less, and the kernel 1.4 %
+  // faster -- it is not bound by vector issue -- while every variant with two definitions of the score or
+  // output registers cost 24-56 VGPRs (a wave per SIMD).  One body, one v_sub per score.
   const int nt = (N + KV_TILE - 1) / KV_TILE;
+  float m_run = -1e30f, l_run = 0.f;  // running row maximum (units of the scores as the matrix pipe delivers them), row sum of P
+  auto fwd_tile = [&](auto BUFC, const int T) {
+    constexpr int BUF = decltype(BUFC)::value;
+    const int kv0 = T * KV_TILE;
+    if (T + 1 < nt && DMA_MODE == 0 && !(TAD_FWD_ABL & 16)) DMA_TILE(BUF ^ 1, kv0 + KV_TILE);
+    if (wave_live) {  // waves whose 32 query rows all lie past the sequence only help staging the tiles
+      op16x8 kf[2][4];
+      f32x16 s[2];
+      if constexpr (!(TAD_FWD_ABL & 8)) {
+      static_for<0, 8>([&](auto ic) {
+        constexpr int i_ = decltype(ic)::value;
+        kf[i_ >> 2][i_ & 3] = lds_read_b128<op16x8, BUF * 2 * TILE_BYTES + (i_ >> 2) * 32 * 128>(k_rd[i_ & 3]);
+      });
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+      static_for<0, 8>([&](auto ic) {
+        constexpr int i_ = decltype(ic)::value, kt = i_ >> 2, ks = i_ & 3;
+        lds_wait<7 - i_>(kf[kt][ks]);
+        s[kt] = TAD_MFMA_32x32x16(kf[kt][ks], qf[ks], s[kt]);
+      });
+      } else {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[kt][r] = o[kt][r] * 1e-3f + (float)T;  // (something live and data dependent)
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) kf[kt][ks] = qf[ks];
+        }
+      }
+      if (kv0 + KV_TILE > N) {  // ragged last tile: mask keys >= N (one lane value against 32 literals: written with the key
+                                // index on the left the compiler computes all 32 indices in front of this branch)
+        int lim = N - kv0 - 4 * h5;
+        asm volatile("" : "+v"(lim));
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (kt * 32 + (r & 3) + 8 * (r >> 2) >= lim) s[kt][r] = -1e30f;
+      }
+      float mloc = s[0][0];
+      if constexpr (!(TAD_FWD_ABL & 2)) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[kt][r]);
+      }
+      // deferred rescale: keep the old running max while the tile max exceeds it by < RESCALE_THR (log2 units): P may reach
+      // 2^THR instead of 1 (harmless in f32 / 16 bits) and the O-wide multiply disappears from almost every tile.  The decision
+      // precedes the exponentiation of this tile (textbook order).
+      const float m_tile = half_swap_max(mloc);
+      const float cq = QS ? 1.f : c;  // log2 units per score unit
+      if (__any((m_tile - m_run) * cq > RESCALE_THR)) {
+        const float m_new = fmaxf(m_run, m_tile);
+        const float alpha = fast_exp2((m_run - m_new) * cq);
+        m_run = m_new;
+        l_run *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+      }
+      const float mc = m_run * c;  // (plain q only)
+      op16x8 pf[2][2];
+      float psum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float sh = QS ? s[kt][8 * s2 + j] - m_run : fmaf(s[kt][8 * s2 + j], c, -mc);
+            const float pe = (TAD_FWD_ABL & 1) ? sh : fast_exp2(sh);
+            pf[kt][s2][j] = (op16_t)pe;
+            if (TAD_FWD_ROWSUM_VALU) psum[(j + 8 * s2) & 3] += pe;
+          }
+      f32x4 rs = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (TAD_FWD_ABL & 4) {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) asm volatile("" ::"v"(pf[kt][s2]));
+      } else if constexpr (TAD_FWD_ABL & 32) {
+        static_for<0, 4>([&](auto gc) {
+          constexpr int g_ = decltype(gc)::value;
+          rs = TAD_MFMA_16x16x32(sel, pf[g_ >> 1][g_ & 1], rs);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) o[dt] = TAD_MFMA_32x32x16(kf[dt][g_], pf[g_ >> 1][g_ & 1], o[dt]);
+        });
+      } else {
+      // V^T fragments through the asm reads of common.h (the builtin made the compiler drain the DMA of the next tile here):
+      // group g = 2 kt + s2 covers keys 16g .. 16g+15; the reads of group g+1 are issued before the MFMAs of group g
+      s16x4 vlo[2][2], vhi[2][2];  // [group parity][dt]
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        vlo[0][dt] = lds_tr16_b64<BUF * 2 * TILE_BYTES + TILE_BYTES>(v_rd[dt]);
+        vhi[0][dt] = lds_tr16_b64<BUF * 2 * TILE_BYTES + TILE_BYTES + 8 * 128>(v_rd[dt]);
+      }
+      static_for<0, 4>([&](auto gc) {
+        constexpr int g_ = decltype(gc)::value, par = g_ & 1;
+        if constexpr (g_ < 3) {
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            vlo[par ^ 1][dt] = lds_tr16_b64<BUF * 2 * TILE_BYTES + TILE_BYTES + (g_ + 1) * 16 * 128>(v_rd[dt]);
+            vhi[par ^ 1][dt] = lds_tr16_b64<BUF * 2 * TILE_BYTES + TILE_BYTES + (g_ + 1) * 16 * 128 + 8 * 128>(v_rd[dt]);
+          }
+        }
+        rs = TAD_MFMA_16x16x32(sel, pf[g_ >> 1][g_ & 1], rs);
+        lds_wait<(g_ < 3 ? 4 : 0)>(vlo[par][0], vhi[par][0], vlo[par][1], vhi[par][1]);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) o[dt] = TAD_MFMA_32x32x16(join_tr(vlo[par][dt], vhi[par][dt]), pf[g_ >> 1][g_ & 1], o[dt]);
+      });
+      }
+      if (TAD_FWD_ROWSUM_VALU) l_run += half_swap_sum((psum[0] + psum[1]) + (psum[2] + psum[3]));
+      else l_run += rs[0];  // the lane's own query: see `sel`
+    }
+    if constexpr (!(TAD_FWD_ABL & 16)) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  };
+
   DMA_TILE(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int t = 0; t < nt; t += 2) {
-    FWD_TILE(0, t);
-    if (t + 1 < nt) FWD_TILE(1, t + 1);
+    fwd_tile(std::integral_constant<int, 0>{}, t);
+    if (t + 1 < nt) fwd_tile(std::integral_constant<int, 1>{}, t + 1);
   }
 
   // ---- epilogue
@@ -253,7 +329,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
             make_float4(o[dt][4 * r4 + 0] * inv, o[dt][4 * r4 + 1] * inv, o[dt][4 * r4 + 2] * inv, o[dt][4 * r4 + 3] * inv);
       }
   }
-  if (qrow < N && h5 == 0 && lse) lse[((int64_t)b * H + head) * N + qrow] = m_run * scale + __logf(l_tot);
+  if (qrow < N && h5 == 0 && lse) lse[((int64_t)b * H + head) * N + qrow] = QS ? (m_run + __log2f(l_tot)) * 0.69314718055994530942f : m_run * scale + __logf(l_tot);
 }
 
 TAD_NAMESPACE_END
@@ -263,7 +339,7 @@ using namespace tad;
 namespace tad { namespace knobs { extern int attn_dma_mode; } }  // attn_bwd.hip (tad_attn_tuning)
 
 extern "C" int tad_attn_fwd(const uint16_t* qkv, void* out, int out_dtype, uint16_t* out_lo, float* lse, int B, int N, int H, int d,
-                            float scale, tad_stream_t stream) {
+                            float scale, int q_prescaled, tad_stream_t stream) {
   TAD_REQUIRE(qkv && out, "attn_fwd: null pointer");
   TAD_REQUIRE(!out_lo || out_dtype == TAD_OP16, "attn_fwd: out_lo (the rounding residual) goes with a 16-bit output");
   TAD_REQUIRE(d == HD, "attn_fwd: head_dim must be 64 (got %d)", d);
@@ -275,17 +351,17 @@ extern "C" int tad_attn_fwd(const uint16_t* qkv, void* out, int out_dtype, uint1
               (long long)B * N * 3 * H * HD * 2, B, N, H);
   TAD_REQUIRE((int64_t)((N + Q_BLOCK - 1) / Q_BLOCK) * H * B < (1ll << 31), "attn_fwd: grid too large");
   const dim3 grid((unsigned)(((N + Q_BLOCK - 1) / Q_BLOCK) * H * B)), block(256);
-#define LAUNCH_FWD(M_)                                                                                                      \
-  {                                                                                                                         \
-    if (out_dtype == TAD_OP16)                                                                                              \
-      hipLaunchKernelGGL((attn_fwd_kernel<true, M_>), grid, block, 0, (hipStream_t)stream, qkv, out, out_lo, lse, N, H, B, scale);  \
-    else                                                                                                                    \
-      hipLaunchKernelGGL((attn_fwd_kernel<false, M_>), grid, block, 0, (hipStream_t)stream, qkv, out, out_lo, lse, N, H, B, scale); \
-    return check_launch("attn_fwd");                                                                                        \
+#define LAUNCH_FWD_(O_, Q_, M_) hipLaunchKernelGGL((attn_fwd_kernel<O_, Q_, M_>), grid, block, 0, (hipStream_t)stream, qkv, out, out_lo, lse, N, H, B, scale)
+#define LAUNCH_FWD(M_)                                                                                \
+  {                                                                                                   \
+    if (out_dtype == TAD_OP16) { if (q_prescaled) LAUNCH_FWD_(true, true, M_); else LAUNCH_FWD_(true, false, M_); }    \
+    else { if (q_prescaled) LAUNCH_FWD_(false, true, M_); else LAUNCH_FWD_(false, false, M_); }       \
+    return check_launch("attn_fwd");                                                                  \
   }
 #ifdef TAD_GEMM_ABLATION
   if (tad::knobs::attn_dma_mode == 2) LAUNCH_FWD(2)
 #endif
   LAUNCH_FWD(0)
 #undef LAUNCH_FWD
+#undef LAUNCH_FWD_
 }

@@ -49,6 +49,8 @@ struct GemmNT {
   const float* bias;  // [N] or null
   const float* bias2; // with bias_seg > 0: columns [0, seg) take bias[n], [2 seg, 3 seg) take bias2[n - 2 seg], the rest 0 (qkv Linear)
   int bias_seg;
+  float colscale;          // EPI_PLAIN: columns [0, colscale_cols) are multiplied by colscale before the one rounding to the output
+  int colscale_cols;       // type (0 = off; a multiple of 8).  The q third of the qkv Linear: q * scale * log2(e) (tad_linear_fwd_qkv)
   const float* residual;   // [M or res_mod, N] f32 or null
   const float* gamma;      // [N] or null
   const float* rowscale;   // [ceil(M/rows_per_scale)] or null
@@ -288,6 +290,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
   for (;;) {
   STAMP(0);
   const int em0 = m0, en0 = n0;  // this tile; (m0, n0) move on to the next one when its first K-tile is prefetched
+  const bool qtile = EPI == EPI_PLAIN && p.colscale_cols > 0 && n0 < p.colscale_cols;  // (uniform) see GemmNT::colscale
   bool peeled = false;            // TAD_NT_PEEL: this tile's last K-tile carried its epilogue and the next tile's first prefetch
   // Global accesses of the epilogue's row pass are raw buffer loads / stores: rows >= M fall outside the descriptor (loads return
   // 0, stores are dropped), columns >= N get an out-of-range offset explicitly.  No per-lane branches, and the barriers of the
@@ -463,6 +466,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
             const bool fulld = nn + 8 <= p.N;
             const uint32_t o = nn < p.N ? (uint32_t)m * (uint32_t)p.N + (uint32_t)nn : OOB;
             const uint32_t ob = o == OOB ? OOB : o * 2;
+            if (qtile) {  // (uniform) a tile with columns of the pre-scaled range: tad_linear_fwd_qkv's q_prescale
+              const float cs = nn < p.colscale_cols ? p.colscale : 1.f;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { acc[i][2 * jj][e] *= cs; acc[i][2 * jj + 1][e] *= cs; }
+            }
             const u32x2 lo = u32x2{pack_op16x2(acc[i][2 * jj][0], acc[i][2 * jj][1]), pack_op16x2(acc[i][2 * jj][2], acc[i][2 * jj][3])};
             const u32x2 hi = u32x2{pack_op16x2(acc[i][2 * jj + 1][0], acc[i][2 * jj + 1][1]), pack_op16x2(acc[i][2 * jj + 1][2], acc[i][2 * jj + 1][3])};
             if (n8p) __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[0], lo[1], hi[0], hi[1]}, c_rs, ob, 0, ST_AUX);
@@ -543,6 +551,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
         float v[CPL];
 #pragma unroll
         for (int e = 0; e < CPL; ++e) v[e] = OUT_BF16 ? acc[i][2 * jj + (e >> 2)][e & 3] : acc[i][jj][e & 3];
+        if (qtile) {
+          const float cs = nn < p.colscale_cols ? p.colscale : 1.f;
+#pragma unroll
+          for (int e = 0; e < CPL; ++e) v[e] *= cs;
+        }
         if (EPI == EPI_GELU) {
           if (p.preact) {
             const uint32_t pb = o == OOB ? OOB : o * 2;
@@ -631,6 +644,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
 #pragma unroll
       for (int b = 0; b < BATCH; ++b) {
         const uint32_t ob = off[b] == OOB ? OOB : off[b] * ESZ;  // byte offset into C
+        if (qtile) {
+          const float cs = n < p.colscale_cols ? p.colscale : 1.f;
+#pragma unroll
+          for (int e = 0; e < CPL; ++e) v[b][e] *= cs;
+        }
         if (EPI == EPI_GELU) {
           if (p.preact) {
             const uint32_t pb = off[b] == OOB ? OOB : off[b] * 2;
@@ -1206,16 +1224,19 @@ int tad_linear_fwd(const uint16_t* x, const uint16_t* w, const float* bias, void
   return launch_gemm_nt(p, (hipStream_t)stream);
 }
 
-int tad_linear_fwd_qkv(const uint16_t* x, const uint16_t* w, const float* q_bias, const float* v_bias, void* y, int y_dtype, int64_t M, int N,
-                       int K, tad_stream_t stream) {
+int tad_linear_fwd_qkv(const uint16_t* x, const uint16_t* w, const float* q_bias, const float* v_bias, void* y, int y_dtype, float q_prescale,
+                       int64_t M, int N, int K, tad_stream_t stream) {
   TAD_REQUIRE(x && w && y, "linear_fwd_qkv: null pointer");
   TAD_REQUIRE((q_bias == nullptr) == (v_bias == nullptr), "linear_fwd_qkv: q_bias and v_bias come together");
   TAD_REQUIRE(y_dtype == TAD_F32 || y_dtype == TAD_OP16, "linear_fwd_qkv: bad y_dtype %d", y_dtype);
   TAD_REQUIRE(N > 0 && N % 12 == 0, "linear_fwd_qkv: N=%d must be 3 x a multiple of 4", N);
   TAD_REQUIRE(M > 0 && M < (1ll << 31), "linear_fwd_qkv: bad M");
+  TAD_REQUIRE(q_prescale > 0.f, "linear_fwd_qkv: q_prescale must be positive (1 = plain)");
+  TAD_REQUIRE(q_prescale == 1.f || N % 24 == 0, "linear_fwd_qkv: q_prescale needs N/3 = %d to be a multiple of 8", N / 3);
   GemmNT p{};
   p.A = x; p.B = w; p.C = y; p.c_bf16 = (y_dtype == TAD_OP16);
   p.bias = q_bias; p.bias2 = v_bias; p.bias_seg = q_bias ? N / 3 : 0;
+  if (q_prescale != 1.f) { p.colscale = q_prescale; p.colscale_cols = N / 3; }
   p.M = (int)M; p.N = N; p.K = K;
   p.rows_per_scale = 1;
   p.epi = EPI_PLAIN;

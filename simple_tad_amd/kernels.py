@@ -480,8 +480,18 @@ def linear_bwd_weight(dy, x, want_bias=True, dW=None, db=None, accumulate=False)
     return dW, (db if want_bias else None)
 
 
-def linear_fwd_qkv(x, w, q_bias, v_bias, out_dtype=None):
-    """qkv Linear with bias = cat(q_bias, 0, v_bias) (modeling_finetune.py:89-92) taken from the two parameters directly"""
+LOG2E = 1.4426950408889634
+
+
+def q_prescale_of(scale: float) -> float:
+    """the factor the attention kernels expect on a pre-scaled q: softmax scale * log2(e) (scores in log2 units)"""
+    return float(scale) * LOG2E
+
+
+def linear_fwd_qkv(x, w, q_bias, v_bias, out_dtype=None, q_prescale: float = 1.0):
+    """qkv Linear with bias = cat(q_bias, 0, v_bias) (modeling_finetune.py:89-92) taken from the two parameters directly.
+    q_prescale != 1: the q third of the output is multiplied by it before the rounding to the output type (`q = q * self.scale`,
+    modeling_finetune.py:96, folded into the Linear; attn_fwd / attn_bwd then take q_prescaled=True)"""
     op = _req16(x, "linear_qkv.x")
     _req16(w, "linear_qkv.w", like=op)
     out_dtype = _out16(out_dtype, op)
@@ -495,8 +505,8 @@ def linear_fwd_qkv(x, w, q_bias, v_bias, out_dtype=None):
         assert q_bias.numel() == v_bias.numel() == N // 3
     y = torch.empty((M, N), dtype=out_dtype, device=x.device)
     with _timed("gemm_nt", 2.0 * M * N * K, 2.0 * (M * K + N * K) + y.element_size() * M * N):
-        check(_fn("tad_linear_fwd_qkv", op)(x.data_ptr(), w.data_ptr(), _p(q_bias), _p(v_bias), y.data_ptr(), _dt(y), M, N, K, _stream()),
-              "tad_linear_fwd_qkv")
+        check(_fn("tad_linear_fwd_qkv", op)(x.data_ptr(), w.data_ptr(), _p(q_bias), _p(v_bias), y.data_ptr(), _dt(y), float(q_prescale), M, N, K,
+                                            _stream()), "tad_linear_fwd_qkv")
     return y
 
 
@@ -528,9 +538,10 @@ def colsum_bf16(a, out=None):
 
 
 # ----------------------------------------------------------------------------- attention
-def attn_fwd(qkv, B: int, N: int, H: int, scale: float, out_dtype=None, want_lse=True, want_lo=False):
+def attn_fwd(qkv, B: int, N: int, H: int, scale: float, out_dtype=None, want_lse=True, want_lo=False, q_prescaled=False):
     """qkv [B*N, 3*H*64] bf16 or f16 (packed [B,N,3,H,64]) -> out [B*N, H*64], lse [B,H,N] f32.  want_lo: returns (out, lse, out_lo)
-    with out_lo = what the 16-bit rounding of out dropped (for attn_bwd's delta)"""
+    with out_lo = what the 16-bit rounding of out dropped (for attn_bwd's delta).  q_prescaled: the q third already carries
+    scale * log2(e) (linear_fwd_qkv's q_prescale = q_prescale_of(scale))"""
     op = _req16(qkv, "attn.qkv")
     out_dtype = _out16(out_dtype, op)
     if qkv.numel() != B * N * 3 * H * 64:
@@ -539,8 +550,8 @@ def attn_fwd(qkv, B: int, N: int, H: int, scale: float, out_dtype=None, want_lse
     lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device) if want_lse else None
     lo = torch.empty_like(out) if (want_lo and out.dtype in OP16_DTYPES) else None
     with _timed("attn_fwd", 4.0 * B * H * N * N * 64, 2.0 * (4 + (lo is not None)) * B * N * H * 64):
-        check(_fn("tad_attn_fwd", op)(qkv.data_ptr(), out.data_ptr(), _dt(out), _p(lo), _p(lse), B, N, H, 64, float(scale), _stream()),
-              "tad_attn_fwd")
+        check(_fn("tad_attn_fwd", op)(qkv.data_ptr(), out.data_ptr(), _dt(out), _p(lo), _p(lse), B, N, H, 64, float(scale), int(bool(q_prescaled)),
+                                      _stream()), "tad_attn_fwd")
     return (out, lse, lo) if want_lo else (out, lse)
 
 
@@ -550,7 +561,8 @@ def attn_tuning(**knobs):
         check(_lib.load().tad_attn_tuning(k.encode(), int(v)), f"tad_attn_tuning({k}={v})")
 
 
-def attn_bwd(qkv, out, dout, lse, B: int, N: int, H: int, scale: float, out_lo=None):
+def attn_bwd(qkv, out, dout, lse, B: int, N: int, H: int, scale: float, out_lo=None, q_prescaled=False):
+    """dqkv; its q slot is the gradient of the PLAIN q whether or not the q of `qkv` is pre-scaled"""
     op = _req16(qkv, "attn_bwd.qkv")
     for t, n in ((out, "out"), (dout, "dout")) + (((out_lo, "out_lo"),) if out_lo is not None else ()):
         _req16(t, "attn_bwd." + n, like=op)
@@ -559,7 +571,7 @@ def attn_bwd(qkv, out, dout, lse, B: int, N: int, H: int, scale: float, out_lo=N
     delta = torch.empty((_lib.load().tad_attn_bwd_scratch_bytes(B, N, H) // 4,), dtype=torch.float32, device=qkv.device)  # -rowsum(dout*out), -lse/scale
     with _timed("attn_bwd", 8.0 * B * H * N * N * 64, 2.0 * (8 + (out_lo is not None)) * B * N * H * 64):
         check(_fn("tad_attn_bwd", op)(qkv.data_ptr(), out.data_ptr(), _p(out_lo), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), delta.data_ptr(),
-                                       B, N, H, 64, float(scale), _stream()), "tad_attn_bwd")
+                                       B, N, H, 64, float(scale), int(bool(q_prescaled)), _stream()), "tad_attn_bwd")
     return dqkv
 
 

@@ -380,6 +380,15 @@ def head_dim_of(qkv_w, H):
 _attn_exact_delta = True
 
 
+_attn_q_prescale = True  # the qkv Linear writes q * scale * log2(e) (False: plain q, the kernels scale their fragments; for A/B runs)
+
+
+def set_attn_q_prescale(on: bool):
+    """must not change between a forward and its backward"""
+    global _attn_q_prescale
+    _attn_q_prescale = bool(on)
+
+
 def set_attn_exact_delta(on: bool):
     global _attn_exact_delta
     _attn_exact_delta = bool(on)
@@ -397,8 +406,11 @@ def _attn_fwd_core(xn, qkv_w, q_bias, v_bias, B, N, H, scale, train, drop=(0.0, 
         qkv = K.linear_fwd_qkv(xn, w_bf16(qkv_w, train), qb, vb, out_dtype=torch.float32)
         ao32, lse = K.attn_fwd_f32(qkv, B, N, H, scale, want_lse=train, d=hd, drop_p=drop[0], seed=drop[1])
         return qkv, K.cast_bf16(ao32), (lse, None)
-    qkv = K.linear_fwd_qkv(xn, w_bf16(qkv_w, train), qb, vb, out_dtype=None)
-    r = K.attn_fwd(qkv, B, N, H, scale, out_dtype=None, want_lse=train, want_lo=train and _attn_exact_delta)
+    # `q = q * self.scale` (modeling_finetune.py:96) rides in the qkv Linear's epilogue, together with log2(e): the attention kernels
+    # get their scores from the matrix pipe in log2 units and spend no vector instruction on the scale (the q third of `qkv` is NOT
+    # the plain q; only tad_attn_fwd / tad_attn_bwd read it)
+    qkv = K.linear_fwd_qkv(xn, w_bf16(qkv_w, train), qb, vb, out_dtype=None, q_prescale=K.q_prescale_of(scale) if _attn_q_prescale else 1.0)
+    r = K.attn_fwd(qkv, B, N, H, scale, out_dtype=None, want_lse=train, want_lo=train and _attn_exact_delta, q_prescaled=_attn_q_prescale)
     return qkv, r[0], (r[1], r[2] if len(r) > 2 else None)
 
 
@@ -409,7 +421,7 @@ def _attn_bwd_core(d_ao, xn, qkv, ao, lse, qkv_w, has_qkv_bias, B, N, H, scale, 
         dqkv = K.cast_bf16(K.attn_bwd_f32(qkv, ao.float(), d_ao.float(), lse, B, N, H, scale, d=head_dim_of(qkv_w, H), drop_p=drop[0],
                                           seed=drop[1]))
     else:
-        dqkv = K.attn_bwd(qkv, ao, d_ao, lse, B, N, H, scale, out_lo=ao_lo)
+        dqkv = K.attn_bwd(qkv, ao, d_ao, lse, B, N, H, scale, out_lo=ao_lo, q_prescaled=_attn_q_prescale)
     dxn = K.linear_bwd_input(dqkv, wT_bf16(qkv_w, True), out_dtype=dx_dtype)
     if has_qkv_bias and qv_params is not None:
         ents = [_sink(qkv_w), _sink(qv_params[0]), _sink(qv_params[1])]

@@ -10,6 +10,7 @@ import pytest
 import torch
 
 import golden_recipe as R
+from attn_util import prescaled_pair
 from oracle import vit_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -152,14 +153,18 @@ def _attn_ref(qkv, B, N, H, scale, dout):
     return ref.detach(), qd.grad
 
 
+@pytest.mark.parametrize("prescaled", [True, False], ids=["q_prescaled", "plain_q"])
 @pytest.mark.parametrize("B,N,H", [(2, 1568, 2), (1, 200, 3), (3, 64, 1)])
-def test_attention_fwd_bwd(K, B, N, H):
+def test_attention_fwd_bwd(K, B, N, H, prescaled):
     scale = 0.125
     qkv = hf(R.tensor_for(f"hatt.qkv{N}", (B * N, 3 * H * 64), scale=1.0))
     dout = hf(R.tensor_for(f"hatt.do{N}", (B * N, H * 64)))
+    opnd = qkv
+    if prescaled:  # the production contract: q third = q * scale * log2e, rounded once (tests/attn_util.py)
+        opnd, qkv = prescaled_pair(qkv, B, N, H, scale, hf)
     ref, ref_dqkv = _attn_ref(qkv, B, N, H, scale, dout)
-    qh = dev(qkv).half()
-    out, lse, lo = K.attn_fwd(qh, B, N, H, scale, want_lo=True)
+    qh = dev(opnd).half()
+    out, lse, lo = K.attn_fwd(qh, B, N, H, scale, want_lo=True, q_prescaled=prescaled)
     assert out.dtype == torch.float16 and lo.dtype == torch.float16
     check(out.float().reshape(B, N, -1), ref, tol=ATT_TOL_F16, what="attn fwd f16")
     # (out + lo reproduces the kernel's f32 accumulator: its distance to the oracle is the rounding of P inside the kernel, not of out)
@@ -167,7 +172,7 @@ def test_attention_fwd_bwd(K, B, N, H):
     q4 = qkv.double().reshape(B, N, 3, H, 64)
     s = torch.einsum("bnhd,bmhd->bhnm", q4[:, :, 0], q4[:, :, 1]) * scale
     assert (lse.cpu().double() - torch.logsumexp(s, -1)).abs().max().item() < 2e-4
-    dqkv = K.attn_bwd(qh, out, dev(dout).half(), lse, B, N, H, scale, out_lo=lo)
+    dqkv = K.attn_bwd(qh, out, dev(dout).half(), lse, B, N, H, scale, out_lo=lo, q_prescaled=prescaled)
     assert dqkv.dtype == torch.float16
     g, r = dqkv.float().cpu().reshape(B, N, 3, H, 64), ref_dqkv.reshape(B, N, 3, H, 64)
     for i, nm in enumerate("qkv"):

@@ -9,6 +9,7 @@ import pytest
 import torch
 
 import golden_recipe as R
+from attn_util import prescaled_pair
 from oracle import vit_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -212,22 +213,30 @@ def _attn_ref(qkv, B, N, H, scale, dout=None):
     return y, q.grad
 
 
+@pytest.mark.parametrize("prescaled", [True, False], ids=["q_prescaled", "plain_q"])
 @pytest.mark.parametrize("B,N,H", ATT_SHAPES)
-def test_attention_fwd_bwd(K, B, N, H):
+def test_attention_fwd_bwd(K, B, N, H, prescaled):
+    """prescaled: the production contract (the qkv Linear writes q * scale * log2e); plain: flash-attn's contract (the kernels apply the
+    factor to the f32 scores)"""
     scale = 64 ** -0.5
     qkv = bf(R.tensor_for(f"att.qkv{N}", (B * N, 3 * H * 64), scale=1.0))
     dout = bf(R.tensor_for(f"att.do{N}", (B * N, H * 64)))
+    opnd = qkv
+    if prescaled:
+        opnd, qkv = prescaled_pair(qkv, B, N, H, scale, bf)
     ref, ref_dqkv = _attn_ref(qkv, B, N, H, scale, dout)
-    qd = dev(qkv).to(torch.bfloat16)
-    out32, lse = K.attn_fwd(qd, B, N, H, scale, out_dtype=torch.float32)
+    qd = dev(opnd).to(torch.bfloat16)
+    kw = {"q_prescaled": prescaled}
+    out32, lse = K.attn_fwd(qd, B, N, H, scale, out_dtype=torch.float32, **kw)
     check(out32.reshape(B, N, -1), ref, tol=ATT_TOL, tol_max=ATT_TOL_MAX, what="attn fwd f32")
     # lse = log sum exp(scale q.k)
     q4 = qkv.double().reshape(B, N, 3, H, 64)
     s = torch.einsum("bnhd,bmhd->bhnm", q4[:, :, 0], q4[:, :, 1]) * scale
-    assert (lse.cpu().double() - torch.logsumexp(s, -1)).abs().max().item() < 1e-3
-    out16, _ = K.attn_fwd(qd, B, N, H, scale, out_dtype=torch.bfloat16)
+    # (the kernel's row sum is taken of the bf16-rounded P the second product uses: 2^-9 per term, averaging out with the key count)
+    assert (lse.cpu().double() - torch.logsumexp(s, -1)).abs().max().item() < (1e-3 if N >= 64 else 2e-3)
+    out16, _ = K.attn_fwd(qd, B, N, H, scale, out_dtype=torch.bfloat16, **kw)
     check(out16.float().reshape(B, N, -1), ref, tol=BF16_ULP, what="attn fwd bf16")
-    dqkv = K.attn_bwd(qd, out16, dev(dout).to(torch.bfloat16), lse, B, N, H, scale)
+    dqkv = K.attn_bwd(qd, out16, dev(dout).to(torch.bfloat16), lse, B, N, H, scale, **kw)
     g = dqkv.float().cpu().reshape(B, N, 3, H, 64)
     r = ref_dqkv.reshape(B, N, 3, H, 64)
     for i, nm in enumerate("qkv"):
@@ -235,8 +244,15 @@ def test_attention_fwd_bwd(K, B, N, H):
         check(g[:, :, i], r[:, :, i], tol=2 * BF16_ULP, what=f"attn d{nm}")
 
 
-def test_attention_softmax_spike(K):
-    """force large, late-arriving row maxima (online-softmax rescale path) and a long ragged sequence"""
+@pytest.mark.parametrize("prescaled", [True, False], ids=["q_prescaled", "plain_q"])
+def test_attention_softmax_spike(K, prescaled):
+    """Force every branch of the online softmax's offset handling (cdna_hip_programming.md rule 26: a rare data-dependent branch needs an
+    input that takes it).  The kernel keeps the offset at 0 while a row's tile maxima stay inside (-RESCALE_LOW, RESCALE_THR] log2
+    units, re-bases on the first tile when its maximum is below that window and whenever a later tile's maximum exceeds it; the
+    score accumulators then start from the per-wave LDS table instead of the constant 0:
+      query 17: late-arriving maxima in tiles 0 and 2 (two upward moves);  query 64: one upward move in tile 2;
+      query 40: every score far below 0 (q anti-parallel to all keys' common component): downward move on the first tile;
+      query 41: far below 0 in tile 0, a key in tile 1 with a positive score far above the (negative) offset."""
     B, N, H = 1, 200, 1
     scale = 64 ** -0.5
     qkv = bf(R.tensor_for("att.spike", (B * N, 3 * H * 64), scale=1.0))
@@ -244,10 +260,21 @@ def test_attention_softmax_spike(K):
     q4[0, 5, 1, 0] = q4[0, 17, 0, 0] * 6.0    # key 5 aligns with query 17
     q4[0, 190, 1, 0] = q4[0, 17, 0, 0] * 12.0  # later key with an even larger score
     q4[0, 130, 1, 0] = q4[0, 64, 0, 0] * 10.0
+    q4[0, :, 1, 0] += 3.0 * torch.ones(64)     # a common component in every key ...
+    q4[0, 40, 0, 0] = -4.0 * torch.ones(64)    # ... against which query 40 scores ~ -96 * 1.44 everywhere
+    q4[0, 41, 0, 0] = -4.0 * torch.ones(64)
+    q4[0, 100, 1, 0] = -2.0 * torch.ones(64)   # ... except query 41 on key 100 (tile 1): +64
     qkv = bf(q4.reshape(B * N, -1))
+    opnd = qkv
+    if prescaled:
+        opnd, qkv = prescaled_pair(qkv, B, N, H, scale, bf)
     ref, _ = _attn_ref(qkv, B, N, H, scale)
-    out32, _ = K.attn_fwd(dev(qkv).to(torch.bfloat16), B, N, H, scale, out_dtype=torch.float32)
+    out32, lse = K.attn_fwd(dev(opnd).to(torch.bfloat16), B, N, H, scale, out_dtype=torch.float32, q_prescaled=prescaled)
+    assert torch.isfinite(out32).all() and torch.isfinite(lse).all()
     check(out32.reshape(B, N, -1), ref, tol=4e-3, what="attn spike")  # P is bf16 inside the kernel: ulp-level error on O(1) weights
+    q4d = qkv.double().reshape(B, N, 3, H, 64)
+    s = torch.einsum("bnhd,bmhd->bhnm", q4d[:, :, 0], q4d[:, :, 1]) * scale
+    assert (lse.cpu().double() - torch.logsumexp(s, -1)).abs().max().item() < 5e-3  # (|lse| reaches ~100 here)
 
 
 # ------------------------------------------------------------------ helpers
@@ -412,6 +439,39 @@ def test_linear_persistent_schedule_is_bit_identical(K, M, N, Kd, mode):
     got = y0[rows].double()
     tol = TOL if y0.dtype == torch.float32 else 2 * BF16_ULP
     assert float((got - ref).abs().max() / ref.abs().max()) < tol
+
+
+@pytest.mark.parametrize("M,D,Kd", [(25088 + 5, 768, 768), (20000 + 3, 384, 384), (300, 128, 128), (40000, 1024, 256)])
+def test_qkv_linear_q_prescale_every_schedule(K, M, D, Kd):
+    """tad_linear_fwd_qkv(q_prescale): `q = q * self.scale` (modeling_finetune.py:96) folded into the qkv Linear -- the q third of the
+    output is multiplied by the factor before its ONE rounding, k and v thirds and the (q_bias, 0, v_bias) bias are those of the plain
+    Linear; identical bits from every scheduling path (per-tile / persistent, LDS / register epilogue, peeled last K-tile); D = 384 puts
+    the q | k boundary inside a 256-column tile."""
+    g = torch.Generator().manual_seed(M + D)
+    x = dev(torch.randn(M, Kd, generator=g)).to(torch.bfloat16)
+    w = dev(torch.randn(3 * D, Kd, generator=g) * 0.05).to(torch.bfloat16)
+    qb, vb = dev(torch.randn(D, generator=g)), dev(torch.randn(D, generator=g))
+    c = K.q_prescale_of(64 ** -0.5)
+    outs = {}
+    try:
+        base = dict(persistent=0, direct_epilogue=0, split_tail=0)
+        for name, cfg in [("tile", {}), ("tile_direct", dict(direct_epilogue=2)), ("persist", dict(persistent=1)),
+                          ("persist_direct", dict(persistent=1, direct_epilogue=2)), ("default", K.LINEAR_TUNING_DEFAULTS)]:
+            K.linear_tuning(**{**base, **cfg})
+            outs[name] = (K.linear_fwd_qkv(x, w, qb, vb, q_prescale=c).clone(), K.linear_fwd_qkv(x, w, qb, vb, out_dtype=torch.float32, q_prescale=c).clone())
+        plain = K.linear_fwd_qkv(x, w, qb, vb)
+    finally:
+        K.linear_tuning(**K.LINEAR_TUNING_DEFAULTS)
+    y0, y0f = outs["tile"]
+    for name in ("tile_direct", "persist", "persist_direct", "default"):
+        assert torch.equal(y0, outs[name][0]) and torch.equal(y0f, outs[name][1]), f"{name}: differs from per-tile scheduling"
+    assert torch.equal(y0[:, D:], plain[:, D:]), "k / v thirds must be the plain Linear's"
+    rows = torch.randint(0, M, (64,), generator=g).tolist() + [0, M - 1]
+    ref = x[rows].double() @ w.double().t()
+    ref[:, :D] = (ref[:, :D] + qb.double()) * c
+    ref[:, 2 * D:] += vb.double()
+    assert float((y0f[rows].double() - ref).abs().max() / ref.abs().max()) < TOL
+    assert float((y0[rows].double() - ref).abs().max() / ref.abs().max()) < 2 * BF16_ULP
 
 
 def test_linear_taller_than_the_32bit_epilogue_offsets(K):

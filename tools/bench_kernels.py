@@ -79,12 +79,19 @@ def main():
             del dy, x
     if want("attn"):
         qkv = rnd(M, 3 * D)
-        out, lse = K.attn_fwd(qkv, B, N, H, 0.125)
-        ms = timeit(lambda: K.attn_fwd(qkv, B, N, H, 0.125), a.iters)
-        rows.append(("attn_fwd", ms, 4.0 * B * H * N * N * 64 / ms / 1e9))
         dout = rnd(M, D)
-        ms = timeit(lambda: K.attn_bwd(qkv, out, dout, lse, B, N, H, 0.125), a.iters)
-        rows.append(("attn_bwd (alg. 2x fwd flops)", ms, 8.0 * B * H * N * N * 64 / ms / 1e9))
+        # production contract: the q third carries scale * log2e (tad_linear_fwd_qkv's q_prescale); plain q = flash-attn's contract
+        qkv_p = qkv.clone()
+        qkv_p[:, :D] = (qkv[:, :D].float() * K.q_prescale_of(0.125)).to(qkv.dtype)
+        for tag, t, pre in (("q pre-scaled", qkv_p, True), ("plain q", qkv, False)):
+            out, lse = K.attn_fwd(t, B, N, H, 0.125, q_prescaled=pre)
+            ms = timeit(lambda: K.attn_fwd(t, B, N, H, 0.125, q_prescaled=pre), a.iters)
+            rows.append((f"attn_fwd [{tag}]", ms, 4.0 * B * H * N * N * 64 / ms / 1e9))
+            out, lse, lo = K.attn_fwd(t, B, N, H, 0.125, want_lo=True, q_prescaled=pre)
+            ms = timeit(lambda: K.attn_fwd(t, B, N, H, 0.125, want_lo=True, q_prescaled=pre), a.iters)
+            rows.append((f"attn_fwd + out_lo [{tag}]", ms, 4.0 * B * H * N * N * 64 / ms / 1e9))
+            ms = timeit(lambda: K.attn_bwd(t, out, dout, lse, B, N, H, 0.125, out_lo=lo, q_prescaled=pre), a.iters)
+            rows.append((f"attn_bwd (alg. 2x fwd flops) [{tag}]", ms, 8.0 * B * H * N * N * 64 / ms / 1e9))
     if want("ln"):
         x = torch.randn(M, D, device=dev)
         g, b = torch.ones(D, device=dev), torch.zeros(D, device=dev)
