@@ -49,7 +49,7 @@ typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 // pipe in log2 units.  Without it (plain q, flash-attn's contract) the factor is applied to the f32 scores: one v_fma per score where the
 // pre-scaled form has a v_sub, same numerics as rounds 1-3.
 template <bool OUT_BF16, bool QS, int DMA_MODE>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, void* __restrict__ out,
+__global__ __launch_bounds__(256, TAD_FWD_ROWSUM_VALU ? 4 : 1) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, void* __restrict__ out,
                                                        uint16_t* __restrict__ out_lo, float* __restrict__ lse, int N, int H, int B,
                                                        float scale) {
   constexpr int TILE_BYTES = KV_TILE * HD * 2;                                  // 8 KiB
