@@ -561,11 +561,16 @@ def main():
                 assert isinstance(opt_h, FusedAdamW)
                 sc_h = E.NativeScalerWithGradNormCount(dp)
                 opt_keep, sc_keep = opt, scaler
+                #  the half-mode optimizer steps on the SAME flat parameter buffer with fresh moments: the headline
+                # optimizer's parameters are put back afterwards, so its moments, step count and mirrors stay one consistent state
+                param_keep = opt.flat_param.clone()
                 opt, scaler = opt_h, sc_h
                 try:
                     dth = timed_steps(3, 10)
                 finally:
                     opt, scaler = opt_keep, sc_keep
+                    opt.flat_param.copy_(param_keep)
+                    del param_keep
                 hs = {"value": round(B / dth, 2), "unit": "clips/sec", "ms_per_step": round(1e3 * dth, 3), "steps": 10, "warmup": 3,
                       "frac_of_f16_mfma_roofline": round(B / dth * f_fb / (PEAK_BF16_TFLOPS * 1e12), 4), "operands": "IEEE half, f32 accumulation",
                       "loss_scale": sc_h.state_dict()["scale"], "skipped_steps": sc_h.skipped_steps,
@@ -696,7 +701,7 @@ def mae_step(T, E, K, dev, class_table, batch=32, steps=8, warmup=3, model_name=
            "workload": f"{model_name}, decoder depth {decoder_depth}, 16x224x224, {batch} clips, tube mask {mask_ratio}: {n_vis} visible / "
                        f"{n_mask} masked tokens (BASELINE configs[4] on one GPU)",
            "algorithmic_gflop_per_clip": round(f_step / 1e9, 1), "frac_of_bf16_mfma_roofline": round(batch * f_step / dt / (PEAK_BF16_TFLOPS * 1e12), 4),
-           "loss": float(last), "parameters": sum(p.numel() for p in params), "roofline_all": ra}
+           "loss": float(last.detach()), "parameters": sum(p.numel() for p in params), "roofline_all": ra}
     del model, dp, opt
     torch.cuda.empty_cache()
     return res

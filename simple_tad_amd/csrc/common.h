@@ -193,12 +193,20 @@ __device__ __forceinline__ void store_rows_via_lds(char* patch, const uint2 (&pk
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int r4 = 0; r4 < 4; ++r4) *reinterpret_cast<uint2*>(patch + rl * 144 + (dt * 32 + 8 * r4 + 4 * h5) * 2) = pk[dt][r4];
+  // The rows are read back by OTHER lanes through a differently typed pointer: make the order explicit instead of relying on the
+  // compiler keeping differently typed LDS accesses in program order -- a workgroup-scope fence (no instruction beyond
+  // the s_waitcnt lgkmcnt(0) the read-back needs anyway; the LDS executes one wave's operations in order).
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = 8 * i + (lane >> 3), ch = lane & 7;
     const uint4 v = *reinterpret_cast<const uint4*>(patch + row * 144 + ch * 16);
     if (row < rows_valid) *reinterpret_cast<uint4*>(dst + row * row_stride + ch * 8) = v;
   }
+  // (a following call reuses the patch: its writes must not pass these reads)
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
 // compile-time loop: f(std::integral_constant<int, I>) for I in [BEGIN, END)

@@ -205,10 +205,15 @@ class NativeScalerWithGradNormCount:
                 norm = optimizer.step(want_sumsq=True).sqrt()
             return norm
         if scaling:  # any other optimizer: unscale in place (GradScaler.unscale_), then the reference's order
-            grads = [p.grad for p in (parameters or []) if p.grad is not None]
-            for g in grads:
+            if parameters is None:
+                raise ValueError("NativeScalerWithGradNormCount: loss scaling with an optimizer other than FusedAdamW needs `parameters` "
+                                 "(the gradients are unscaled and checked here before the step)")
+            grads = [p.grad for p in parameters if p.grad is not None]
+            found = torch.zeros((), dtype=torch.float32, device=grads[0].device) if grads else None
+            for g in grads:  # one reduction per tensor on the device, ONE host read for all of them
                 g.mul_(inv)
-            found_inf = not all(bool(torch.isfinite(g).all()) for g in grads)
+                found += (~torch.isfinite(g)).any().float()
+            found_inf = bool(grads) and bool(found.item() > 0)
             self._update_scale(found_inf)
             if found_inf:
                 return torch.tensor(float("inf"))
@@ -226,15 +231,27 @@ class NativeScalerWithGradNormCount:
         return norm
 
     def state_dict(self):
-        """GradScaler.state_dict()'s keys; ``scale`` reads 1.0 while no scaling is applied (what the engines log as loss_scale)"""
+        """GradScaler.state_dict()'s keys.  ``scale`` reads 1.0 while no scaling is applied -- the engines log it as loss_scale each step
+        (engine_for_finetuning.py:100) -- and the scale this object carries travels beside it as ``_scale`` so that a checkpoint
+        written in one precision mode resumes correctly in another (the 65536 of a half-mode run used to be dropped when
+        the precision was set after the load, and a bf16-mode checkpoint installed scale 1.0 in a half-mode run)."""
         self._settle()
         return {"scale": self.scale if self.scaling() else 1.0, "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
-                "growth_interval": self.growth_interval, "_growth_tracker": self.growth_tracker}
+                "growth_interval": self.growth_interval, "_growth_tracker": self.growth_tracker, "_scale": self.scale}
 
     def load_state_dict(self, state_dict):
-        if self.scaling() and "scale" in state_dict:
+        """restores the carried scale whatever the precision mode is at this moment; a checkpoint without ``_scale`` (the reference's
+        GradScaler, or an older run of this package) provides ``scale``, which is ignored when it is the 1.0 placeholder of a run that
+        applied no scaling"""
+        if "_scale" in state_dict:
+            self.scale = float(state_dict["_scale"])
+        elif "scale" in state_dict and float(state_dict["scale"]) != 1.0:
             self.scale = float(state_dict["scale"])
-            self.growth_tracker = int(state_dict.get("_growth_tracker", 0))
+        elif "scale" in state_dict and self.scaling():
+            import warnings
+            warnings.warn("NativeScalerWithGradNormCount.load_state_dict: the checkpoint carries loss scale 1.0 (written without loss scaling); "
+                          f"keeping this run's scale {self.scale:g} for the IEEE-half mode")
+        self.growth_tracker = int(state_dict.get("_growth_tracker", self.growth_tracker))
 
 
 METER_NAMES = ("loss", "class_acc", "grad_norm", "lr", "min_lr", "loss_scale")

@@ -65,3 +65,54 @@ def test_train_one_epoch_step_ordering():
         assert abs(lr - lr_sched[i // 2] * 0.5) < 1e-12 and abs(wd - wd_sched[i // 2]) < 1e-12
     assert all(s == 1.0 for s in stats["loss_scale"])
     assert all(p.grad is not None and float(p.grad.abs().sum()) == 0.0 for p in model.parameters())  # zero_grad after update
+
+
+def test_loss_scaler_state_round_trips_across_precision_modes():
+    """the carried loss scale survives a checkpoint whatever the precision mode was on either side; the logged ``scale``
+    stays GradScaler's key and reads 1.0 while no scaling is applied (engine_for_finetuning.py:100 logs it every step)"""
+    import warnings
+    from simple_tad_amd import engine as E
+    half = E.NativeScalerWithGradNormCount(enabled=True)
+    half.scale, half.growth_tracker = 2.0 ** 20, 7
+    sd = half.state_dict()
+    assert sd["scale"] == 2.0 ** 20 and sd["_scale"] == 2.0 ** 20 and sd["_growth_tracker"] == 7
+    # restored into a run whose precision is (still) not half: the scale must not be dropped ...
+    later = E.NativeScalerWithGradNormCount(enabled=False)
+    later.load_state_dict(sd)
+    assert later.scale == 2.0 ** 20 and later.growth_tracker == 7 and later.state_dict()["scale"] == 1.0
+    later.enabled = True  # ... so that switching to half afterwards continues from it
+    assert later.state_dict()["scale"] == 2.0 ** 20
+    # a checkpoint written without loss scaling carries the 1.0 placeholder: it must not install scale 1.0 in a half-mode run
+    plain = E.NativeScalerWithGradNormCount(enabled=False).state_dict()
+    assert plain["scale"] == 1.0 and plain["_scale"] == 65536.0
+    resumed = E.NativeScalerWithGradNormCount(enabled=True)
+    resumed.load_state_dict(plain)
+    assert resumed.scale == 65536.0
+    with warnings.catch_warnings(record=True) as w:  # the reference's GradScaler.state_dict() of an unscaled run (no `_scale`)
+        warnings.simplefilter("always")
+        legacy = E.NativeScalerWithGradNormCount(enabled=True)
+        legacy.load_state_dict({"scale": 1.0, "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 2000, "_growth_tracker": 3})
+        assert legacy.scale == 65536.0 and legacy.growth_tracker == 3 and any("loss scale 1.0" in str(x.message) for x in w)
+    legacy.load_state_dict({"scale": 4096.0})
+    assert legacy.scale == 4096.0
+
+
+def test_loss_scaling_with_a_plain_optimizer_needs_the_parameter_list():
+    import pytest
+    import torch
+    from simple_tad_amd import engine as E
+    lin = torch.nn.Linear(4, 2)
+    opt = torch.optim.SGD(lin.parameters(), lr=0.1)
+    sc = E.NativeScalerWithGradNormCount(enabled=True)
+    with pytest.raises(ValueError, match="parameters"):
+        sc(lin(torch.randn(3, 4)).sum(), opt, parameters=None)
+    w0 = lin.weight.detach().clone()
+    sc(lin(torch.randn(3, 4)).sum(), opt, parameters=list(lin.parameters()))
+    assert not torch.equal(w0, lin.weight) and sc.scale == 65536.0 and sc.growth_tracker == 1
+    # an overflowing step is skipped and halves the scale
+    sc2 = E.NativeScalerWithGradNormCount(enabled=True)
+    lin2 = torch.nn.Linear(4, 2)
+    opt2 = torch.optim.SGD(lin2.parameters(), lr=0.1)
+    before = lin2.weight.detach().clone()
+    n = sc2((lin2(torch.ones(3, 4)) * float("inf")).sum(), opt2, parameters=list(lin2.parameters()))
+    assert not torch.isfinite(n) and sc2.scale == 32768.0 and sc2.skipped_steps == 1 and torch.equal(before, lin2.weight)
