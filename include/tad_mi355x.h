@@ -118,15 +118,21 @@ int tad_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float*
  * x [M,K] bf16, w [N,K] bf16, bias [N] f32 (nullable), y [M,N] y_dtype.
  * preact [M,N] bf16 (nullable): x W^T + b before GELU (saved for backward).
  * residual [M,N] f32, gamma [N] f32 (nullable), rowscale f32 [ceil(M/rows_per_scale)] (nullable). */
+/* ws (nullable; tad_linear_workspace_bytes(M, N, K) bytes, private to the call's stream until the launches have run): scratch for the
+ * split-K form of an under-filled last round of tiles -- an N = 768 Linear at 50176 rows is 588 tiles of 256 x 256 = 2.3 rounds of
+ * one workgroup per CU; with a workspace the last 78 tiles run as 3 shares each on 234 CUs (their f32 partial tiles are combined
+ * inside the launch) instead of one K loop on 156 CUs.  The launch then needs its grid resident at once: pass NULL while other
+ * kernels (an overlapped RCCL exchange) hold CUs.  Results differ from the ws == NULL plan only in the summation order over K. */
+size_t tad_linear_workspace_bytes(int64_t M, int N, int K);
 int tad_linear_fwd(const uint16_t* x, const uint16_t* w, const float* bias, void* y, int y_dtype,
                    int epilogue, uint16_t* preact, const float* residual, const float* gamma,
-                   const float* rowscale, int rows_per_scale, int64_t M, int N, int K,
+                   const float* rowscale, int rows_per_scale, void* ws, size_t ws_bytes, int64_t M, int N, int K,
                    tad_stream_t stream);
 /* Input gradient: dx [M,K] = (dy [M,N] @ W)  using wT [K,N] bf16.
  * If gelu_preact [M,K] is given, dx *= gelu'(preact) (backward through the GELU that fed this Linear).
  * colscale [N] / rowscale are applied to dy on the fly is NOT supported; scale dy beforehand. */
 int tad_linear_bwd_input(const uint16_t* dy, const uint16_t* wT, void* dx, int dx_dtype,
-                         const uint16_t* gelu_preact, int64_t M, int N, int K, tad_stream_t stream);
+                         const uint16_t* gelu_preact, void* ws, size_t ws_bytes, int64_t M, int N, int K, tad_stream_t stream);
 /* The qkv Linear of Attention (modeling_finetune.py:64-76, 89-92): bias = cat(q_bias, zeros, v_bias) without materialising it.
  * N = 3 * all_head_dim; q_bias / v_bias [N/3] f32 (both or neither).  Forward: y = x W^T + bias.  Weight gradient: as
  * tad_linear_bwd_weight, with the column sums of the first / last third of dy going to dq_bias / dv_bias (workspace: the same
@@ -144,7 +150,9 @@ int tad_linear_bwd_weight_qkv(const uint16_t* dy, const uint16_t* x, float* dW, 
  *   "direct_epilogue" 2 = epilogue on the accumulator registers, stores straight from the MFMA layout; 0 = accumulators
  *                     transposed through the LDS first (whole rows per store instruction); 1 = per epilogue kind (default)
  *   "split_tail"      1 = a Linear whose 256 x 256 tiles do not fill whole rounds of one workgroup per CU may run as two
- *                     launches (whole rounds + remaining rows) when the cost model says so (default); 0 = never; 2 = always */
+ *                     launches (whole rounds + remaining rows) when the cost model says so (default); 0 = never; 2 = always
+ *   "splitk_tail"     1 = with a workspace, the second of those launches may split its tiles along K (default); 0 = never;
+ *                     2 = whenever eligible (this one changes the summation order over K of the rows it covers) */
 int tad_linear_tuning(const char* key, int value);
 /* Number of gemm_nt kernel launches issued so far by tad_linear_fwd* / tad_linear_bwd_input / tad_patch_embed_* (a call is one
  * launch, or two when the split-tail plan is taken): lets a profiler attribute event time to kernel launches. */
@@ -347,12 +355,12 @@ int tad_layernorm_bwd_f16(const void* dy, int dy_dtype, const float* x, const fl
                           const float* rowscale, int rows_per_scale, int accumulate, void* ws, size_t ws_bytes, int64_t rows, int D,
                           tad_stream_t stream);
 int tad_linear_fwd_f16(const uint16_t* x, const uint16_t* w, const float* bias, void* y, int y_dtype, int epilogue, uint16_t* preact,
-                       const float* residual, const float* gamma, const float* rowscale, int rows_per_scale, int64_t M, int N, int K,
-                       tad_stream_t stream);
+                       const float* residual, const float* gamma, const float* rowscale, int rows_per_scale, void* ws, size_t ws_bytes,
+                       int64_t M, int N, int K, tad_stream_t stream);
 int tad_linear_fwd_qkv_f16(const uint16_t* x, const uint16_t* w, const float* q_bias, const float* v_bias, void* y, int y_dtype,
                            float q_prescale, int64_t M, int N, int K, tad_stream_t stream);
-int tad_linear_bwd_input_f16(const uint16_t* dy, const uint16_t* wT, void* dx, int dx_dtype, const uint16_t* gelu_preact, int64_t M,
-                             int N, int K, tad_stream_t stream);
+int tad_linear_bwd_input_f16(const uint16_t* dy, const uint16_t* wT, void* dx, int dx_dtype, const uint16_t* gelu_preact, void* ws,
+                             size_t ws_bytes, int64_t M, int N, int K, tad_stream_t stream);
 int tad_linear_bwd_weight_f16(const uint16_t* dy, const uint16_t* x, float* dW, float* db, int accumulate, void* ws, size_t ws_bytes,
                               int64_t M, int N, int K, tad_stream_t stream);
 int tad_linear_bwd_weight_qkv_f16(const uint16_t* dy, const uint16_t* x, float* dW, float* dq_bias, float* dv_bias, int accumulate,

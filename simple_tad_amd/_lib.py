@@ -29,13 +29,14 @@ SIGNATURES = {
     "tad_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i64, _i, _f, _vp]),
     "tad_layernorm_bwd_workspace_bytes": (_sz, [_i64, _i]),
     "tad_layernorm_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _sz, _i64, _i, _vp]),
-    "tad_linear_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp]),
+    "tad_linear_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _sz, _i64, _i, _i, _vp]),
+    "tad_linear_workspace_bytes": (_sz, [_i64, _i, _i]),
     "tad_linear_tuning": (_i, [C.c_char_p, _i]),
     "tad_linear_fwd_qkv": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _i64, _i, _i, _vp]),
     "tad_linear_bwd_weight_qkv": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _i64, _i, _i, _vp]),
     "tad_linear_debug_stamps": (_i, [_vp]),
     "tad_linear_kernel_launches": (C.c_longlong, []),
-    "tad_linear_bwd_input": (_i, [_vp, _vp, _vp, _i, _vp, _i64, _i, _i, _vp]),
+    "tad_linear_bwd_input": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _sz, _i64, _i, _i, _vp]),
     "tad_linear_bwd_weight_workspace_bytes": (_sz, [_i64, _i, _i]),
     "tad_linear_bwd_weight": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _sz, _i64, _i, _i, _vp]),
     "tad_attn_fwd": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),

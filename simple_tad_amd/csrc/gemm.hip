@@ -64,6 +64,13 @@ struct GemmNT {
   int M, N, K;
   int debug;  // ablation (TAD_GEMM_DEBUG, timing only, wrong results): 1 = no DMA inside the K loop, 2 = no MFMA, 4 = no epilogue,
               // 8 = (gemm_tn) no fragment reads and no MFMA: staging and barriers only, 16 = (gemm_tn) unswizzled DMA source
+  // split-K launch (SPLITK kernels: the under-filled last round of a Linear, see launch_gemm_nt): every 256 x 256 tile is computed by
+  // sk_splits workgroups, each over its share of the K-tiles; sk_ws holds their f32 partial tiles [tile][split][256][256], sk_cnt one
+  // arrival counter per tile (zeroed by the launcher), sk_err a word that is set if a wait gave up
+  float* sk_ws;
+  unsigned* sk_cnt;
+  unsigned* sk_err;
+  int sk_splits;
   int group_m;        // tile raster: row panels swept per column panel before moving to the next column panel (L2 reuse)
   unsigned long long* stamps;  // debug timeline (tad_linear_debug_stamps): per workgroup 64 slots of 4 x s_memrealtime, or null
 };
@@ -129,8 +136,15 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 // PERSIST: one workgroup per CU walks a strided list of tiles (see the comment at the tile loop).
 // DIRECT: the epilogue runs on the accumulator registers and stores straight from the MFMA layout (16 rows x 64 contiguous bytes
 // per store instruction); otherwise the accumulators are transposed through the LDS first (whole rows per instruction).
-template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int EPI, bool OUT_BF16, bool PERSIST, bool DIRECT>
+// SPLITK: one workgroup = one SHARE of a tile's K-tiles (grid = tiles x p.sk_splits, all of them resident at once: the launcher keeps
+// the grid within one workgroup per CU).  The workgroup leaves its f32 partial tile in p.sk_ws, announces it on the tile's arrival
+// counter, waits until all shares of the tile are there, and then finishes ITS rows of the tile: sum over the shares, epilogue,
+// store.  Nobody waits before publishing, so the wait cannot deadlock while the grid is resident; it is bounded all the same.
+// The hand-off follows cdna_hip_programming.md Guideline 16 (plain stores, every wave's vmcnt(0), barrier, one lane's agent-scope
+// release, counter add; one relaxed poll, one agent-scope acquire, barrier, plain loads) and depends on no placement.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int EPI, bool OUT_BF16, bool PERSIST, bool DIRECT, bool SPLITK = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const GemmNT p) {
+  static_assert(!SPLITK || (!PERSIST && !DIRECT && BM == 256 && BN == 256 && (EPI == EPI_PLAIN || EPI == EPI_RESIDUAL)), "split-K variant");
   constexpr int BKT = BK;
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr bool IS_RES = (EPI == EPI_RESIDUAL || EPI == EPI_RESMOD);
@@ -178,11 +192,18 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
     t_cur = t_first + j;
     t_end = t_first + (tiles_m * tiles_n >> 3) + ((xcd < ((tiles_m * tiles_n) & 7)) ? 1 : 0);
     t_step = gridDim.x >> 3;
+  } else if (SPLITK) {
+    // logical id = tile * splits + share: the XCD remap keeps consecutive logical ids -- the shares of one tile -- on one XCD
+    // (speed only: the partial tiles then travel through one L2)
+    t_cur = xcd_remap(blockIdx.x, gridDim.x) / p.sk_splits;
+    t_end = t_cur + 1;
+    t_step = 1;
   } else {
     t_cur = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     t_end = t_cur + 1;
     t_step = 1;
   }
+  const int sk_share = SPLITK ? xcd_remap(blockIdx.x, gridDim.x) % p.sk_splits : 0;
   int m0, n0;
 #define DECODE_TILE(tile)                                  \
   {                                                        \
@@ -211,8 +232,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
     }                                                                                                                  \
   }
 #define STAGE_NT(buf, kt) \
-  stage_tile<BM / (RPP * NW), NW, true>(p.A, a_bytes, lds + (buf) * STAGE_BYTES, a_off, (uint32_t)(kt) * ROWB, wave); \
-  stage_tile<BN / (RPP * NW), NW, true>(p.B, b_bytes, lds + (buf) * STAGE_BYTES + A_BYTES, b_off, (uint32_t)(kt) * ROWB, wave)
+  stage_tile<BM / (RPP * NW), NW, true>(p.A, a_bytes, lds + (buf) * STAGE_BYTES, a_off, (uint32_t)((kt) + kt0) * ROWB, wave); \
+  stage_tile<BN / (RPP * NW), NW, true>(p.B, b_bytes, lds + (buf) * STAGE_BYTES + A_BYTES, b_off, (uint32_t)((kt) + kt0) * ROWB, wave)
 
   // ---- fragment addressing
   const int c = lane & 15, kq = lane >> 4;
@@ -240,7 +261,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
     b_sw[j] = sw_nt(row);
   }
 
-  const int nk = p.K / BKT;
+  const int nk_all = p.K / BKT;
+  const int kt0 = SPLITK ? sk_share * nk_all / p.sk_splits : 0;                       // this workgroup's K-tiles: [kt0, kt0 + nk)
+  const int nk = SPLITK ? (sk_share + 1) * nk_all / p.sk_splits - kt0 : nk_all;
 #define FRAG_A(dst, base, ks) \
   _Pragma("unroll") for (int i = 0; i < MREP; ++i)  \
       dst[i] = *reinterpret_cast<const op16x8*>((base) + a_rd[i] + ((((KSTEPS > 1 ? 4 * (ks) : 0) + kq) ^ a_sw[i]) << 4))
@@ -290,6 +313,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
   for (;;) {
   STAMP(0);
   const int em0 = m0, en0 = n0;  // this tile; (m0, n0) move on to the next one when its first K-tile is prefetched
+  const int etile = t_cur;
   const bool qtile = EPI == EPI_PLAIN && p.colscale_cols > 0 && n0 < p.colscale_cols;  // (uniform) see GemmNT::colscale
   bool peeled = false;            // TAD_NT_PEEL: this tile's last K-tile carried its epilogue and the next tile's first prefetch
   // Global accesses of the epilogue's row pass are raw buffer loads / stores: rows >= M fall outside the descriptor (loads return
@@ -311,7 +335,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
   // What the epilogue READS besides the accumulators (f32 residual rows / bf16 pre-activation rows) is fetched one chunk ahead:
   // chunk 0 during the last K-tile of the main loop, chunk q + 1 while chunk q is processed.  Fetched on demand, each batch of
   // rows exposed a full HBM latency (4 batches x ~3 us per 256 x 128 f32 tile: longer than that tile's K loop at K = 768).
-  constexpr bool HAS_EXTRA = (IS_RES || EPI == EPI_DGELU);
+  constexpr bool HAS_EXTRA = !SPLITK && (IS_RES || EPI == EPI_DGELU);  // (the split-K variant reads them in its combine pass)
   constexpr int EXW = (IS_RES) ? CPL / 4 : 1;
   constexpr int NJ = OUT_BF16 ? NREP / 2 : NREP;  // DIRECT: 16-byte column groups per lane and m-fragment
   u32x4 extra[2][HAS_EXTRA ? (DIRECT ? NJ : NR) : 1][EXW];
@@ -378,7 +402,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
   for (int j = 0; j < NREP; ++j) {
     const int nc = n0 + wn * WTN + (OUT_BF16 ? (32 * (j >> 1) + 8 * kq + 4 * (j & 1)) : (16 * j + 4 * kq));
     f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (EPI != EPI_DGELU && p.bias && nc < p.N) {
+    if (EPI != EPI_DGELU && p.bias && nc < p.N && (!SPLITK || sk_share == 0)) {
       if (EPI == EPI_PLAIN && p.bias_seg > 0) {
         if (nc < p.bias_seg || nc >= 2 * p.bias_seg) {
           const float4 t = *reinterpret_cast<const float4*>(nc < p.bias_seg ? p.bias + nc : p.bias2 + (nc - 2 * p.bias_seg));
@@ -606,7 +630,136 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
       }
     }
   }
-  if (!DIRECT && !((DBG_BITS(p) & 4) && p.M > 1)) {
+  if constexpr (SPLITK) {
+    // ---- split-K: (1) the partial tile goes to the workspace as whole rows, through the LDS transposition of the ordinary epilogue
+    const int S = p.sk_splits;
+    float* const part = p.sk_ws + ((size_t)etile * S + sk_share) * (size_t)(BM * BN);
+    const auto part_rs = __builtin_amdgcn_make_buffer_rsrc((void*)part, 0, BM * BN * 4, 0x00020000);
+#pragma unroll
+    for (int q = 0; q < NCHUNK; ++q) {
+#pragma unroll
+      for (int ii = 0; ii < MREP_C; ++ii) {
+        const int lr = wm * (16 * MREP_C) + ii * 16 + c;
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) {
+          const int cc = wn * WTN + (OUT_BF16 ? (32 * (j >> 1) + 8 * kq + 4 * (j & 1)) : (16 * j + 4 * kq));
+          *reinterpret_cast<f32x4*>(epi_lds + lr * CSTRIDE + cc * 4) = acc[q * MREP_C + ii][j];
+        }
+      }
+      lds_barrier();
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const int lr = (r * NW + wave) * RPI + lane / LPR;
+        const int trow = (lr / (16 * MREP_C)) * WTM + 16 * MREP_C * q + lr % (16 * MREP_C);
+#pragma unroll
+        for (int e4 = 0; e4 < CPL / 4; ++e4) {
+          const u32x4 t = *reinterpret_cast<const u32x4*>(epi_lds + lr * CSTRIDE + col * 4 + 16 * e4);
+          // write-through (sc1): the partial tile leaves the XCD's L2 as it is stored, so publishing it needs no agent-scope release
+          // (a release fence writes back EVERY dirty line of the L2: 8 us and more with 256 KB freshly written per workgroup)
+          __builtin_amdgcn_raw_buffer_store_b128(t, part_rs, (uint32_t)((trow * BN + col + 4 * e4) * 4), 0, 16);
+        }
+      }
+      if (q + 1 < NCHUNK) lds_barrier();
+    }
+    // ---- (2) publish, wait for the other shares of this tile (Guideline 16, form R1: write-through stores, every storing wave
+    // drains them, barrier, ONE lane adds to the counter; ONE relaxed poll, one agent-scope acquire, barrier, then plain loads)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __hip_atomic_fetch_add(p.sk_cnt + etile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned spins = 0;
+      while (__hip_atomic_load(p.sk_cnt + etile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)S) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > (1u << 22)) {  // (seconds: a share of this tile is not running -- the grid was not resident) give up loudly
+          __hip_atomic_store(p.sk_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    // ---- (3) this workgroup's rows of the tile: sum over the shares (share 0 carries the bias), epilogue, store
+    float gam[CPL];
+#pragma unroll
+    for (int e = 0; e < CPL; ++e) gam[e] = (IS_RES && p.gamma && nvalid && (e < 4 || full)) ? p.gamma[n + e] : 1.f;
+    const int r0 = sk_share * BM / S, r1 = (sk_share + 1) * BM / S;
+    const float* const tile_ws = p.sk_ws + (size_t)etile * S * (size_t)(BM * BN);
+    const auto ws_rs = __builtin_amdgcn_make_buffer_rsrc((void*)tile_ws, 0, S * BM * BN * 4, 0x00020000);
+    // rows r0 + (it * NW + wave) * RPI + lane / LPR; RB row-instructions per batch so that ~16 partial-tile loads are in flight per
+    // lane (one dependent round trip per batch instead of one per row); SS = number of shares as a literal
+    auto combine = [&](auto SSC) {
+      constexpr int SS = decltype(SSC)::value;
+      constexpr int RB = (16 / (SS * (CPL / 4))) > 0 ? (16 / (SS * (CPL / 4))) : 1;
+      for (int row0 = r0 + wave * RPI + lane / LPR; row0 - (wave * RPI + lane / LPR) < r1; row0 += RB * NW * RPI) {
+        u32x4 pv[RB][SS][CPL / 4], rr[RB][CPL / 4];
+        uint32_t off[RB];
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+          const int row = row0 + b * NW * RPI;
+          const bool live = row < r1;
+          const int m = em0 + row;
+          off[b] = (live && nvalid) ? (uint32_t)m * (uint32_t)p.N + (uint32_t)n : OOB;
+#pragma unroll
+          for (int sh = 0; sh < SS; ++sh)
+#pragma unroll
+            for (int e4 = 0; e4 < CPL / 4; ++e4)
+              pv[b][sh][e4] = __builtin_amdgcn_raw_buffer_load_b128(ws_rs, live ? (uint32_t)(((sh * BM + row) * BN + col + 4 * e4) * 4) : OOB, 0, 0);
+          if (IS_RES && p.residual) {
+            const uint32_t rb = off[b] == OOB ? OOB : off[b] * 4;
+            rr[b][0] = __builtin_amdgcn_raw_buffer_load_b128(res_rs, rb, 0, 0);
+            if (CPL == 8) rr[b][CPL / 4 - 1] = __builtin_amdgcn_raw_buffer_load_b128(res_rs, full ? rb + 16 : OOB, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+          const int m = em0 + row0 + b * NW * RPI;
+          float v[CPL];
+#pragma unroll
+          for (int e = 0; e < CPL; ++e) v[e] = __uint_as_float(pv[b][0][e >> 2][e & 3]);
+#pragma unroll
+          for (int sh = 1; sh < SS; ++sh)  // fixed order: share 0 (it carries the bias), 1, 2, ...
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) v[e] += __uint_as_float(pv[b][sh][e >> 2][e & 3]);
+          if (IS_RES) {
+            if (p.gamma || p.rowscale) {
+              float rsc;
+              if (RS_ALWAYS_TILE || rs_tile) rsc = m < rs_split ? rs_lo : rs_hi;
+              else rsc = (p.rowscale && m < p.M) ? p.rowscale[(m + p.row_base) / p.rows_per_scale] : 1.f;
+#pragma unroll
+              for (int e = 0; e < CPL; ++e) v[e] *= gam[e] * rsc;
+            }
+            if (p.residual) {
+#pragma unroll
+              for (int e = 0; e < CPL; ++e) v[e] += __uint_as_float(rr[b][e >> 2][e & 3]);
+            }
+          }
+          const uint32_t ob = off[b] == OOB ? OOB : off[b] * ESZ;
+          if (OUT_BF16) {
+            const u32x2 lo = u32x2{pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
+            const u32x2 hi = u32x2{pack_op16x2(v[CPL - 4], v[CPL - 3]), pack_op16x2(v[CPL - 2], v[CPL - 1])};
+            if (n8) __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[0], lo[1], hi[0], hi[1]}, c_rs, ob, 0, ST_AUX);
+            else {
+              __builtin_amdgcn_raw_buffer_store_b64(lo, c_rs, ob, 0, ST_AUX);
+              __builtin_amdgcn_raw_buffer_store_b64(hi, c_rs, full ? ob + 8 : OOB, 0, ST_AUX);
+            }
+          } else {
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, c_rs, ob, 0, ST_AUX);
+          }
+        }
+      }
+    };
+    switch (S) {
+      case 2: combine(std::integral_constant<int, 2>{}); break;
+      case 3: combine(std::integral_constant<int, 3>{}); break;
+      case 4: combine(std::integral_constant<int, 4>{}); break;
+      case 5: combine(std::integral_constant<int, 5>{}); break;
+      case 6: combine(std::integral_constant<int, 6>{}); break;
+      case 7: combine(std::integral_constant<int, 7>{}); break;
+      default: combine(std::integral_constant<int, 8>{}); break;
+    }
+  }
+  if (!SPLITK && !DIRECT && !((DBG_BITS(p) & 4) && p.M > 1)) {
   float gam[CPL];
 #pragma unroll
   for (int e = 0; e < CPL; ++e) gam[e] = (IS_RES && p.gamma && nvalid && (e < 4 || full)) ? p.gamma[n + e] : 1.f;
@@ -936,13 +1089,14 @@ int gemm_debug = env_int("TAD_GEMM_DEBUG");  // ablation bits (GemmNT::debug); o
 int nt_persist = !env_int("TAD_GEMM_NO_PERSIST");
 int nt_direct = getenv("TAD_GEMM_DIRECT_EPI") ? env_int("TAD_GEMM_DIRECT_EPI") : 1;
 int nt_split = getenv("TAD_GEMM_SPLIT_TAIL") ? env_int("TAD_GEMM_SPLIT_TAIL") : 1;
+int nt_splitk = getenv("TAD_GEMM_SPLITK_TAIL") ? env_int("TAD_GEMM_SPLITK_TAIL") : 1;  // 1 = the tail launch of the split plan may split its tiles along K (needs a workspace); 0 = never; 2 = whenever eligible
 int nt_variant = env_int("TAD_GEMM_NT_VARIANT");  // 0 = planned per shape (launch_gemm_nt), else the tile configuration for every launch
 int nt_group_m_knob = getenv("TAD_GEMM_GROUP_M") ? env_int("TAD_GEMM_GROUP_M") : 0;  // 0 = per-shape choice (nt_group_m)
 int tn_variant = env_int("TAD_GEMM_TN_VARIANT");
 unsigned long long* nt_stamps = nullptr;
 long long nt_launches = 0;  // gemm_nt kernel launches so far (tad_linear_kernel_launches)
 #else
-extern int gemm_debug, nt_persist, nt_direct, nt_split, nt_variant, nt_group_m_knob, tn_variant;
+extern int gemm_debug, nt_persist, nt_direct, nt_split, nt_splitk, nt_variant, nt_group_m_knob, tn_variant;
 extern unsigned long long* nt_stamps;
 extern long long nt_launches;
 #endif
@@ -1005,6 +1159,46 @@ static void launch_nt_variant(int v, GemmNT& p, hipStream_t st) {
 #undef NT_LAUNCH
 }
 
+// Split-K launch of a (small) problem: tiles x splits workgroups, all resident (the caller checked tiles * splits <= CUs).  Workspace:
+// [arrival counters, one per tile | error word][partial tiles].  The counters are zeroed on the stream in front of the launch.
+constexpr size_t SK_HEADER_BYTES = 4096;  // counters (<= 1008 tiles) + the error word at byte 4032
+constexpr size_t SK_TILE_BYTES = 256 * 256 * sizeof(float);
+static int launch_gemm_nt_splitk(GemmNT p, int splits, void* ws, hipStream_t st) {
+  ++nt_launches;
+  const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+  p.sk_splits = splits;
+  p.sk_cnt = (unsigned*)ws;
+  p.sk_err = (unsigned*)((char*)ws + 4032);
+  p.sk_ws = (float*)((char*)ws + SK_HEADER_BYTES);
+  p.group_m = nt_group_m((p.M + 255) / 256, (p.N + 255) / 256, p.K);
+  if (hipMemsetAsync(ws, 0, SK_HEADER_BYTES, st) != hipSuccess) { set_error("gemm_nt: split-K counter reset failed"); return TAD_ELAUNCH; }
+  const dim3 grid(tiles * splits), block(512);
+  if (p.epi == EPI_PLAIN && p.c_bf16) hipLaunchKernelGGL((gemm_nt_kernel<256, 256, 2, 4, 2, EPI_PLAIN, true, false, false, true>), grid, block, 0, st, p);
+  else if (p.epi == EPI_PLAIN) hipLaunchKernelGGL((gemm_nt_kernel<256, 256, 2, 4, 2, EPI_PLAIN, false, false, false, true>), grid, block, 0, st, p);
+  else if (p.epi == EPI_RESIDUAL && !p.c_bf16) hipLaunchKernelGGL((gemm_nt_kernel<256, 256, 2, 4, 2, EPI_RESIDUAL, false, false, false, true>), grid, block, 0, st, p);
+  else { set_error("gemm_nt: no split-K kernel for epilogue %d", p.epi); return TAD_EINVAL; }
+  return check_launch("gemm_nt_splitk");
+}
+// splits for a tail of `tiles` 256 x 256 tiles with nk K-tiles each, or 0: every share needs at least two K-tiles, all shares must be
+// resident at once, and the combine pass costs ~14 us (partial tiles written and read back, arrival wait), so short reductions gain nothing
+static int nt_splitk_plan(const GemmNT& t, size_t ws_bytes, double* cost_us) {
+  const int tiles = ((t.M + 255) / 256) * ((t.N + 255) / 256), nk = t.K / BK, cus = cu_count();
+  if (!nt_splitk || tiles <= 0 || tiles > cus / 2 || tiles > 1008) return 0;
+  // measured (tools/exp_splitk.py, round 4): the 78-tile tails of ViT-B's N = 768 Linears (30 % of the CUs busy for one K loop) do NOT
+  // gain -- three shares of 16 K-tiles + the combine take as long as one 256 x 128 K loop of 48 -- while the 16-tile tails of ViT-L's
+  // N = 1024 Linears (6 % of the CUs) do: auto mode takes tails of at most a quarter of the CUs whose K loop is long enough
+  if (nt_splitk == 1 && (tiles > cus / 4 || nk < 64)) return 0;  // (K = 3072 at 16 tiles: 289 -> 297 us; K = 4096: 424 -> 392, 387 -> 376)
+  if (!((t.epi == EPI_PLAIN) || (t.epi == EPI_RESIDUAL && !t.c_bf16 && t.res_mod <= 0))) return 0;
+  if (t.rowscale && t.rows_per_scale < 256) return 0;
+  if (t.colscale_cols > 0) return 0;
+  int s = cus / tiles;
+  if (s > nk / 2) s = nk / 2;
+  if (s > 8) s = 8;
+  if (s < 2 || ws_bytes < SK_HEADER_BYTES + (size_t)tiles * s * SK_TILE_BYTES) return 0;
+  *cost_us = (double)((nk + s - 1) / s) * 1.65 + 14.0 + 3.0;
+  return s;
+}
+
 static int launch_gemm_nt_one(GemmNT p, int v, hipStream_t st) {
   ++nt_launches;
   if (p.epi == EPI_RESIDUAL && p.residual && p.res_mod > 0) p.epi = EPI_RESMOD;
@@ -1058,7 +1252,7 @@ static double nt_cost(int v, int epi, int c_bf16, int M, int N, int K) {
   return (double)((tiles + 2 * cus - 1) / (2 * cus)) * (nk * 1.3 + 5.0) + 3.0;
 }
 
-int launch_gemm_nt(const GemmNT& p_in, hipStream_t st) {
+int launch_gemm_nt(const GemmNT& p_in, hipStream_t st, void* ws = nullptr, size_t ws_bytes = 0) {
   GemmNT p = p_in;
   if (!(p.M > 0 && p.N > 0 && p.K > 0)) { set_error("gemm_nt: empty problem"); return TAD_EINVAL; }
   if (p.K % BK) { set_error("gemm_nt: K=%d must be a multiple of %d", p.K, BK); return TAD_EINVAL; }
@@ -1080,7 +1274,7 @@ int launch_gemm_nt(const GemmNT& p_in, hipStream_t st) {
     if (p.M > max_rows) {
       for (int64_t r0 = 0; r0 < p.M; r0 += max_rows) {
         const int rows = (int)((p.M - r0) < max_rows ? (p.M - r0) : max_rows);
-        const int rc = launch_gemm_nt(row_range(p, (int)r0, rows), st);
+        const int rc = launch_gemm_nt(row_range(p, (int)r0, rows), st, ws, ws_bytes);
         if (rc) return rc;
       }
       return TAD_OK;
@@ -1105,7 +1299,7 @@ int launch_gemm_nt(const GemmNT& p_in, hipStream_t st) {
   const double cost_a = nt_cost(3, p.epi, p.c_bf16, p.M, p.N, p.K);
   const double cost_b = v1_ok ? nt_cost(1, p.epi, p.c_bf16, p.M, p.N, p.K) : 1e300;
   double cost_c = 1e300;
-  int main_rows = 0;
+  int main_rows = 0, tail_splits = 0;
   if (v1_ok && nt_split) {
     const int tiles_n = (p.N + 255) / 256, tiles_m = (p.M + 255) / 256;
     const int grid = cu_count() & ~7;
@@ -1114,8 +1308,15 @@ int launch_gemm_nt(const GemmNT& p_in, hipStream_t st) {
     if (panels > 0 && panels < tiles_m) {
       main_rows = panels * 256;
       const int tail = p.M - main_rows;
-      const double tail_cost = tail < 2048 ? nt_cost(2, p.epi, p.c_bf16, tail, p.N, p.K)
-                                           : fmin(nt_cost(3, p.epi, p.c_bf16, tail, p.N, p.K), nt_cost(1, p.epi, p.c_bf16, tail, p.N, p.K));
+      double tail_cost = tail < 2048 ? nt_cost(2, p.epi, p.c_bf16, tail, p.N, p.K)
+                                     : fmin(nt_cost(3, p.epi, p.c_bf16, tail, p.N, p.K), nt_cost(1, p.epi, p.c_bf16, tail, p.N, p.K));
+      // (d) the tail's tiles split along K over all CUs (SPLITK kernels): 78 tiles of the N = 768 Linears of ViT-B run as 3 shares
+      // each on 234 CUs instead of one K loop on 156
+      if (ws) {
+        double sk_cost = 1e300;
+        const int s = nt_splitk_plan(row_range(p, main_rows, tail), ws_bytes, &sk_cost);
+        if (s && (sk_cost < tail_cost || nt_splitk == 2)) { tail_splits = s; tail_cost = sk_cost; }
+      }
       cost_c = nt_cost(1, p.epi, p.c_bf16, main_rows, p.N, p.K) + tail_cost;
     }
   }
@@ -1124,6 +1325,7 @@ int launch_gemm_nt(const GemmNT& p_in, hipStream_t st) {
     int rc = launch_gemm_nt_one(row_range(p, 0, main_rows), 1, st);
     if (rc) return rc;
     const GemmNT t = row_range(p, main_rows, p.M - main_rows);
+    if (tail_splits) return launch_gemm_nt_splitk(t, tail_splits, ws, st);
     if (t.M < 2048) return launch_gemm_nt_one(t, 2, st);
     return launch_gemm_nt_one(t, nt_cost(1, t.epi, t.c_bf16, t.M, t.N, t.K) < nt_cost(3, t.epi, t.c_bf16, t.M, t.N, t.K) ? 1 : 3, st);
   }
@@ -1207,8 +1409,8 @@ using namespace tad;
 extern "C" {
 
 int tad_linear_fwd(const uint16_t* x, const uint16_t* w, const float* bias, void* y, int y_dtype, int epilogue, uint16_t* preact,
-                   const float* residual, const float* gamma, const float* rowscale, int rows_per_scale, int64_t M, int N, int K,
-                   tad_stream_t stream) {
+                   const float* residual, const float* gamma, const float* rowscale, int rows_per_scale, void* ws, size_t ws_bytes,
+                   int64_t M, int N, int K, tad_stream_t stream) {
   TAD_REQUIRE(x && w && y, "linear_fwd: null pointer");
   TAD_REQUIRE(y_dtype == TAD_F32 || y_dtype == TAD_OP16, "linear_fwd: bad y_dtype %d", y_dtype);
   TAD_REQUIRE(epilogue >= TAD_EPI_BIAS && epilogue <= TAD_EPI_BIAS_RESIDUAL, "linear_fwd: bad epilogue %d", epilogue);
@@ -1221,8 +1423,16 @@ int tad_linear_fwd(const uint16_t* x, const uint16_t* w, const float* bias, void
   if (epilogue == TAD_EPI_BIAS_GELU) { p.epi = EPI_GELU; p.preact = preact; }
   else if (epilogue == TAD_EPI_BIAS_RESIDUAL) { p.epi = EPI_RESIDUAL; p.residual = residual; p.gamma = gamma; p.rowscale = rowscale; }
   else p.epi = EPI_PLAIN;
-  return launch_gemm_nt(p, (hipStream_t)stream);
+  return launch_gemm_nt(p, (hipStream_t)stream, ws, ws ? ws_bytes : 0);
 }
+
+#ifndef TAD_OPND_F16
+size_t tad_linear_workspace_bytes(int64_t M, int N, int K) {
+  (void)N; (void)K;
+  if (M < 4096) return 0;  // (small problems never take the split plan)
+  return SK_HEADER_BYTES + (size_t)cu_count() * SK_TILE_BYTES;  // tiles x splits <= CUs partial tiles of 256 x 256 f32
+}
+#endif
 
 int tad_linear_fwd_qkv(const uint16_t* x, const uint16_t* w, const float* q_bias, const float* v_bias, void* y, int y_dtype, float q_prescale,
                        int64_t M, int N, int K, tad_stream_t stream) {
@@ -1254,6 +1464,7 @@ int tad_linear_bwd_weight_qkv(const uint16_t* dy, const uint16_t* x, float* dW, 
 int tad_linear_tuning(const char* key, int value) {
   TAD_REQUIRE(key, "linear_tuning: null key");
   const std::string k(key);
+  if (k == "splitk_tail") { TAD_REQUIRE(value >= 0 && value <= 2, "linear_tuning: splitk_tail=%d not in {0, 1, 2}", value); nt_splitk = value; return TAD_OK; }
   if (k == "persistent") nt_persist = value != 0;
   else if (k == "direct_epilogue") { TAD_REQUIRE(value >= 0 && value <= 2, "linear_tuning: direct_epilogue=%d not in 0..2", value); nt_direct = value; }
   else if (k == "debug") gemm_debug = value;  // ablation bits (timing experiments; ignored by production builds)
@@ -1275,8 +1486,8 @@ int tad_linear_debug_stamps(void* buf) {
 }
 #endif
 
-int tad_linear_bwd_input(const uint16_t* dy, const uint16_t* wT, void* dx, int dx_dtype, const uint16_t* gelu_preact, int64_t M, int N,
-                         int K, tad_stream_t stream) {
+int tad_linear_bwd_input(const uint16_t* dy, const uint16_t* wT, void* dx, int dx_dtype, const uint16_t* gelu_preact, void* ws, size_t ws_bytes,
+                         int64_t M, int N, int K, tad_stream_t stream) {
   TAD_REQUIRE(dy && wT && dx, "linear_bwd_input: null pointer");
   TAD_REQUIRE(dx_dtype == TAD_F32 || dx_dtype == TAD_OP16, "linear_bwd_input: bad dx_dtype %d", dx_dtype);
   TAD_REQUIRE(M > 0 && M < (1ll << 31), "linear_bwd_input: bad M");
@@ -1286,7 +1497,7 @@ int tad_linear_bwd_input(const uint16_t* dy, const uint16_t* wT, void* dx, int d
   p.rows_per_scale = 1;
   p.epi = gelu_preact ? EPI_DGELU : EPI_PLAIN;
   p.dgelu_h = gelu_preact;
-  return launch_gemm_nt(p, (hipStream_t)stream);
+  return launch_gemm_nt(p, (hipStream_t)stream, ws, ws ? ws_bytes : 0);
 }
 
 #ifndef TAD_OPND_F16

@@ -419,10 +419,31 @@ def linear_fwd(x, w, bias=None, out_dtype=None, epilogue=EPI_BIAS, want_preact=F
         assert tuple(residual.shape) == (M, N)
     y = torch.empty((M, N), dtype=out_dtype, device=x.device)
     pre = torch.empty((M, N), dtype=op, device=x.device) if want_preact else None
+    ws, wsb = _linear_ws(M, N, K, x.device)
     with _timed("gemm_nt", 2.0 * M * N * K, 2.0 * (M * K + N * K) + y.element_size() * M * N):
         check(_fn("tad_linear_fwd", op)(x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), _dt(y), epilogue, _p(pre), _p(residual),
-                                         _p(gamma), _p(rowscale), int(rows_per_scale), M, N, K, _stream()), "tad_linear_fwd")
+                                         _p(gamma), _p(rowscale), int(rows_per_scale), ws, wsb, M, N, K, _stream()), "tad_linear_fwd")
     return y, pre
+
+
+# Split-K tails of the Linear GEMMs (include/tad_mi355x.h: tad_linear_fwd's `ws`): a per-(device, stream) scratch buffer is handed to the
+# Linear calls unless switched off -- parallel.DataParallel does that for world sizes > 1, where an overlapped RCCL kernel may hold CUs
+# and the split-K launch (all workgroups resident at once) must not be used.
+_linear_splitk = True
+
+
+def set_linear_splitk(on: bool):
+    global _linear_splitk
+    _linear_splitk = bool(on)
+
+
+def _linear_ws(M, N, K, device):
+    if not _linear_splitk:
+        return None, 0
+    nbytes = _lib.load().tad_linear_workspace_bytes(M, N, K)
+    if not nbytes:
+        return None, 0
+    return linear_workspace(nbytes, device).data_ptr(), nbytes
 
 
 def _pad_reduction(a, b, mult: int = 64):
@@ -431,7 +452,26 @@ def _pad_reduction(a, b, mult: int = 64):
     return torch.nn.functional.pad(a, (0, pad)).contiguous(), torch.nn.functional.pad(b, (0, pad)).contiguous()
 
 
-LINEAR_TUNING_DEFAULTS = dict(persistent=1, direct_epilogue=1, split_tail=1, group_m=0, variant=0)
+LINEAR_TUNING_DEFAULTS = dict(persistent=1, direct_epilogue=1, split_tail=1, splitk_tail=1, group_m=0, variant=0)
+
+
+_lin_ws = {}
+
+
+def linear_workspace(nbytes: int, device) -> torch.Tensor:
+    """scratch of the split-K Linear tails, one per (device, stream); apart from `workspace`, so that neither buffer's growth retires
+    the other"""
+    key = _ws_key(device)
+    buf = _lin_ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _lin_ws[key] = buf
+    return buf
+
+
+def linear_kernel_launches() -> int:
+    """gemm_nt kernel launches issued so far (tad_linear_kernel_launches)"""
+    return int(_lib.load().tad_linear_kernel_launches())
 
 
 def linear_tuning(**knobs):
@@ -454,9 +494,10 @@ def linear_bwd_input(dy, wT, out_dtype=None, gelu_preact=None):
         _req16(gelu_preact, "linear_bwd_input.gelu_preact", like=op)
         assert tuple(gelu_preact.shape) == (M, K)
     dx = torch.empty((M, K), dtype=out_dtype, device=dy.device)
+    ws, wsb = _linear_ws(M, K, N, dy.device)
     with _timed("gemm_nt", 2.0 * M * N * K, 2.0 * (M * N + N * K) + dx.element_size() * M * K):
-        check(_fn("tad_linear_bwd_input", op)(dy.data_ptr(), wT.data_ptr(), dx.data_ptr(), _dt(dx), _p(gelu_preact), M, N, K, _stream()),
-              "tad_linear_bwd_input")
+        check(_fn("tad_linear_bwd_input", op)(dy.data_ptr(), wT.data_ptr(), dx.data_ptr(), _dt(dx), _p(gelu_preact), ws, wsb, M, N, K,
+                                               _stream()), "tad_linear_bwd_input")
     return dx
 
 

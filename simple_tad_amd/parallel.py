@@ -136,6 +136,7 @@ class DataParallel(nn.Module):
             # instead.  (Costs the next-tile prefetch and the peeled last K-tile: 0.2 % of a single-GPU step on the round-2 build.)
             from . import kernels as _K
             _K.linear_tuning(persistent=0)
+            _K.set_linear_splitk(False)  # (the split-K tail launch needs all of its workgroups resident at once: same reason)
         # flat gradient buffer (layout shared with the fused optimizer: flat.FlatSpace)
         self.space = FlatSpace(params)
         self.flat_grad = self.space.ensure_grads()

@@ -54,9 +54,9 @@ def test_every_operand_entry_point_has_a_half_twin(lib_path):
     buf = ctypes.create_string_buffer(64)
     p = ctypes.cast(buf, ctypes.c_void_p)
     # the twin takes TAD_F16 (2) where its sibling takes TAD_BF16 (1) as the 16-bit output type, and refuses the other one
-    assert lib.tad_linear_fwd_f16(p, p, None, p, 1, 0, None, None, None, None, 1, 16, 16, 64, None) == -1
+    assert lib.tad_linear_fwd_f16(p, p, None, p, 1, 0, None, None, None, None, 1, None, 0, 16, 16, 64, None) == -1
     assert b"y_dtype" in lib.tad_last_error_string()
-    assert lib.tad_linear_fwd(p, p, None, p, 2, 0, None, None, None, None, 1, 16, 16, 64, None) == -1
+    assert lib.tad_linear_fwd(p, p, None, p, 2, 0, None, None, None, None, 1, None, 0, 16, 16, 64, None) == -1
     assert b"y_dtype" in lib.tad_last_error_string()
 
 
@@ -70,7 +70,7 @@ def test_host_validation_without_gpu(lib_path):
     p = ctypes.cast(buf, ctypes.c_void_p)
     assert lib.tad_attn_fwd(p, p, 1, None, None, 1, 8, 1, 32, 0.125, 0, None) == -1  # head_dim != 64
     assert b"head_dim" in lib.tad_last_error_string()
-    assert lib.tad_linear_fwd(p, p, None, p, 1, 0, None, None, None, None, 1, 16, 16, 60, None) == -1  # K % 64
+    assert lib.tad_linear_fwd(p, p, None, p, 1, 0, None, None, None, None, 1, None, 0, 16, 16, 60, None) == -1  # K % 64
     assert b"K=60" in lib.tad_last_error_string()
     assert lib.tad_layernorm_fwd(p, p, p, p, 1, None, None, 4, 6, 1e-6, None) == -1  # D % 4
     assert lib.tad_im2col_tubelets(p, p, 1, 3, 3, 16, 16, 2, 8, None) == -1  # T % tubelet

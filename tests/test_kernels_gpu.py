@@ -308,7 +308,7 @@ def test_errors_are_loud(K):
         K.linear_fwd(torch.zeros(4, 64, dtype=torch.bfloat16, device="cuda"), torch.zeros(8, 128, dtype=torch.bfloat16, device="cuda"))
     from simple_tad_amd import _lib
     a, b, y = (torch.zeros(n, dtype=torch.bfloat16, device="cuda") for n in (4 * 60, 8 * 60, 4 * 8))
-    rc = _lib.load().tad_linear_fwd(a.data_ptr(), b.data_ptr(), None, y.data_ptr(), 1, 0, None, None, None, None, 1, 4, 8, 60, None)
+    rc = _lib.load().tad_linear_fwd(a.data_ptr(), b.data_ptr(), None, y.data_ptr(), 1, 0, None, None, None, None, 1, None, 0, 4, 8, 60, None)
     assert rc != 0 and b"multiple of 64" in _lib.load().tad_last_error_string()  # the C ABI itself keeps the K-tile contract; the wrapper pads (next test)
     with pytest.raises(TadError):
         K.attn_fwd(torch.zeros(4, 3 * 64, dtype=torch.bfloat16, device="cuda"), 1, 5, 1, 0.125)  # wrong element count
@@ -408,10 +408,10 @@ def test_linear_persistent_schedule_is_bit_identical(K, M, N, Kd, mode):
 
     outs = {}
     try:
-        base = dict(persistent=0, direct_epilogue=0, split_tail=0)
+        base = dict(persistent=0, direct_epilogue=0, split_tail=0, splitk_tail=0)  # (the split-K tail changes the summation order: its own test)
         for name, cfg in [("tile", {}), ("tile_direct", dict(direct_epilogue=2)), ("persist", dict(persistent=1)),
                           ("persist_direct", dict(persistent=1, direct_epilogue=2)), ("split", dict(persistent=1, split_tail=2)),
-                          ("default", K.LINEAR_TUNING_DEFAULTS)]:
+                          ("default", {**K.LINEAR_TUNING_DEFAULTS, "splitk_tail": 0})]:
             K.linear_tuning(**{**base, **cfg})
             y, pre = run()
             torch.cuda.synchronize()
@@ -472,6 +472,61 @@ def test_qkv_linear_q_prescale_every_schedule(K, M, D, Kd):
     ref[:, 2 * D:] += vb.double()
     assert float((y0f[rows].double() - ref).abs().max() / ref.abs().max()) < TOL
     assert float((y0[rows].double() - ref).abs().max() / ref.abs().max()) < 2 * BF16_ULP
+
+
+@pytest.mark.parametrize("M,N,Kd,mode", [(50176, 768, 3072, "plain"), (50176 - 37, 768, 2304, "plain_f32"), (50176, 768, 3072, "res"),
+                                         (50176, 768, 768, "res"), (50176, 1024, 1024, "plain"), (25088 + 5, 768, 1024, "res")])
+def test_linear_splitk_tail_matches_the_single_launch_plans(K, M, N, Kd, mode):
+    """The under-filled last round of tiles as a split-K launch (tad_linear_fwd's `ws`; csrc/gemm.hip SPLITK): every tile of the tail
+    is computed by several workgroups over shares of the K-tiles, their f32 partial tiles are combined inside the launch (arrival
+    counter, agent-scope release / acquire).  Against the plan without it the result differs only in the summation order over K
+    (tolerance-identical: the f32 accumulators of the shares are added in f32); rows of the main launch are bit-identical; the wait
+    never gave up (error word 0); twice in a row gives identical bits (the combine order is fixed: share 0, 1, 2 ...)."""
+    g = torch.Generator().manual_seed(M + N + Kd)
+    x = dev(torch.randn(M, Kd, generator=g)).to(torch.bfloat16)
+    w = dev(torch.randn(N, Kd, generator=g) * 0.05).to(torch.bfloat16)
+    bias = dev(torch.randn(N, generator=g))
+    res = dev(torch.randn(M, N, generator=g)) if mode == "res" else None
+    gamma = dev(torch.rand(N, generator=g) + 0.5) if mode == "res" else None
+    rows_per_scale = 1568
+    rowscale = dev(torch.rand((M + rows_per_scale - 1) // rows_per_scale, generator=g) + 0.5) if mode == "res" else None
+
+    def run():
+        if mode == "res":
+            return K.linear_fwd(x, w, bias, out_dtype=torch.float32, epilogue=K.EPI_BIAS_RESIDUAL, residual=res, gamma=gamma, rowscale=rowscale,
+                                rows_per_scale=rows_per_scale)[0]
+        if mode == "plain_f32":
+            return K.linear_fwd(x, w, bias, out_dtype=torch.float32)[0]
+        return K.linear_fwd(x, w, bias)[0]
+
+    try:
+        K.linear_tuning(**{**K.LINEAR_TUNING_DEFAULTS, "splitk_tail": 0})
+        y0 = run().clone()
+        K.linear_tuning(**{**K.LINEAR_TUNING_DEFAULTS, "splitk_tail": 2, "split_tail": 2})
+        launches = K.linear_kernel_launches()
+        y1 = run().clone()
+        assert K.linear_kernel_launches() - launches == 2  # main rounds + the split-K tail
+        y2 = run().clone()
+    finally:
+        K.linear_tuning(**K.LINEAR_TUNING_DEFAULTS)
+    torch.cuda.synchronize()
+    ws = K.linear_workspace(0, x.device)
+    assert int(ws[4032:4036].view(torch.int32).item()) == 0, "a split-K wait gave up"
+    assert torch.equal(y1, y2)
+    # which rows the tail covers: everything behind the whole rounds of 256 x 256 tiles
+    tiles_n, tiles_m, cus = (N + 255) // 256, (M + 255) // 256, K.device_info()["cu_count"] & ~7
+    main_rows = (tiles_m * tiles_n // cus) * cus // tiles_n * 256
+    assert 0 < main_rows < M
+    assert torch.equal(y0[:main_rows], y1[:main_rows])
+    a, b = y0[main_rows:].double(), y1[main_rows:].double()
+    tol = 2e-5 if y0.dtype == torch.float32 else 2 * BF16_ULP  # (bf16 outputs: an f32 difference in the last bits can flip a rounding)
+    assert float((a - b).abs().max() / a.abs().max()) < tol
+    rows = torch.randint(main_rows, M, (48,), generator=g).tolist() + [main_rows, M - 1]
+    ref = x[rows].double() @ w.double().t() + bias.double()
+    if mode == "res":
+        sc = rowscale[torch.tensor(rows, device=x.device) // rows_per_scale].double()[:, None]
+        ref = ref * gamma.double() * sc + res[rows].double()
+    assert float((y1[rows].double() - ref).abs().max() / ref.abs().max()) < (TOL if y1.dtype == torch.float32 else 2 * BF16_ULP)
 
 
 def test_linear_taller_than_the_32bit_epilogue_offsets(K):
