@@ -67,7 +67,7 @@ def parse_args():
                     "batch of 2 oversubscribes: minutes per batch on the pool's 256-core host; off by default)")
     ap.add_argument("--no-live-profile", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip everything after the timed region except cpu_baseline")
-    ap.add_argument("--only-extras", default="", help="comma list out of roofline_all,engine_loop,fwd_only,half,precise,mae_pretrain,torch_route "
+    ap.add_argument("--only-extras", default="", help="comma list out of roofline_all,engine_loop,fwd_only,half,precise,mae_pretrain,torch_route,vit_small,vit_large "
                                                       "(default: all)")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel-class table to stderr")
     ap.add_argument("--dry-run", action="store_true", help="launch plumbing only: rendezvous, one all-reduce, rank 0 prints the world size "
@@ -439,7 +439,8 @@ def main():
                                "avg_launch_us": round(1e3 * g["ms"] / g["launches"], 2),
                                "gflop_per_launch": round(g["flops"] / g["launches"] / 1e9, 2)}
 
-    want = set(filter(None, args.only_extras.split(","))) or {"roofline_all", "engine_loop", "fwd_only", "half", "precise", "mae_pretrain", "torch_route"}
+    want = set(filter(None, args.only_extras.split(","))) or {"roofline_all", "engine_loop", "fwd_only", "half", "precise", "mae_pretrain", "torch_route",
+                                                                "vit_small", "vit_large"}
     extras = world == 1 and not args.no_extras and args.mode == "train" and args.graph != 1
     if args.precision != "fast":  # the other modes' objects compare against the bf16 headline: only the per-class table makes sense here
         want &= {"roofline_all"}
@@ -622,6 +623,16 @@ def main():
             K.set_profiler(None)
             out["mae_pretrain"] = {"error": repr(e)}
 
+    # ---- the other two models the reference ships fine-tune jobs for (jobs/finetune/VideoMAE-S_DoTA.sh, VideoMAE-L_D2K.sh; factories
+    # modeling_finetune.py:338-388): the same 32-clip fwd + bwd + AdamW step, with their own per-class tables
+    for key, name in (("vit_small", "vit_small_patch16_224"), ("vit_large", "vit_large_patch16_224")):
+        if extras and key in want and args.model == "vit_base_patch16_224" and args.frames == 16:
+            try:
+                out[key] = finetune_step(T, E, K, dev, class_table, name, batch=B, drop_path=args.drop_path)
+            except Exception as e:  # noqa: BLE001
+                K.set_profiler(None)
+                out[key] = {"error": repr(e)}
+
     # ---- torch_route: the reference's own operator route (stock torch modules under bf16 autocast, torch's fused attention,
     # torch.optim.AdamW; tools/bench_torch_eager.py) for the same workload on THIS GPU, beside `value`.  Calibration only.
     if extras and "torch_route" in want and args.model == "vit_base_patch16_224" and args.frames == 16:
@@ -645,6 +656,56 @@ def main():
     if distributed:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+
+
+def finetune_step(T, E, K, dev, class_table, model_name, batch=32, steps=8, warmup=3, drop_path=0.1):
+    """the headline's step (forward + CE loss + backward + fused AdamW with layer decay, synthetic clips and labels) for another factory of
+    modeling_finetune.py:338-398"""
+    import torch
+    from simple_tad_amd.parallel import DataParallel
+    torch.manual_seed(0)
+    model = T.create_model(model_name, pretrained=False, num_classes=2, all_frames=16, tubelet_size=2, final_reduction="fc_norm",
+                           drop_path_rate=drop_path, init_scale=0.001, use_flash_attn=True).to(dev).train()
+    dp = DataParallel(model, bucket_mb=64.0)
+    opt = E.create_optimizer(dp, lr=1e-3, weight_decay=0.05, layer_decay=0.75)
+    scaler = E.NativeScalerWithGradNormCount(dp)
+    crit = torch.nn.CrossEntropyLoss()
+    params = list(model.parameters())
+    x = torch.randn(batch, 3, 16, 224, 224, device=dev)
+    y = torch.randint(0, 2, (batch,), device=dev)
+    dp.zero_grad()
+
+    def step():
+        loss = crit(dp(x), y)
+        scaler(loss, opt, parameters=params)
+        dp.zero_grad()
+        return loss
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    nprof = 2
+    pall = K.LaunchProfiler(only=None, stride=1)
+    K.set_profiler(pall)
+    for _ in range(nprof):
+        step()
+    K.set_profiler(None)
+    ra = class_table(pall.summary(), nprof, batch)
+    D, L, ntok = model.embed_dim, model.get_num_layers(), model.patch_embed.num_patches
+    _, f_fb = flops_per_clip(ntok, D, L)
+    res = {"value": round(batch / dt, 2), "unit": "clips/sec", "ms_per_step": round(1e3 * dt, 3), "steps": steps, "warmup": warmup,
+           "workload": f"{model_name} 16x224x224, {batch} clips, fwd+bwd+AdamW fine-tune step with CE loss on synthetic labels, drop_path {drop_path}",
+           "embed_dim": D, "depth": L, "heads": model.num_heads, "algorithmic_gflop_per_clip": round(f_fb / 1e9, 2),
+           "frac_of_bf16_mfma_roofline": round(batch * f_fb / dt / (PEAK_BF16_TFLOPS * 1e12), 4), "loss": float(last.detach()),
+           "parameters": sum(p.numel() for p in params), "roofline_all": ra}
+    del model, dp, opt, scaler, x
+    torch.cuda.empty_cache()
+    return res
 
 
 def mae_step(T, E, K, dev, class_table, batch=32, steps=8, warmup=3, model_name="pretrain_videomae_large_patch16_224", decoder_depth=12,

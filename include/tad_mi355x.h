@@ -178,9 +178,14 @@ int tad_linear_bwd_weight(const uint16_t* dy, const uint16_t* x, float* dW, floa
  * bits), for tad_attn_bwd's delta.
  * q_prescaled != 0: the q third of qkv already carries the factor scale * log2(e) (tad_linear_fwd_qkv's q_prescale); `scale` is
  * still the softmax scale.  0: plain q, as flash_attn_varlen_qkvpacked_func takes it (the kernels then scale their Q fragments
- * themselves: a second 16-bit rounding of q). */
+ * themselves: on the f32 scores).
+ * dropout_p in [0, 1), seed: attention dropout (nn.Dropout on the softmax matrix, modeling_finetune.py:99-101; dropout_p of
+ * flash_attn_varlen_qkvpacked_func, flash_attention_class.py:56-61): element (b, h, query, key) is kept iff
+ * hash((b H + h) N + query, key, seed) >= dropout_p * 2^32 (csrc/common.h: drop_keep; oracle/vit_oracle.py:
+ * attention_dropout_keep regenerates the mask) and kept probabilities are scaled by 1 / (1 - dropout_p); lse is that of the full
+ * softmax.  tad_attn_bwd must be given the same dropout_p and seed.  0 = no dropout (evaluation). */
 int tad_attn_fwd(const uint16_t* qkv, void* out, int out_dtype, uint16_t* out_lo, float* lse, int B, int N, int H, int d,
-                 float scale, int q_prescaled, tad_stream_t stream);
+                 float scale, int q_prescaled, float dropout_p, uint32_t seed, tad_stream_t stream);
 /* dqkv [B,N,3,H,d] bf16 (fully overwritten).  delta: scratch of tad_attn_bwd_scratch_bytes(B, N, H) bytes = 2*B*H*N floats (the
  * first kernel leaves -rowsum(dout*out) in [0, BHN) and -lse/scale (-lse*log2(e) with q_prescaled) in [BHN, 2 BHN) for the second
  * one, which takes them as the initial values of its accumulators).  The q slot of dqkv is the gradient of the PLAIN q in either case. */
@@ -196,8 +201,8 @@ int tad_attn_debug_stamps(void* buf);
  * is what cancels against the dP the kernels recompute (without it the q / k gradients of near-uniform attention rows carry the
  * rounding of out amplified by |delta| / |dP - delta|). */
 int tad_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* out_lo, const uint16_t* dout, const float* lse,
-                 uint16_t* dqkv, float* delta, int B, int N, int H, int d, float scale, int q_prescaled,
-                 tad_stream_t stream);
+                 uint16_t* dqkv, float* delta, int B, int N, int H, int d, float scale, int q_prescaled, float dropout_p,
+                 uint32_t seed, tad_stream_t stream);
 
 /* ---- token mean-pool x.mean(1) (modeling_finetune.py:325-326) -------------------------
  * x [B,N,D] f32 -> y [B,D] f32.  ws: B*TAD_POOL_SPLIT*D floats. */
@@ -366,9 +371,10 @@ int tad_linear_bwd_weight_f16(const uint16_t* dy, const uint16_t* x, float* dW, 
 int tad_linear_bwd_weight_qkv_f16(const uint16_t* dy, const uint16_t* x, float* dW, float* dq_bias, float* dv_bias, int accumulate,
                                   void* ws, size_t ws_bytes, int64_t M, int N, int K, tad_stream_t stream);
 int tad_attn_fwd_f16(const uint16_t* qkv, void* out, int out_dtype, uint16_t* out_lo, float* lse, int B, int N, int H, int d,
-                     float scale, int q_prescaled, tad_stream_t stream);
+                     float scale, int q_prescaled, float dropout_p, uint32_t seed, tad_stream_t stream);
 int tad_attn_bwd_f16(const uint16_t* qkv, const uint16_t* out, const uint16_t* out_lo, const uint16_t* dout, const float* lse,
-                     uint16_t* dqkv, float* delta, int B, int N, int H, int d, float scale, int q_prescaled, tad_stream_t stream);
+                     uint16_t* dqkv, float* delta, int B, int N, int H, int d, float scale, int q_prescaled, float dropout_p,
+                     uint32_t seed, tad_stream_t stream);
 int tad_meanpool_bwd_f16(const float* dy, float* dx, uint16_t* dx_f16, int B, int N, int D, tad_stream_t stream);
 int tad_adamw_step_f16(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint16_t* param_f16,
                        const uint8_t* chunk_group, int64_t n, const float* group_lr, const float* group_wd, int n_groups,

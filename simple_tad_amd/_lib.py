@@ -39,11 +39,11 @@ SIGNATURES = {
     "tad_linear_bwd_input": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _sz, _i64, _i, _i, _vp]),
     "tad_linear_bwd_weight_workspace_bytes": (_sz, [_i64, _i, _i]),
     "tad_linear_bwd_weight": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _sz, _i64, _i, _i, _vp]),
-    "tad_attn_fwd": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    "tad_attn_fwd": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _i, _f, C.c_uint32, _vp]),
     "tad_attn_tuning": (_i, [C.c_char_p, _i]),
     "tad_attn_bwd_scratch_bytes": (_sz, [_i, _i, _i]),
     "tad_attn_debug_stamps": (_i, [_vp]),
-    "tad_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    "tad_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _f, C.c_uint32, _vp]),
     "tad_meanpool_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "tad_meanpool_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "tad_colsum_workspace_bytes": (_sz, [_i64, _i]),

@@ -84,12 +84,15 @@ __device__ __forceinline__ op16x8 pack8(const f32x16& a, int s2) {
 // 3 = dK/dV kernel without its transposed LDS reads.  The variants round 2 measured and dropped (pieces spread into the tile, a
 // three-deep tile ring, 64 keys per wave at one wave per SIMD) are archived under experiments/r02_variants.
 // QS: the q third of qkv carries the factor scale * log2(e) (see attn_fwd.hip); without it the factor is applied to the f32 scores.
-template <bool QS, int DMA_MODE>
+// DROP: attention dropout (see attn_fwd.hip): dP reaches the softmax backward as keep ? dP / (1 - p) : 0, delta = rowsum(dO o O) is that
+// of the dropped forward (so it still equals sum_k P_k dP_k), dV sees the dropped P.
+template <bool QS, bool DROP, int DMA_MODE>
 __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out,
                                                           const uint16_t* __restrict__ out_lo,
                                                           const uint16_t* __restrict__ dout, const float* __restrict__ lse,
                                                           float* __restrict__ delta, uint16_t* __restrict__ dqkv, int N, int H, int B,
-                                                          float scale) {
+                                                          float scale, const Drop drop) {
+  constexpr bool SUBD = TAD_DQ_BATCH || DROP;  // delta subtracted by vector instructions (else it is the initial dP accumulator)
   constexpr int TILE_BYTES = 64 * 128;
   constexpr int NST = 2;  // K/V (Q/dO) tile ring depth
   __shared__ __attribute__((aligned(1024))) char lds[NST * 2 * TILE_BYTES];  // [buf][K|V]
@@ -121,6 +124,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
     }
   }
   const float lse2 = lse[((int64_t)b * H + head) * N + qrow] * LOG2E;
+  const uint32_t drop_row = (uint32_t)((b * H + head) * N + qrow);  // (DROP) the lane's row of the keep mask
   // delta = rowsum(dO o O): this lane holds half of its query row (the 8-element groups 2ks + h5), lane ^ 32 the other half
   float dlt;
   {
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
 #else
       DQ_TR_ISSUE();  // issued now and waited for after the exponentials
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = -dlt; }
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = SUBD ? 0.f : -dlt; }
       const int key = kt * 32 + ql;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -272,7 +276,11 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
       }
       f32x16 ds;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(QS ? s[r] - lse2 : fmaf(s[r], c, -lse2)) * (TAD_DQ_BATCH ? dp[r] - dlt : dp[r]);  // (QS: scores in log2 units)
+      for (int r = 0; r < 16; ++r) {
+        float dpe = dp[r];
+        if (DROP) dpe = drop_keep(drop, drop_row, (uint32_t)(kv0 + kt * 32 + acc_row(r, h5))) ? dpe * drop.inv_keep : 0.f;
+        ds[r] = fast_exp2(QS ? s[r] - lse2 : fmaf(s[r], c, -lse2)) * (SUBD ? dpe - dlt : dpe);  // (QS: scores in log2 units)
+      }
       lds_wait<4>(tl[0][0], th[0][0], tl[0][1], th[0][1]);
       {
         const op16x8 dsf = pack8(ds, 0);
@@ -308,10 +316,10 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
-template <bool QS, int DMA_MODE>
+template <bool QS, bool DROP, int DMA_MODE>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
                                                            const float* __restrict__ rowc_g, uint16_t* __restrict__ dqkv, int N, int H, int B,
-                                                           float scale, unsigned long long* stamps) {
+                                                           float scale, unsigned long long* stamps, const Drop drop) {
   constexpr int TILE_BYTES = 64 * 128;
   constexpr int STAGE = 2 * TILE_BYTES + 512;  // Q tile, dO tile, 64 x (-lse/scale), 64 x (-delta)
   constexpr int NST = 2;
@@ -462,7 +470,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
       }
       f32x16 s, dp;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = si[r >> 2][r & 3]; dp[r] = di[r >> 2][r & 3]; }
+      for (int r = 0; r < 16; ++r) { s[r] = si[r >> 2][r & 3]; dp[r] = DROP ? 0.f : di[r >> 2][r & 3]; }
       if (t * 64 + 32 * qt + 32 > N) {  // ragged half tile (N % 32 != 0): rows >= N get exp2(c*(s - 3e30)) = 0 and delta = 0
         // (one lane value against 16 literals: written as `row0 + literal + 4 h5 >= N` the compiler computed the 16 row indices in
         // front of this branch, i.e. in every half tile)
@@ -470,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
         asm volatile("" : "+v"(lim));
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          if ((r & 3) + 8 * (r >> 2) >= lim) { s[r] = -3.0e30f; dp[r] = 0.f; }
+          if ((r & 3) + 8 * (r >> 2) >= lim) { s[r] = -3.0e30f; dp[r] = 0.f; if (DROP) di[r >> 2][r & 3] = 0.f; }
       }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -482,6 +490,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         pm[r] = QS ? fast_exp2(s[r]) : fast_exp2(s[r] * c);  // QS: q . k is in log2 units already
+        if (DROP) {  // (the row constant -delta enters behind the mask; rows past the sequence have P = 0)
+          const uint32_t row = (uint32_t)((b * H + head) * N + min(t * 64 + 32 * qt + acc_row(r, h5), N - 1));
+          const bool keep = drop_keep(drop, row, (uint32_t)krow);
+          ds[r] = pm[r] * ((keep ? dp[r] * drop.inv_keep : 0.f) + di[r >> 2][r & 3]);
+          pm[r] = keep ? pm[r] * drop.inv_keep : 0.f;  // what the dV product sees
+        } else
         ds[r] = pm[r] * dp[r];
       }
       if constexpr (DMA_MODE != 3) {
@@ -594,24 +608,28 @@ extern "C" size_t tad_attn_bwd_scratch_bytes(int B, int N, int H) {
 #endif
 
 extern "C" int tad_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* out_lo, const uint16_t* dout, const float* lse,
-                            uint16_t* dqkv, float* delta, int B, int N, int H, int d, float scale, int q_prescaled, tad_stream_t stream) {
+                            uint16_t* dqkv, float* delta, int B, int N, int H, int d, float scale, int q_prescaled, float dropout_p,
+                            uint32_t seed, tad_stream_t stream) {
   TAD_REQUIRE(qkv && out && dout && lse && dqkv && delta, "attn_bwd: null pointer");
   TAD_REQUIRE(d == BHD, "attn_bwd: head_dim must be 64 (got %d)", d);
   TAD_REQUIRE(B > 0 && N > 0 && H > 0 && H <= 65535 && B <= 65535, "attn_bwd: bad shape");
   TAD_REQUIRE(scale > 0.f, "attn_bwd: scale must be positive");
+  Drop drop;
+  TAD_REQUIRE(make_drop(dropout_p, seed, &drop), "attn_bwd: dropout_p=%g outside [0, 1)", (double)dropout_p);
   TAD_REQUIRE((int64_t)B * H * N * 8 < (1ll << 31), "attn_bwd: B*H*N too large for the row-constant descriptor");
   TAD_REQUIRE((int64_t)B * N * 3 * H * BHD * 2 < (1ll << 32), "attn_bwd: qkv exceeds the 4 GiB buffer descriptor (B=%d N=%d H=%d)", B, N, H);
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)(((N + 127) / 128) * H * B)), block(256);
   const int mode = attn_dma_mode;
-#define LAUNCH_BWD_(Q_, M_)                                                                                                  \
+#define LAUNCH_BWD__(Q_, D_, M_)                                                                                             \
   {                                                                                                                          \
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<Q_, M_>), grid, block, 0, st, qkv, out, out_lo, dout, lse, delta, dqkv, N, H, B, scale);  \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<Q_, D_, M_>), grid, block, 0, st, qkv, out, out_lo, dout, lse, delta, dqkv, N, H, B, scale, drop);  \
     int rc = check_launch("attn_bwd_dq");                                                                                    \
     if (rc) return rc;                                                                                                       \
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<Q_, M_>), grid, block, 0, st, qkv, dout, delta, dqkv, N, H, B, scale, attn_stamps);  \
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<Q_, D_, M_>), grid, block, 0, st, qkv, dout, delta, dqkv, N, H, B, scale, attn_stamps, drop);  \
     return check_launch("attn_bwd_dkv");                                                                                     \
   }
+#define LAUNCH_BWD_(Q_, M_) { if (dropout_p > 0.f) LAUNCH_BWD__(Q_, true, M_) else LAUNCH_BWD__(Q_, false, M_) }
 #define LAUNCH_BWD(M_) { if (q_prescaled) LAUNCH_BWD_(true, M_) else LAUNCH_BWD_(false, M_) }
 #ifdef TAD_GEMM_ABLATION
   if (mode == 2) LAUNCH_BWD(2)
@@ -621,4 +639,5 @@ extern "C" int tad_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint
   LAUNCH_BWD(0)
 #undef LAUNCH_BWD
 #undef LAUNCH_BWD_
+#undef LAUNCH_BWD__
 }

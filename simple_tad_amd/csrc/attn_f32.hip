@@ -30,9 +30,6 @@ struct AttnF32 {
   static_assert(HD % 8 == 0 && HD <= 96, "head dim");
 };
 
-// accumulator register r of lane half h holds row (r & 3) + 8 (r >> 2) + 4 h of a 32 x 32 tile
-__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-
 __device__ __forceinline__ float swap_max(float x) {
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
   return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
@@ -40,20 +37,6 @@ __device__ __forceinline__ float swap_max(float x) {
 __device__ __forceinline__ float swap_sum(float x) {
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-
-// Attention dropout (nn.Dropout on the softmax matrix, modeling_finetune.py:99-101; flash_attention_class.py:59-61 passes dropout_p in
-// training): element (b, h, query, key) is kept iff hash(row, key, seed) >= p * 2^32, row = (b H + h) N + query, and kept
-// probabilities are scaled by 1 / (1 - p).  A counter-based hash instead of a stored N x N mask: the three kernels regenerate the
-// same bits, and so does the oracle (oracle/vit_oracle.py: attention_dropout_keep) -- parity by injected mask, as for drop-path.
-struct Drop {
-  uint32_t thr, seed;
-  float inv_keep;
-};
-__device__ __forceinline__ bool drop_keep(const Drop& d, uint32_t row, uint32_t key) {
-  uint32_t x = row * 0x9E3779B1u + key * 0x85EBCA77u + d.seed;
-  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
-  return x >= d.thr;
 }
 
 // stage 32 rows x HD floats (row `first + r` of a [rows][row_stride] f32 tensor, clamped to `last`) into tile[32][STRIDE], times mul
@@ -314,14 +297,6 @@ TAD_NAMESPACE_END
 using namespace tad;
 
 extern "C" {
-
-static bool make_drop(float p, uint32_t seed, Drop* d) {
-  if (!(p >= 0.f && p < 1.f)) return false;
-  d->thr = (uint32_t)((double)p * 4294967296.0);
-  d->seed = seed;
-  d->inv_keep = 1.f / (1.f - p);
-  return true;
-}
 
 int tad_attn_fwd_f32(const float* qkv, float* out, float* lse, int B, int N, int H, int d, float scale, float dropout_p, uint32_t seed,
                      tad_stream_t stream) {

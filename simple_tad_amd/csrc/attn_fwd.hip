@@ -48,10 +48,14 @@ typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 // QS: the q third of qkv already carries the factor scale * log2(e) (tad_linear_fwd_qkv's q_prescale): the scores leave the matrix
 // pipe in log2 units.  Without it (plain q, flash-attn's contract) the factor is applied to the f32 scores: one v_fma per score where the
 // pre-scaled form has a v_sub, same numerics as rounds 1-3.
-template <bool OUT_BF16, bool QS, int DMA_MODE>
+// DROP: attention dropout (modeling_finetune.py:99-101; flash_attention_class.py:59-61) -- the softmax is normalised by the row sum of
+// ALL probabilities (taken as f32 vector adds here), the P V product sees keep ? P / (1 - p) : 0 with the counter-based mask of
+// common.h (drop_keep), which the two backward kernels and the oracle regenerate.
+template <bool OUT_BF16, bool QS, bool DROP, int DMA_MODE>
 __global__ __launch_bounds__(256, TAD_FWD_ROWSUM_VALU ? 4 : 1) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, void* __restrict__ out,
                                                        uint16_t* __restrict__ out_lo, float* __restrict__ lse, int N, int H, int B,
-                                                       float scale) {
+                                                       float scale, const Drop drop) {
+  constexpr bool VSUM = TAD_FWD_ROWSUM_VALU || DROP;  // row sums of P by vector adds instead of MFMAs
   constexpr int TILE_BYTES = KV_TILE * HD * 2;                                  // 8 KiB
   __shared__ __attribute__((aligned(1024))) char lds[2 * 2 * TILE_BYTES];       // [buf][K|V][64 keys][128 B]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -165,6 +169,7 @@ __global__ __launch_bounds__(256, TAD_FWD_ROWSUM_VALU ? 4 : 1) void attn_fwd_ker
   // faster -- it is not bound by vector issue -- while every variant with two definitions of the score or
   // output registers cost 24-56 VGPRs (a wave per SIMD).  One body, one v_sub per score.
   const int nt = (N + KV_TILE - 1) / KV_TILE;
+  const uint32_t drop_row = (uint32_t)((b * H + head) * N + min(q0 + ql, N - 1));  // (DROP) the lane's row of the keep mask
   float m_run = -1e30f, l_run = 0.f;  // running row maximum (units of the scores as the matrix pipe delivers them), row sum of P
   auto fwd_tile = [&](auto BUFC, const int T) {
     constexpr int BUF = decltype(BUFC)::value;
@@ -239,8 +244,9 @@ __global__ __launch_bounds__(256, TAD_FWD_ROWSUM_VALU ? 4 : 1) void attn_fwd_ker
           for (int j = 0; j < 8; ++j) {
             const float sh = QS ? s[kt][8 * s2 + j] - m_run : fmaf(s[kt][8 * s2 + j], c, -mc);
             const float pe = (TAD_FWD_ABL & 1) ? sh : fast_exp2(sh);
-            pf[kt][s2][j] = (op16_t)pe;
-            if (TAD_FWD_ROWSUM_VALU) psum[(j + 8 * s2) & 3] += pe;
+            if (VSUM) psum[(j + 8 * s2) & 3] += pe;
+            if (DROP) pf[kt][s2][j] = (op16_t)(drop_keep(drop, drop_row, (uint32_t)(kv0 + kt * 32 + acc_row(8 * s2 + j, h5))) ? pe * drop.inv_keep : 0.f);
+            else pf[kt][s2][j] = (op16_t)pe;
           }
       f32x4 rs = {0.f, 0.f, 0.f, 0.f};
       if constexpr (TAD_FWD_ABL & 4) {
@@ -279,7 +285,7 @@ __global__ __launch_bounds__(256, TAD_FWD_ROWSUM_VALU ? 4 : 1) void attn_fwd_ker
         for (int dt = 0; dt < 2; ++dt) o[dt] = TAD_MFMA_32x32x16(join_tr(vlo[par][dt], vhi[par][dt]), pf[g_ >> 1][g_ & 1], o[dt]);
       });
       }
-      if (TAD_FWD_ROWSUM_VALU) l_run += half_swap_sum((psum[0] + psum[1]) + (psum[2] + psum[3]));
+      if (VSUM) l_run += half_swap_sum((psum[0] + psum[1]) + (psum[2] + psum[3]));
       else l_run += rs[0];  // the lane's own query: see `sel`
     }
     if constexpr (!(TAD_FWD_ABL & 16)) {
@@ -339,23 +345,27 @@ using namespace tad;
 namespace tad { namespace knobs { extern int attn_dma_mode; } }  // attn_bwd.hip (tad_attn_tuning)
 
 extern "C" int tad_attn_fwd(const uint16_t* qkv, void* out, int out_dtype, uint16_t* out_lo, float* lse, int B, int N, int H, int d,
-                            float scale, int q_prescaled, tad_stream_t stream) {
+                            float scale, int q_prescaled, float dropout_p, uint32_t seed, tad_stream_t stream) {
   TAD_REQUIRE(qkv && out, "attn_fwd: null pointer");
   TAD_REQUIRE(!out_lo || out_dtype == TAD_OP16, "attn_fwd: out_lo (the rounding residual) goes with a 16-bit output");
   TAD_REQUIRE(d == HD, "attn_fwd: head_dim must be 64 (got %d)", d);
   TAD_REQUIRE(B > 0 && N > 0 && H > 0 && H <= 65535 && B <= 65535, "attn_fwd: bad shape B=%d N=%d H=%d", B, N, H);
   TAD_REQUIRE(out_dtype == TAD_F32 || out_dtype == TAD_OP16, "attn_fwd: bad out_dtype %d", out_dtype);
   TAD_REQUIRE(scale > 0.f, "attn_fwd: scale must be positive");
+  Drop drop;
+  TAD_REQUIRE(make_drop(dropout_p, seed, &drop), "attn_fwd: dropout_p=%g outside [0, 1)", (double)dropout_p);
+  TAD_REQUIRE(dropout_p == 0.f || (int64_t)B * H * N < (1ll << 32), "attn_fwd: B*H*N too large for the dropout mask's row index");
   // the kernel addresses qkv through ONE buffer descriptor with 32-bit byte offsets (K/V staging by LDS-DMA)
   TAD_REQUIRE((int64_t)B * N * 3 * H * HD * 2 < (1ll << 32), "attn_fwd: qkv of %lld bytes exceeds the 4 GiB buffer descriptor (B=%d N=%d H=%d)",
               (long long)B * N * 3 * H * HD * 2, B, N, H);
   TAD_REQUIRE((int64_t)((N + Q_BLOCK - 1) / Q_BLOCK) * H * B < (1ll << 31), "attn_fwd: grid too large");
   const dim3 grid((unsigned)(((N + Q_BLOCK - 1) / Q_BLOCK) * H * B)), block(256);
-#define LAUNCH_FWD_(O_, Q_, M_) hipLaunchKernelGGL((attn_fwd_kernel<O_, Q_, M_>), grid, block, 0, (hipStream_t)stream, qkv, out, out_lo, lse, N, H, B, scale)
+#define LAUNCH_FWD__(O_, Q_, D_, M_) hipLaunchKernelGGL((attn_fwd_kernel<O_, Q_, D_, M_>), grid, block, 0, (hipStream_t)stream, qkv, out, out_lo, lse, N, H, B, scale, drop)
+#define LAUNCH_FWD_(O_, Q_, M_) { if (dropout_p > 0.f) LAUNCH_FWD__(O_, Q_, true, M_); else LAUNCH_FWD__(O_, Q_, false, M_); }
 #define LAUNCH_FWD(M_)                                                                                \
   {                                                                                                   \
-    if (out_dtype == TAD_OP16) { if (q_prescaled) LAUNCH_FWD_(true, true, M_); else LAUNCH_FWD_(true, false, M_); }    \
-    else { if (q_prescaled) LAUNCH_FWD_(false, true, M_); else LAUNCH_FWD_(false, false, M_); }       \
+    if (out_dtype == TAD_OP16) { if (q_prescaled) LAUNCH_FWD_(true, true, M_) else LAUNCH_FWD_(true, false, M_) }    \
+    else { if (q_prescaled) LAUNCH_FWD_(false, true, M_) else LAUNCH_FWD_(false, false, M_) }         \
     return check_launch("attn_fwd");                                                                  \
   }
 #ifdef TAD_GEMM_ABLATION
@@ -364,4 +374,5 @@ extern "C" int tad_attn_fwd(const uint16_t* qkv, void* out, int out_dtype, uint1
   LAUNCH_FWD(0)
 #undef LAUNCH_FWD
 #undef LAUNCH_FWD_
+#undef LAUNCH_FWD__
 }

@@ -209,6 +209,30 @@ __device__ __forceinline__ void store_rows_via_lds(char* patch, const uint2 (&pk
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
+// Attention dropout (nn.Dropout on the softmax matrix, modeling_finetune.py:99-101; flash_attention_class.py:59-61 passes dropout_p in
+// training): element (b, h, query, key) is kept iff hash(row, key, seed) >= p * 2^32, row = (b H + h) N + query, and kept
+// probabilities are scaled by 1 / (1 - p).  A counter-based hash instead of a stored N x N mask: every attention kernel (16-bit and
+// f32 operands, forward and the two backward kernels) regenerates the same bits, and so does the oracle (oracle/vit_oracle.py:
+// attention_dropout_keep) -- parity by injected mask, as for drop-path.
+struct Drop {
+  uint32_t thr, seed;
+  float inv_keep;
+};
+__device__ __forceinline__ bool drop_keep(const Drop& d, uint32_t row, uint32_t key) {
+  uint32_t x = row * 0x9E3779B1u + key * 0x85EBCA77u + d.seed;
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return x >= d.thr;
+}
+inline bool make_drop(float p, uint32_t seed, Drop* d) {
+  if (!(p >= 0.f && p < 1.f)) return false;
+  d->thr = (uint32_t)((double)p * 4294967296.0);
+  d->seed = seed;
+  d->inv_keep = 1.f / (1.f - p);
+  return true;
+}
+// accumulator register r of lane half h holds row (r & 3) + 8 (r >> 2) + 4 h of a 32 x 32 tile
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
 // compile-time loop: f(std::integral_constant<int, I>) for I in [BEGIN, END)
 template <int BEGIN, int END, typename F>
 __device__ __forceinline__ void static_for(F&& f) {

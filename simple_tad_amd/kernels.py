@@ -579,7 +579,8 @@ def colsum_bf16(a, out=None):
 
 
 # ----------------------------------------------------------------------------- attention
-def attn_fwd(qkv, B: int, N: int, H: int, scale: float, out_dtype=None, want_lse=True, want_lo=False, q_prescaled=False):
+def attn_fwd(qkv, B: int, N: int, H: int, scale: float, out_dtype=None, want_lse=True, want_lo=False, q_prescaled=False, drop_p: float = 0.0,
+             seed: int = 0):
     """qkv [B*N, 3*H*64] bf16 or f16 (packed [B,N,3,H,64]) -> out [B*N, H*64], lse [B,H,N] f32.  want_lo: returns (out, lse, out_lo)
     with out_lo = what the 16-bit rounding of out dropped (for attn_bwd's delta).  q_prescaled: the q third already carries
     scale * log2(e) (linear_fwd_qkv's q_prescale = q_prescale_of(scale))"""
@@ -592,7 +593,7 @@ def attn_fwd(qkv, B: int, N: int, H: int, scale: float, out_dtype=None, want_lse
     lo = torch.empty_like(out) if (want_lo and out.dtype in OP16_DTYPES) else None
     with _timed("attn_fwd", 4.0 * B * H * N * N * 64, 2.0 * (4 + (lo is not None)) * B * N * H * 64):
         check(_fn("tad_attn_fwd", op)(qkv.data_ptr(), out.data_ptr(), _dt(out), _p(lo), _p(lse), B, N, H, 64, float(scale), int(bool(q_prescaled)),
-                                      _stream()), "tad_attn_fwd")
+                                      float(drop_p), int(seed) & 0xffffffff, _stream()), "tad_attn_fwd")
     return (out, lse, lo) if want_lo else (out, lse)
 
 
@@ -602,7 +603,7 @@ def attn_tuning(**knobs):
         check(_lib.load().tad_attn_tuning(k.encode(), int(v)), f"tad_attn_tuning({k}={v})")
 
 
-def attn_bwd(qkv, out, dout, lse, B: int, N: int, H: int, scale: float, out_lo=None, q_prescaled=False):
+def attn_bwd(qkv, out, dout, lse, B: int, N: int, H: int, scale: float, out_lo=None, q_prescaled=False, drop_p: float = 0.0, seed: int = 0):
     """dqkv; its q slot is the gradient of the PLAIN q whether or not the q of `qkv` is pre-scaled"""
     op = _req16(qkv, "attn_bwd.qkv")
     for t, n in ((out, "out"), (dout, "dout")) + (((out_lo, "out_lo"),) if out_lo is not None else ()):
@@ -612,7 +613,8 @@ def attn_bwd(qkv, out, dout, lse, B: int, N: int, H: int, scale: float, out_lo=N
     delta = torch.empty((_lib.load().tad_attn_bwd_scratch_bytes(B, N, H) // 4,), dtype=torch.float32, device=qkv.device)  # -rowsum(dout*out), -lse/scale
     with _timed("attn_bwd", 8.0 * B * H * N * N * 64, 2.0 * (8 + (out_lo is not None)) * B * N * H * 64):
         check(_fn("tad_attn_bwd", op)(qkv.data_ptr(), out.data_ptr(), _p(out_lo), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), delta.data_ptr(),
-                                       B, N, H, 64, float(scale), int(bool(q_prescaled)), _stream()), "tad_attn_bwd")
+                                       B, N, H, 64, float(scale), int(bool(q_prescaled)), float(drop_p), int(seed) & 0xffffffff, _stream()),
+              "tad_attn_bwd")
     return dqkv
 
 

@@ -64,11 +64,11 @@ def test_host_validation_without_gpu(lib_path):
     """argument checks run before any launch, so they are testable on CPU"""
     from simple_tad_amd import _lib
     lib = _lib.load()
-    assert lib.tad_attn_fwd(None, None, 1, None, None, 1, 1, 1, 64, 0.125, 0, None) == -1
+    assert lib.tad_attn_fwd(None, None, 1, None, None, 1, 1, 1, 64, 0.125, 0, 0.0, 0, None) == -1
     assert b"null" in lib.tad_last_error_string()
     buf = ctypes.create_string_buffer(64)
     p = ctypes.cast(buf, ctypes.c_void_p)
-    assert lib.tad_attn_fwd(p, p, 1, None, None, 1, 8, 1, 32, 0.125, 0, None) == -1  # head_dim != 64
+    assert lib.tad_attn_fwd(p, p, 1, None, None, 1, 8, 1, 32, 0.125, 0, 0.0, 0, None) == -1  # head_dim != 64
     assert b"head_dim" in lib.tad_last_error_string()
     assert lib.tad_linear_fwd(p, p, None, p, 1, 0, None, None, None, None, 1, None, 0, 16, 16, 60, None) == -1  # K % 64
     assert b"K=60" in lib.tad_last_error_string()

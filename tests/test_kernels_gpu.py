@@ -574,6 +574,45 @@ def test_attention_dropout_f32_vs_oracle_with_the_injected_mask(K, d, H):
     assert abs(keep.mean().item() - (1 - p)) < 2e-3 and abs(keep.mean(-1).std().item() - (p * (1 - p) / 512) ** 0.5) < 3e-3
 
 
+@pytest.mark.parametrize("fmt", ["bf16", "f16"])
+@pytest.mark.parametrize("prescaled", [True, False], ids=["q_prescaled", "plain_q"])
+def test_attention_dropout_16bit_kernels_vs_oracle_with_the_injected_mask(K, fmt, prescaled):
+    """attn_drop inside the 16-bit MFMA attention kernels (round 4; before, attn_drop > 0 fell to the exact-f32 kernels at 1/16 of the
+    matrix rate): same counter-based keep mask as the f32 family, regenerated by the oracle and injected into the reference formula
+    softmax(q k^T) -> dropout -> @ v (modeling_finetune.py:96-103), forward and backward, ragged N spanning several tiles, both
+    operand formats, both q contracts; lse is that of the FULL softmax; p = 0 and another seed behave."""
+    B, N, H, p, seed = 2, 200, 2, 0.25, 7654321
+    scale = 64 ** -0.5
+    dt = torch.bfloat16 if fmt == "bf16" else torch.float16
+    rnd = lambda t: t.to(dt).float()  # noqa: E731
+    qkv = rnd(R.tensor_for("attdrop16.qkv", (B * N, 3 * H * 64), scale=1.0))
+    dout = rnd(R.tensor_for("attdrop16.do", (B * N, H * 64)))
+    opnd = qkv
+    if prescaled:
+        opnd, qkv = prescaled_pair(qkv, B, N, H, scale, rnd)
+    qd = qkv.double().reshape(B, N, -1).requires_grad_()
+    ref = O.attention_core(qd, H, scale, drop_p=p, seed=seed)
+    ref.backward(dout.double().reshape(B, N, -1))
+    kw = dict(q_prescaled=prescaled, drop_p=p, seed=seed)
+    x = dev(opnd).to(dt)
+    out32, lse = K.attn_fwd(x, B, N, H, scale, out_dtype=torch.float32, **kw)
+    tol, tol_max = (ATT_TOL, ATT_TOL_MAX) if fmt == "bf16" else (6e-4, 1.2e-3)
+    check(out32.reshape(B, N, -1), ref, tol=tol, tol_max=tol_max, what="attn dropout fwd")
+    q4 = qkv.double().reshape(B, N, 3, H, 64)
+    sc = torch.einsum("bnhd,bmhd->bhnm", q4[:, :, 0], q4[:, :, 1]) * scale
+    assert (lse.cpu().double() - torch.logsumexp(sc, -1)).abs().max().item() < 1e-3  # (the full softmax's, whatever was dropped)
+    out16, lse, lo = K.attn_fwd(x, B, N, H, scale, want_lo=True, **kw)
+    dqkv = K.attn_bwd(x, out16, dev(dout).to(dt), lse, B, N, H, scale, out_lo=lo, **kw)
+    g, r = dqkv.float().cpu().reshape(B, N, 3, H, 64), qd.grad.reshape(B, N, 3, H, 64)
+    for i, nm in enumerate("qkv"):
+        check(g[:, :, i], r[:, :, i], tol=2 * (BF16_ULP if fmt == "bf16" else 2 * tol), what=f"attn dropout d{nm}")
+    # the mask is applied: the result differs from the undropped one, another seed is another mask, p = 0 is the plain kernel
+    out0, _ = K.attn_fwd(x, B, N, H, scale, out_dtype=torch.float32, q_prescaled=prescaled)
+    out2, _ = K.attn_fwd(x, B, N, H, scale, out_dtype=torch.float32, q_prescaled=prescaled, drop_p=p, seed=seed + 1)
+    assert not torch.equal(out32, out0) and not torch.equal(out32, out2)
+    check(out0.reshape(B, N, -1), O.attention_core(qkv.double().reshape(B, N, -1), H, scale), tol=tol, tol_max=tol_max, what="attn p=0")
+
+
 def test_attention_dropout_in_the_model_is_reproducible_and_off_in_eval():
     import simple_tad_amd as T
     torch.manual_seed(0)

@@ -48,11 +48,11 @@ def bind(spec):
         bwd = lambda: lib.tad_attn_bwd(qkv.data_ptr(), out.data_ptr(), lo.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),  # noqa: E731
                                        delta.data_ptr(), B, N, H, 64, 0.125, st)
     else:
-        lib.tad_attn_fwd.argtypes = [vp, vp, i, vp, vp, i, i, i, i, f, i, vp]
-        lib.tad_attn_bwd.argtypes = [vp] * 7 + [i, i, i, i, f, i, vp]
-        fwd = lambda: lib.tad_attn_fwd(qkv_p.data_ptr(), out.data_ptr(), 1, lo.data_ptr(), lse.data_ptr(), B, N, H, 64, 0.125, 1, st)  # noqa: E731
+        lib.tad_attn_fwd.argtypes = [vp, vp, i, vp, vp, i, i, i, i, f, i, f, C.c_uint32, vp]
+        lib.tad_attn_bwd.argtypes = [vp] * 7 + [i, i, i, i, f, i, f, C.c_uint32, vp]
+        fwd = lambda: lib.tad_attn_fwd(qkv_p.data_ptr(), out.data_ptr(), 1, lo.data_ptr(), lse.data_ptr(), B, N, H, 64, 0.125, 1, 0.0, 0, st)  # noqa: E731
         bwd = lambda: lib.tad_attn_bwd(qkv_p.data_ptr(), out.data_ptr(), lo.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),  # noqa: E731
-                                       delta.data_ptr(), B, N, H, 64, 0.125, 1, st)
+                                       delta.data_ptr(), B, N, H, 64, 0.125, 1, 0.0, 0, st)
     return name, fwd, bwd
 
 
