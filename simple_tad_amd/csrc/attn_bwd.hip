@@ -23,10 +23,7 @@
 
 TAD_NAMESPACE_BEGIN
 
-constexpr int BHD = 64;
-#ifndef TAD_DQ_BATCH
-#define TAD_DQ_BATCH 0  // dQ kernel: 1 = row fragments of a half tile requested in one batch (asm reads) -- measured SLOWER (backward pair 846 -> 866 us, round 4); 0 = plain loads
-#endif
+
 constexpr float LOG2E = 1.44269504088896340736f;
 
 // 16-byte chunk swizzle for 128-byte rows, conflict-free for row reads (32 consecutive rows, chunk 2ks+h) and for
@@ -86,16 +83,25 @@ __device__ __forceinline__ op16x8 pack8(const f32x16& a, int s2) {
 // QS: the q third of qkv carries the factor scale * log2(e) (see attn_fwd.hip); without it the factor is applied to the f32 scores.
 // DROP: attention dropout (see attn_fwd.hip): dP reaches the softmax backward as keep ? dP / (1 - p) : 0, delta = rowsum(dO o O) is that
 // of the dropped forward (so it still equals sum_k P_k dP_k), dV sees the dropped P.
-template <bool QS, bool DROP, int DMA_MODE>
-__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out,
+// HD: head dim 64, or 80 as 64 + 16 (see attn_fwd.hip): dims 64..79 of the K / V tiles travel in side images of 32-byte rows, the score
+// and dP products get a fifth k-step, dQ a third (half-used) d tile.
+// (Round 4 measured the row fragments of a half tile requested as one batch of asm reads, as in the forward: the backward pair 846 ->
+// 866 us, with delta moved to the vector pipe to free the registers; not kept -- experiments/README.md.)
+template <int HD, bool QS, bool DROP, int DMA_MODE>
+__global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out,
                                                           const uint16_t* __restrict__ out_lo,
                                                           const uint16_t* __restrict__ dout, const float* __restrict__ lse,
                                                           float* __restrict__ delta, uint16_t* __restrict__ dqkv, int N, int H, int B,
                                                           float scale, const Drop drop) {
-  constexpr bool SUBD = TAD_DQ_BATCH || DROP;  // delta subtracted by vector instructions (else it is the initial dP accumulator)
+  static_assert(HD == 64 || HD == 80, "head dim");
+  constexpr bool X = HD == 80;
+  constexpr int NKS = HD / 16, NDT = X ? 3 : 2;
+  constexpr bool SUBD = DROP;  // delta subtracted by vector instructions (else it is the initial dP accumulator)
   constexpr int TILE_BYTES = 64 * 128;
-  constexpr int NST = 2;  // K/V (Q/dO) tile ring depth
-  __shared__ __attribute__((aligned(1024))) char lds[NST * 2 * TILE_BYTES];  // [buf][K|V]
+  constexpr int SIDE_BYTES = X ? 64 * 32 : 0;
+  constexpr int BUF_BYTES = 2 * TILE_BYTES + 2 * SIDE_BYTES;  // [K main | V main | K side | V side]
+  constexpr int NST = 2;  // K/V tile ring depth
+  __shared__ __attribute__((aligned(1024))) char lds[NST * BUF_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nblk = (N + 127) / 128;  // 1-D XCD-aware grid: the blocks of one (batch, head) pair share an L2 (see attn_fwd.hip)
@@ -103,22 +109,20 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
   const int head = (lin / nblk) % H, b = lin / nblk / H;
   const int q0 = (lin % nblk) * 128 + wave * 32;
   const int ql = lane & 31, h5 = lane >> 5;
-  const int64_t tok = (int64_t)3 * H * BHD;
-  const uint16_t* base = qkv + (int64_t)b * N * tok + head * BHD;
-  const uint16_t* kbase = base + (int64_t)H * BHD;
-  const uint16_t* vbase = base + (int64_t)2 * H * BHD;
+  const int64_t tok = (int64_t)3 * H * HD;
+  const uint16_t* base = qkv + (int64_t)b * N * tok + head * HD;
   const float c = scale * LOG2E;
 
   int qrow = q0 + ql;
   const bool qvalid = qrow < N;
   const bool wave_live = q0 < N;  // wave-uniform
   if (!qvalid) qrow = N - 1;
-  op16x8 qf[4], dof[4];
+  op16x8 qf[NKS], dof[NKS];
   {
     const uint16_t* qp = base + (int64_t)qrow * tok + 8 * h5;
-    const uint16_t* dp = dout + (((int64_t)b * N + qrow) * H + head) * BHD + 8 * h5;
+    const uint16_t* dp = dout + (((int64_t)b * N + qrow) * H + head) * HD + 8 * h5;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < NKS; ++ks) {
       qf[ks] = *reinterpret_cast<const op16x8*>(qp + 16 * ks);
       dof[ks] = *reinterpret_cast<const op16x8*>(dp + 16 * ks);
     }
@@ -133,10 +137,10 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
     // dO . (O - round(O)), an error in dS proportional to P that does not cancel -- for rows whose dP_k are nearly equal across the
     // keys (dS small against delta: near-uniform attention, a common component in V) it dominated dQ / dK and the q / k gradients
     // behind them (measured on ViT-B at the real shape: the worst q-row slice of a qkv weight gradient off by 12 % in bf16, 2 % in f16).
-    const int64_t orow = (((int64_t)b * N + qrow) * H + head) * BHD + 8 * h5;
+    const int64_t orow = (((int64_t)b * N + qrow) * H + head) * HD + 8 * h5;
     float part = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < NKS; ++ks) {
       const op16x8 of = *reinterpret_cast<const op16x8*>(out + orow + 16 * ks);
       if (out_lo) {
         const op16x8 ol = *reinterpret_cast<const op16x8*>(out_lo + orow + 16 * ks);
@@ -166,28 +170,34 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int key = (wave + 4 * i) * 8 + (lane >> 3);
-    dma_k[i] = (uint32_t)(((int64_t)b * N + key) * tok * 2) + (uint32_t)((head + H) * BHD * 2) + (uint32_t)(((lane & 7) ^ sw_dual(key)) << 4);
+    dma_k[i] = (uint32_t)(((int64_t)b * N + key) * tok * 2) + (uint32_t)((head + H) * HD * 2) + (uint32_t)(((lane & 7) ^ sw_dual(key)) << 4);
   }
-  const uint32_t v_off = (uint32_t)(H * BHD * 2), key_step = (uint32_t)(tok * 2);
+  const uint32_t v_off = (uint32_t)(H * HD * 2), key_step = (uint32_t)(tok * 2);
+  // side images (HD 80): one piece per wave and tile = 32 keys x 32 B; waves 0 / 1 move the two halves of K's, waves 2 / 3 of V's
+  const uint32_t dma_s = (uint32_t)(((int64_t)b * N + 32 * (wave & 1) + (lane >> 1)) * tok * 2) + (uint32_t)((head + (1 + (wave >> 1)) * H) * HD * 2) +
+                         128u + (uint32_t)((lane & 1) << 4);
 #define DMA_K_(buf, kv0)                                                                                                        \
   {                                                                                                                             \
-    char* kl_ = lds + (buf) * 2 * TILE_BYTES;                                                                                   \
+    char* kl_ = lds + (buf) * BUF_BYTES;                                                                                        \
     const uint32_t adv_ = (uint32_t)(kv0) * key_step;                                                                           \
     _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                               \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_qkv, LDS_PTR(kl_ + (wave + 4 * i) * 1024), 16, dma_k[i] + adv_, 0, 0, 0);     \
   }
 #define DMA_V_(buf, kv0)                                                                                                        \
   {                                                                                                                             \
-    char* kl_ = lds + (buf) * 2 * TILE_BYTES;                                                                                   \
+    char* kl_ = lds + (buf) * BUF_BYTES;                                                                                        \
     const uint32_t adv_ = (uint32_t)(kv0) * key_step;                                                                           \
     _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                               \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_qkv, LDS_PTR(kl_ + TILE_BYTES + (wave + 4 * i) * 1024), 16, dma_k[i] + v_off + adv_, 0, 0, 0); \
+    if constexpr (X)                                                                                                            \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_qkv, LDS_PTR(kl_ + 2 * TILE_BYTES + (wave >> 1) * SIDE_BYTES + (wave & 1) * 1024), 16, \
+                                               dma_s + adv_, 0, 0, 0);                                                          \
   }
 #define DMA_KV(buf, kv0) { DMA_K_(buf, kv0); DMA_V_(buf, kv0); }
 
-  f32x16 dq[2];
+  f32x16 dq[NDT];  // (HD 80: of dq[2] only rows 0..15 = dims 64..79 mean something)
 #pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
+  for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
 
@@ -202,9 +212,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
   uint32_t ktr[2][2];  // K^T fragment addresses (tile 0 of buffer 0), [d tile][first / second read]
   tr_dual_addr(lds_addr(lds), 0, lane, ktr[0]);
   tr_dual_addr(lds_addr(lds), 32, lane, ktr[1]);
-  uint32_t rfa[4];     // row fragments (row lane&31 of a half tile, chunk 2ks + h5) of the K tile in slot 0; V tile: + TILE_BYTES
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) rfa[ks] = lds_addr(lds) + (uint32_t)(ql * 128 + (((2 * ks + h5) ^ sw_dual(ql)) << 4));
+  // K side image, transposed reads (dims 64..79 as rows of the third d tile): key 4 (G >> 1) + (li >> 2) (+ 8), dims 4 (li & 3) .. +3;
+  // the 16-lane groups with G & 1 = 1 would address dims 80..95 and repeat the other group's address (rows 16..31 are never stored)
+  const uint32_t ktr_s = lds_addr(lds) + (uint32_t)(2 * TILE_BYTES + (4 * (lane >> 5) + ((lane & 15) >> 2)) * 32 + 8 * (lane & 3));
   auto dq_tile = [&](auto BUFC, int t) {
     constexpr int BUF = decltype(BUFC)::value;
     const int kv0 = t * 64;
@@ -212,7 +222,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
     constexpr int NBUF = BUF ^ 1;  // its buffer ...
     const int nkv0 = kv0 + 64;     // ... and first key
     if (more && DMA_MODE == 0) DMA_KV(NBUF, nkv0);
-    const char* kl = lds + BUF * 2 * TILE_BYTES;
+    const char* kl = lds + BUF * BUF_BYTES;
     const char* vl = kl + TILE_BYTES;
     // a wave whose 32 query rows all lie past the sequence (the last block of N = 1568 has one live wave of four) only helps
     // staging the tiles: its matrix / VALU slots go to the other waves on its SIMD
@@ -220,41 +230,21 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
     static_for<0, 2>([&](auto ktc) {
       constexpr int kt = decltype(ktc)::value;
       if (kv0 + 32 * kt >= N) return;  // a half tile past the sequence (N = 1568: the second half of the last tile) contributes nothing
-      s16x4 tl[2][2], th[2][2];  // K^T fragments for the dQ product, [s2][dt] (asm reads: see common.h)
-#define DQ_TR_ISSUE()                                                                                        \
-  _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2)                                                           \
-      _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) {                                                     \
-    tl[s2][dt] = s2 == 0 ? lds_tr16_b64<BUF * 2 * TILE_BYTES + (kt * 32) * 128>(ktr[dt][0])                  \
-                         : lds_tr16_b64<BUF * 2 * TILE_BYTES + (kt * 32 + 16) * 128>(ktr[dt][0]);            \
-    th[s2][dt] = s2 == 0 ? lds_tr16_b64<BUF * 2 * TILE_BYTES + (kt * 32) * 128>(ktr[dt][1])                  \
-                         : lds_tr16_b64<BUF * 2 * TILE_BYTES + (kt * 32 + 16) * 128>(ktr[dt][1]);            \
-  }
-      f32x16 s, dp;
-#if TAD_DQ_BATCH
-      // The eight row fragments of the half tile (K and V rows of key lane&31) are requested in one batch of asm reads with counted
-      // waits: from plain loads the two chains ran read, read -> s_waitcnt -> two MFMAs four times per half tile, one exposed LDS
-      // latency each.  The K^T fragments of the dQ product are requested behind the chains (into the registers the row fragments
-      // leave) and waited for after the exponentials.  delta is subtracted in the vector pipe: as the initial accumulator it kept a
-      // 16-register block of -delta alive through the whole kernel, which the batch needs.
+      // K^T fragments for the dQ product, [s2][dt], issued now and waited for after the exponentials (asm reads: see common.h)
+      s16x4 tl[2][NDT], th[2][NDT];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-      {
-        op16x8 kr[4], vr[4];
-        static_for<0, 4>([&](auto kc) {
-          constexpr int ks = decltype(kc)::value;
-          kr[ks] = lds_read_b128<op16x8, BUF * 2 * TILE_BYTES + kt * 32 * 128>(rfa[ks]);
-          vr[ks] = lds_read_b128<op16x8, BUF * 2 * TILE_BYTES + TILE_BYTES + kt * 32 * 128>(rfa[ks]);
-        });
-        static_for<0, 4>([&](auto kc) {
-          constexpr int ks = decltype(kc)::value;
-          lds_wait<6 - 2 * ks>(kr[ks], vr[ks]);
-          s = TAD_MFMA_32x32x16(kr[ks], qf[ks], s);
-          dp = TAD_MFMA_32x32x16(vr[ks], dof[ks], dp);
-        });
+      for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          tl[s2][dt] = s2 == 0 ? lds_tr16_b64<BUF * BUF_BYTES + (kt * 32) * 128>(ktr[dt][0]) : lds_tr16_b64<BUF * BUF_BYTES + (kt * 32 + 16) * 128>(ktr[dt][0]);
+          th[s2][dt] = s2 == 0 ? lds_tr16_b64<BUF * BUF_BYTES + (kt * 32) * 128>(ktr[dt][1]) : lds_tr16_b64<BUF * BUF_BYTES + (kt * 32 + 16) * 128>(ktr[dt][1]);
+        }
+        if constexpr (X) {
+          tl[s2][NDT - 1] = s2 == 0 ? lds_tr16_b64<BUF * BUF_BYTES + (kt * 32) * 32>(ktr_s) : lds_tr16_b64<BUF * BUF_BYTES + (kt * 32 + 16) * 32>(ktr_s);
+          th[s2][NDT - 1] = s2 == 0 ? lds_tr16_b64<BUF * BUF_BYTES + (kt * 32 + 8) * 32>(ktr_s) : lds_tr16_b64<BUF * BUF_BYTES + (kt * 32 + 24) * 32>(ktr_s);
+        }
       }
-      DQ_TR_ISSUE();
-#else
-      DQ_TR_ISSUE();  // issued now and waited for after the exponentials
+      f32x16 s, dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = SUBD ? 0.f : -dlt; }
       const int key = kt * 32 + ql;
@@ -263,8 +253,10 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
         s = TAD_MFMA_32x32x16(row_frag_dual(kl, key, ks, h5), qf[ks], s);
         dp = TAD_MFMA_32x32x16(row_frag_dual(vl, key, ks, h5), dof[ks], dp);
       }
-#endif
-#undef DQ_TR_ISSUE
+      if constexpr (X) {  // dims 64..79: the side images' rows
+        s = TAD_MFMA_32x32x16(*reinterpret_cast<const op16x8*>(kl + 2 * TILE_BYTES + key * 32 + h5 * 16), qf[NKS - 1], s);
+        dp = TAD_MFMA_32x32x16(*reinterpret_cast<const op16x8*>(kl + 2 * TILE_BYTES + SIDE_BYTES + key * 32 + h5 * 16), dof[NKS - 1], dp);
+      }
       // dS^T = P^T o (dP^T - delta); keys >= N contribute nothing
       if (kv0 + 64 > N) {  // ragged last tile only: keys >= N get P = 0
         // (one lane value against 16 literals: see attn_bwd_dkv_kernel)
@@ -281,18 +273,14 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
         if (DROP) dpe = drop_keep(drop, drop_row, (uint32_t)(kv0 + kt * 32 + acc_row(r, h5))) ? dpe * drop.inv_keep : 0.f;
         ds[r] = fast_exp2(QS ? s[r] - lse2 : fmaf(s[r], c, -lse2)) * (SUBD ? dpe - dlt : dpe);  // (QS: scores in log2 units)
       }
-      lds_wait<4>(tl[0][0], th[0][0], tl[0][1], th[0][1]);
-      {
-        const op16x8 dsf = pack8(ds, 0);
+      static_for<0, 2>([&](auto sc) {
+        constexpr int s2 = decltype(sc)::value;
+        if constexpr (X) lds_wait<(s2 == 0 ? 6 : 0)>(tl[s2][0], th[s2][0], tl[s2][1], th[s2][1], tl[s2][NDT - 1], th[s2][NDT - 1]);
+        else lds_wait<(s2 == 0 ? 4 : 0)>(tl[s2][0], th[s2][0], tl[s2][1], th[s2][1]);
+        const op16x8 dsf = pack8(ds, s2);
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) dq[dt] = TAD_MFMA_32x32x16(join_tr(tl[0][dt], th[0][dt]), dsf, dq[dt]);
-      }
-      lds_wait<0>(tl[1][0], th[1][0], tl[1][1], th[1][1]);
-      {
-        const op16x8 dsf = pack8(ds, 1);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) dq[dt] = TAD_MFMA_32x32x16(join_tr(tl[1][dt], th[1][dt]), dsf, dq[dt]);
-      }
+        for (int dt = 0; dt < NDT; ++dt) dq[dt] = TAD_MFMA_32x32x16(join_tr(tl[s2][dt], th[s2][dt]), dsf, dq[dt]);
+      });
     });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -311,17 +299,36 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
         pk[dt][r4].x = pack_op16x2(dq[dt][4 * r4 + 0] * scale, dq[dt][4 * r4 + 1] * scale);
         pk[dt][r4].y = pack_op16x2(dq[dt][4 * r4 + 2] * scale, dq[dt][4 * r4 + 3] * scale);
       }
-    store_rows_via_lds(lds + wave * ROW_PATCH_BYTES, pk, dqkv + ((int64_t)b * N + q0) * tok + head * BHD /* q slot */, tok, N - q0, lane);
+    uint16_t* const qdst = dqkv + ((int64_t)b * N + q0) * tok + head * HD;  // q slot
+    store_rows_via_lds(lds + wave * ROW_PATCH_BYTES, pk, qdst, tok, N - q0, lane);
+    if constexpr (X) {
+      uint2 pk2[2];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        pk2[g].x = pack_op16x2(dq[NDT - 1][4 * g + 0] * scale, dq[NDT - 1][4 * g + 1] * scale);
+        pk2[g].y = pack_op16x2(dq[NDT - 1][4 * g + 2] * scale, dq[NDT - 1][4 * g + 3] * scale);
+      }
+      store_side16(pk2, qdst + 64, tok, N - q0, lane);
+    }
   }
 }
+#undef DMA_K_
+#undef DMA_V_
+#undef DMA_KV
 
 // ------------------------------------------------------------------------------------------------ dK, dV
-template <bool QS, bool DROP, int DMA_MODE>
+template <int HD, bool QS, bool DROP, int DMA_MODE>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
                                                            const float* __restrict__ rowc_g, uint16_t* __restrict__ dqkv, int N, int H, int B,
                                                            float scale, unsigned long long* stamps, const Drop drop) {
+  static_assert(HD == 64 || HD == 80, "head dim");
+  constexpr bool X = HD == 80;   // dims 64..79 of the Q / dO tiles in side images of 32-byte rows (see attn_fwd.hip)
+  constexpr int NKS = HD / 16, NDT = X ? 3 : 2;
+  constexpr int BHD = HD;
   constexpr int TILE_BYTES = 64 * 128;
-  constexpr int STAGE = 2 * TILE_BYTES + 512;  // Q tile, dO tile, 64 x (-lse/scale), 64 x (-delta)
+  constexpr int SIDE_BYTES = X ? 64 * 32 : 0;
+  constexpr int SIDE_OFF = 2 * TILE_BYTES + 512;
+  constexpr int STAGE = SIDE_OFF + 2 * SIDE_BYTES;  // Q tile, dO tile, 64 x (-lse/scale), 64 x (-delta) [, Q side, dO side]
   constexpr int NST = 2;
   __shared__ __attribute__((aligned(1024))) char lds[NST * STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -342,9 +349,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
   const bool kvalid = krow < N;
   const bool wave_live = key0 < N;  // wave-uniform
   if (!kvalid) krow = N - 1;
-  op16x8 kfr[4], vfr[4];
+  op16x8 kfr[NKS], vfr[NKS];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
+  for (int ks = 0; ks < NKS; ++ks) {
     kfr[ks] = *reinterpret_cast<const op16x8*>(kbase + (int64_t)krow * tok + 16 * ks + 8 * h5);
     vfr[ks] = *reinterpret_cast<const op16x8*>(vbase + (int64_t)krow * tok + 16 * ks + 8 * h5);
   }
@@ -364,6 +371,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
     dma_do[i] = (uint32_t)((((int64_t)b * N + row) * H + head) * BHD * 2) + ch;
   }
   const uint32_t q_step = (uint32_t)(tok * 2), do_step = (uint32_t)(H * BHD * 2);
+  // side images (HD 80): one piece per wave and tile = 32 rows x 32 B; waves 0 / 1 move the two halves of Q's, waves 2 / 3 of dO's
+  const int srow = 32 * (wave & 1) + (lane >> 1);
+  const uint32_t dma_s = (wave < 2 ? (uint32_t)(((int64_t)b * N + srow) * tok * 2) + (uint32_t)(head * BHD * 2)
+                                   : (uint32_t)((((int64_t)b * N + srow) * H + head) * BHD * 2)) + 128u + (uint32_t)((lane & 1) << 4);
   // Row constants (initial accumulator values, written by the dQ kernel): rows [0, BHN) of `rowc` hold -delta, rows [BHN, 2 BHN)
   // hold -lse/scale.  They are staged by LDS-DMA as well (4 bytes per lane: wave 0 moves the 64 -lse/scale values of the tile,
   // wave 1 the 64 -delta values), so the tile loop holds no ordinary global load and no LDS store -- with either of them in the loop
@@ -384,12 +395,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_do, LDS_PTR(ql_ + TILE_BYTES + (wave + 4 * i) * 1024), 16, dma_do[i] + (uint32_t)(q0) * do_step, 0, 0, 0); \
     if (wave < 2) /* wave-uniform */                                                                       \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_rc, LDS_PTR(ql_ + 2 * TILE_BYTES + wave * 256), 4, rc_off + (uint32_t)(q0) * 4u, 0, 0, 0); \
+    if constexpr (X) {                                                                                     \
+      if (wave < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_qkv, LDS_PTR(ql_ + SIDE_OFF + (wave & 1) * 1024), 16, dma_s + (uint32_t)(q0) * q_step, 0, 0, 0); \
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_do, LDS_PTR(ql_ + SIDE_OFF + SIDE_BYTES + (wave & 1) * 1024), 16, dma_s + (uint32_t)(q0) * do_step, 0, 0, 0); \
+    }                                                                                                      \
   }
 #define LOAD_QDO(buf, q0) { LOAD_Q_(buf, q0); LOAD_DO_RC_(buf, q0); }
 
-  f32x16 dk[2], dv[2];
+  f32x16 dk[NDT], dv[NDT];  // (HD 80: of dk[2] / dv[2] only rows 0..15 = dims 64..79 mean something)
 #pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
+  for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
 
@@ -405,6 +420,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) rfa[ks] = lds0 + (uint32_t)(kl_ * 128 + (((2 * ks + h5) ^ sw_dual(kl_)) << 4));
   const uint32_t rca = lds0 + 2 * TILE_BYTES + 16 * h5;  // row constants: 4 floats at [8 r4 + 4 h5]
+  // side images: row fragment (row lane&31 of a half tile, dims 64 + 8 h5 .. +7) and transposed fragment (rows 4 (G >> 1) + (li >> 2)
+  // (+ 8), dims 64 + 4 (li & 3) .. +3; the lane groups with G & 1 = 1 repeat the other group's address) of the Q side image; dO: + SIDE_BYTES
+  const uint32_t rfa_s = lds0 + (uint32_t)(SIDE_OFF + kl_ * 32 + h5 * 16);
+  const uint32_t qtr_s = lds0 + (uint32_t)(SIDE_OFF + (4 * (lane >> 5) + ((lane & 15) >> 2)) * 32 + 8 * (lane & 3));
 
   const int nt = (N + 63) / 64;
   LOAD_QDO(0, 0);
@@ -433,8 +452,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
       constexpr int HT = qt * 32 * 128;  // byte offset of the half tile inside a tile
       if (t * 64 + 32 * qt >= N) return;  // half tile of query rows past the sequence: P = dS = 0 there anyway
       // batch 1: initial accumulators (per-row constants; accumulator register r <-> row (r&3) + 8*(r>>2) + 4*h5) and row fragments
+      constexpr int HTS = qt * 32 * 32;  // byte offset of the half tile inside a side image
+      constexpr int NTR = X ? 12 : 8;    // transposed reads per batch
       f32x4 si[4], di[4];
-      op16x8 qa[4], da[4];
+      op16x8 qa[NKS], da[NKS];
       static_for<0, 4>([&](auto r4c) {
         constexpr int r4 = decltype(r4c)::value;
         si[r4] = lds_read_b128<f32x4, SO + (qt * 32 + 8 * r4) * 4>(rca);
@@ -445,28 +466,40 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
         qa[ks] = lds_read_b128<op16x8, SO + HT>(rfa[ks]);
         da[ks] = lds_read_b128<op16x8, SO + TILE_BYTES + HT>(rfa[ks]);
       }
+      if constexpr (X) {
+        qa[NKS - 1] = lds_read_b128<op16x8, SO + HTS>(rfa_s);
+        da[NKS - 1] = lds_read_b128<op16x8, SO + SIDE_BYTES + HTS>(rfa_s);
+      }
       // batch 2 / 3: transposed fragments for the dV / dK products of rows 0..15 / 16..31 of the half tile
-      s16x4 dol[2][2], doh[2][2], qtl[2][2], qth[2][2];  // [s2][dt]
+      s16x4 dol[2][NDT], doh[2][NDT], qtl[2][NDT], qth[2][NDT];  // [s2][dt]
 #define TR_ISSUE(s2_)                                                                         \
   _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) {                                          \
     dol[s2_][dt] = lds_tr16_b64<SO + TILE_BYTES + HT + 16 * (s2_) * 128>(qtr[dt][0]);         \
     doh[s2_][dt] = lds_tr16_b64<SO + TILE_BYTES + HT + 16 * (s2_) * 128>(qtr[dt][1]);         \
     qtl[s2_][dt] = lds_tr16_b64<SO + HT + 16 * (s2_) * 128>(qtr[dt][0]);                      \
     qth[s2_][dt] = lds_tr16_b64<SO + HT + 16 * (s2_) * 128>(qtr[dt][1]);                      \
+  }                                                                                           \
+  if constexpr (X) {                                                                          \
+    dol[s2_][NDT - 1] = lds_tr16_b64<SO + SIDE_BYTES + HTS + 16 * (s2_) * 32>(qtr_s);         \
+    doh[s2_][NDT - 1] = lds_tr16_b64<SO + SIDE_BYTES + HTS + (16 * (s2_) + 8) * 32>(qtr_s);   \
+    qtl[s2_][NDT - 1] = lds_tr16_b64<SO + HTS + 16 * (s2_) * 32>(qtr_s);                      \
+    qth[s2_][NDT - 1] = lds_tr16_b64<SO + HTS + (16 * (s2_) + 8) * 32>(qtr_s);                \
   }
 #define TR_MFMA(s2_, YOUNGER, pf_, dsf_)                                                                                       \
   lds_wait<YOUNGER>(dol[s2_][0], doh[s2_][0], qtl[s2_][0], qth[s2_][0], dol[s2_][1], doh[s2_][1], qtl[s2_][1], qth[s2_][1]);   \
-  _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) {                                                                           \
+  if constexpr (X) lds_wait<YOUNGER>(dol[s2_][NDT - 1], doh[s2_][NDT - 1], qtl[s2_][NDT - 1], qth[s2_][NDT - 1]);              \
+  _Pragma("unroll") for (int dt = 0; dt < NDT; ++dt) {                                                                         \
     dv[dt] = TAD_MFMA_32x32x16(join_tr(dol[s2_][dt], doh[s2_][dt]), pf_, dv[dt]);               \
     dk[dt] = TAD_MFMA_32x32x16(join_tr(qtl[s2_][dt], qth[s2_][dt]), dsf_, dk[dt]);              \
   }
-      if constexpr (DMA_MODE != 3) {
+      if constexpr (DMA_MODE != 3 && !X) {
         TR_ISSUE(0);
         lds_wait<16>(si[0], si[1], si[2], si[3], di[0], di[1], di[2], di[3]);  // (the counter saturates at 15: this also covers the row fragments)
-        lds_wait<8>(qa[0], qa[1], qa[2], qa[3], da[0], da[1], da[2], da[3]);
+        lds_wait<NTR>(qa[0], qa[1], qa[2], qa[3], da[0], da[1], da[2], da[3]);
       } else {  // ablation (timing only): no transposed reads at all -- how much of the kernel is LDS read traffic?
         lds_wait<0>(si[0], si[1], si[2], si[3], di[0], di[1], di[2], di[3]);
         lds_wait<0>(qa[0], qa[1], qa[2], qa[3], da[0], da[1], da[2], da[3]);
+        if constexpr (X) lds_wait<0>(qa[NKS - 1], da[NKS - 1]);
       }
       f32x16 s, dp;
 #pragma unroll
@@ -481,11 +514,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
           if ((r & 3) + 8 * (r >> 2) >= lim) { s[r] = -3.0e30f; dp[r] = 0.f; if (DROP) di[r >> 2][r & 3] = 0.f; }
       }
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
+      for (int ks = 0; ks < NKS; ++ks) {
         s = TAD_MFMA_32x32x16(qa[ks], kfr[ks], s);
         dp = TAD_MFMA_32x32x16(da[ks], vfr[ks], dp);
       }
-      if constexpr (DMA_MODE != 3) { TR_ISSUE(1); }
+      // (head_dim 80 has no registers left to hold the row fragments and both batches of transposed fragments: there the
+      // first batch is issued here, behind the S / dP products, and the second one behind the first batch's products)
+      if constexpr (DMA_MODE != 3) { TR_ISSUE(X ? 0 : 1); }
       f32x16 pm, ds;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -501,8 +536,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
       if constexpr (DMA_MODE != 3) {
         {
           const op16x8 pf = pack8(pm, 0), dsf = pack8(ds, 0);
-          TR_MFMA(0, 8, pf, dsf);
+          TR_MFMA(0, (X ? 0 : NTR), pf, dsf);
         }
+        if constexpr (X) { TR_ISSUE(1); }
         {
           const op16x8 pf = pack8(pm, 1), dsf = pack8(ds, 1);
           TR_MFMA(1, 0, pf, dsf);
@@ -556,6 +592,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
         pk[dt][r4].y = pack_op16x2(dv[dt][4 * r4 + 2], dv[dt][4 * r4 + 3]);
       }
     store_rows_via_lds(lds + wave * ROW_PATCH_BYTES, pk, okp + (int64_t)H * BHD, tok, N - key0, lane);
+    if constexpr (X) {  // dims 64..79: registers 0..7 of the third d tiles
+      const float ks_ = QS ? 0.69314718055994530942f : scale;
+      uint2 pk2[2];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        pk2[g].x = pack_op16x2(dk[NDT - 1][4 * g + 0] * ks_, dk[NDT - 1][4 * g + 1] * ks_);
+        pk2[g].y = pack_op16x2(dk[NDT - 1][4 * g + 2] * ks_, dk[NDT - 1][4 * g + 3] * ks_);
+      }
+      store_side16(pk2, okp + 64, tok, N - key0, lane);
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        pk2[g].x = pack_op16x2(dv[NDT - 1][4 * g + 0], dv[NDT - 1][4 * g + 1]);
+        pk2[g].y = pack_op16x2(dv[NDT - 1][4 * g + 2], dv[NDT - 1][4 * g + 3]);
+      }
+      store_side16(pk2, okp + (int64_t)H * BHD + 64, tok, N - key0, lane);
+    }
   }
 }
 
@@ -611,7 +663,8 @@ extern "C" int tad_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint
                             uint16_t* dqkv, float* delta, int B, int N, int H, int d, float scale, int q_prescaled, float dropout_p,
                             uint32_t seed, tad_stream_t stream) {
   TAD_REQUIRE(qkv && out && dout && lse && dqkv && delta, "attn_bwd: null pointer");
-  TAD_REQUIRE(d == BHD, "attn_bwd: head_dim must be 64 (got %d)", d);
+  TAD_REQUIRE(d == 64 || d == 80, "attn_bwd: head_dim must be 64 or 80 (got %d)", d);
+  const int BHD = d;
   TAD_REQUIRE(B > 0 && N > 0 && H > 0 && H <= 65535 && B <= 65535, "attn_bwd: bad shape");
   TAD_REQUIRE(scale > 0.f, "attn_bwd: scale must be positive");
   Drop drop;
@@ -623,10 +676,12 @@ extern "C" int tad_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint
   const int mode = attn_dma_mode;
 #define LAUNCH_BWD__(Q_, D_, M_)                                                                                             \
   {                                                                                                                          \
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<Q_, D_, M_>), grid, block, 0, st, qkv, out, out_lo, dout, lse, delta, dqkv, N, H, B, scale, drop);  \
+    if (d == 64) hipLaunchKernelGGL((attn_bwd_dq_kernel<64, Q_, D_, M_>), grid, block, 0, st, qkv, out, out_lo, dout, lse, delta, dqkv, N, H, B, scale, drop);  \
+    else hipLaunchKernelGGL((attn_bwd_dq_kernel<80, Q_, D_, M_>), grid, block, 0, st, qkv, out, out_lo, dout, lse, delta, dqkv, N, H, B, scale, drop);  \
     int rc = check_launch("attn_bwd_dq");                                                                                    \
     if (rc) return rc;                                                                                                       \
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<Q_, D_, M_>), grid, block, 0, st, qkv, dout, delta, dqkv, N, H, B, scale, attn_stamps, drop);  \
+    if (d == 64) hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, Q_, D_, M_>), grid, block, 0, st, qkv, dout, delta, dqkv, N, H, B, scale, attn_stamps, drop);  \
+    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<80, Q_, D_, M_>), grid, block, 0, st, qkv, dout, delta, dqkv, N, H, B, scale, attn_stamps, drop);  \
     return check_launch("attn_bwd_dkv");                                                                                     \
   }
 #define LAUNCH_BWD_(Q_, M_) { if (dropout_p > 0.f) LAUNCH_BWD__(Q_, true, M_) else LAUNCH_BWD__(Q_, false, M_) }

@@ -14,7 +14,6 @@
 
 TAD_NAMESPACE_BEGIN
 
-constexpr int HD = 64;      // head dim
 constexpr int KV_TILE = 64; // keys per LDS tile
 constexpr int Q_WAVE = 32;  // query rows per wave
 constexpr int Q_BLOCK = 128;
@@ -51,13 +50,21 @@ typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 // DROP: attention dropout (modeling_finetune.py:99-101; flash_attention_class.py:59-61) -- the softmax is normalised by the row sum of
 // ALL probabilities (taken as f32 vector adds here), the P V product sees keep ? P / (1 - p) : 0 with the counter-based mask of
 // common.h (drop_keep), which the two backward kernels and the oracle regenerate.
-template <bool OUT_BF16, bool QS, bool DROP, int DMA_MODE>
+// HD: head dim 64, or 80 (the "huge" factories, modeling_finetune.py:390-398) handled as 64 + 16: the first 64 dims of a K / V tile
+// keep the 128-byte-row LDS image and everything built on it; dims 64..79 travel in a SIDE image of 32-byte rows (one more 1-KiB DMA
+// piece per wave and tile), add a fifth k-step to the score products and a third (half-used) d tile to the P V product.
+template <int HD, bool OUT_BF16, bool QS, bool DROP, int DMA_MODE>
 __global__ __launch_bounds__(256, TAD_FWD_ROWSUM_VALU ? 4 : 1) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, void* __restrict__ out,
                                                        uint16_t* __restrict__ out_lo, float* __restrict__ lse, int N, int H, int B,
                                                        float scale, const Drop drop) {
   constexpr bool VSUM = TAD_FWD_ROWSUM_VALU || DROP;  // row sums of P by vector adds instead of MFMAs
-  constexpr int TILE_BYTES = KV_TILE * HD * 2;                                  // 8 KiB
-  __shared__ __attribute__((aligned(1024))) char lds[2 * 2 * TILE_BYTES];       // [buf][K|V][64 keys][128 B]
+  static_assert(HD == 64 || HD == 80, "head dim");
+  constexpr bool X = HD == 80;                                                   // 16 extra dims in the side images
+  constexpr int NKS = HD / 16, NDT = X ? 3 : 2;                                  // k-steps of the score product, d tiles of the output
+  constexpr int TILE_BYTES = KV_TILE * 128;                                      // 8 KiB: dims 0..63
+  constexpr int SIDE_BYTES = X ? KV_TILE * 32 : 0;                               // 2 KiB: dims 64..79
+  constexpr int BUF_BYTES = 2 * TILE_BYTES + 2 * SIDE_BYTES;                     // [K main | V main | K side | V side]
+  __shared__ __attribute__((aligned(1024))) char lds[2 * BUF_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // 1-D grid, XCD-aware: the query blocks of one (batch, head) pair re-read the same K/V (400 KB); dealt round-robin over the
@@ -77,13 +84,13 @@ __global__ __launch_bounds__(256, TAD_FWD_ROWSUM_VALU ? 4 : 1) void attn_fwd_ker
   const float c = scale * 1.44269504088896340736f;  // scale * log2(e)
 
   // Q^T fragments (B operand): lane (q, h5) holds Q[q][16ks + 8h5 .. +7]
-  op16x8 qf[4];
+  op16x8 qf[NKS];
   {
     int qrow = q0 + ql;
     if (qrow > N - 1) qrow = N - 1;  // clamped rows are computed but never stored
     const uint16_t* qp = base + (int64_t)qrow * tok_stride + 8 * h5;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const op16x8*>(qp + 16 * ks);
+    for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const op16x8*>(qp + 16 * ks);
   }
 
   // staging: K/V tiles go global -> LDS by LDS-DMA (no staging registers, no ds_write): a 1-KiB piece = 8 keys x 128 B; wave w
@@ -101,25 +108,33 @@ __global__ __launch_bounds__(256, TAD_FWD_ROWSUM_VALU ? 4 : 1) void attn_fwd_ker
     dma_v[i] = rowb + (uint32_t)(2 * H * HD * 2) + (uint32_t)((dch ^ swv(key)) << 4);
   }
   const uint32_t tile_step = (uint32_t)(tok_stride * 2);  // bytes per key
+  // side images (HD 80): one piece per wave and tile = 32 keys x 32 B; waves 0 / 1 move the two halves of K's, waves 2 / 3 of V's
+  const uint32_t dma_s = (uint32_t)(((int64_t)b * N + 32 * (wave & 1) + (lane >> 1)) * tok_stride * 2) + (uint32_t)(head * HD * 2) +
+                         (uint32_t)((1 + (wave >> 1)) * H * HD * 2) + 128u + (uint32_t)((lane & 1) << 4);
+#define DMA_SIDE_(buf, kv0)                                                                                                 \
+  if constexpr (X) {                                                                                                        \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_qkv, LDS_PTR(lds + (buf) * BUF_BYTES + 2 * TILE_BYTES + (wave >> 1) * SIDE_BYTES + (wave & 1) * 1024), \
+                                             16, dma_s + (uint32_t)(kv0) * tile_step, 0, 0, 0);                             \
+  }
 #define DMA_K_(buf, kv0)                                                                                                    \
   {                                                                                                                         \
-    char* kl_ = lds + (buf) * 2 * TILE_BYTES;                                                                               \
+    char* kl_ = lds + (buf) * BUF_BYTES;                                                                                    \
     const uint32_t adv_ = (uint32_t)(kv0) * tile_step;                                                                      \
     _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                           \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_qkv, LDS_PTR(kl_ + (wave + 4 * i) * 1024), 16, dma_k[i] + adv_, 0, 0, 0); \
   }
 #define DMA_V_(buf, kv0)                                                                                                    \
   {                                                                                                                         \
-    char* kl_ = lds + (buf) * 2 * TILE_BYTES;                                                                               \
+    char* kl_ = lds + (buf) * BUF_BYTES;                                                                                    \
     const uint32_t adv_ = (uint32_t)(kv0) * tile_step;                                                                      \
     _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                           \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_qkv, LDS_PTR(kl_ + TILE_BYTES + (wave + 4 * i) * 1024), 16, dma_v[i] + adv_, 0, 0, 0); \
   }
-#define DMA_TILE(buf, kv0) { DMA_K_(buf, kv0); DMA_V_(buf, kv0); }
+#define DMA_TILE(buf, kv0) { DMA_K_(buf, kv0); DMA_V_(buf, kv0); DMA_SIDE_(buf, kv0); }
 
-  f32x16 o[2];
+  f32x16 o[NDT];  // (HD 80: of o[2] only rows 0..15 = dims 64..79 mean something)
 #pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
+  for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
 
@@ -139,9 +154,13 @@ __global__ __launch_bounds__(256, TAD_FWD_ROWSUM_VALU ? 4 : 1) void attn_fwd_ker
 
   // lane-constant LDS addresses of the K row fragments (key lane&31 of a 32-key block, chunk 2ks + h5) in buffer 0, block 0: the
   // swizzle only looks at key bits 1..3, so block kt and the buffer are plain byte offsets
-  uint32_t k_rd[4];
+  uint32_t k_rd[NKS];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) k_rd[ks] = lds_addr(lds) + (uint32_t)(ql * 128 + (((2 * ks + h5) ^ swk(ql)) << 4));
+  if constexpr (X) k_rd[NKS - 1] = lds_addr(lds) + (uint32_t)(2 * TILE_BYTES + ql * 32 + h5 * 16);  // side image: dims 64 + 8 h5 .. +7 of key ql
+  // side image of V, transposed reads: the 16-lane groups with G & 1 = 1 would address dims 80..95: they repeat the other group's
+  // address (rows 16..31 of the third d tile are never stored)
+  const uint32_t vs_rd = lds_addr(lds) + (uint32_t)(2 * TILE_BYTES + SIDE_BYTES + (4 * v_h + v_q) * 32 + 8 * v_p);
 
   // Row sums of P^T out of the matrix pipe instead of 32 v_add per lane and tile (the kernel is VALU-issue bound, and the sum then uses
   // the same bf16-rounded P as the PV product) -- as ONE v_mfma_f32_16x16x32_bf16 per P fragment (half the matrix time and a quarter
@@ -176,20 +195,20 @@ __global__ __launch_bounds__(256, TAD_FWD_ROWSUM_VALU ? 4 : 1) void attn_fwd_ker
     const int kv0 = T * KV_TILE;
     if (T + 1 < nt && DMA_MODE == 0 && !(TAD_FWD_ABL & 16)) DMA_TILE(BUF ^ 1, kv0 + KV_TILE);
     if (wave_live) {  // waves whose 32 query rows all lie past the sequence only help staging the tiles
-      op16x8 kf[2][4];
+      op16x8 kf[2][NKS];
       f32x16 s[2];
       if constexpr (!(TAD_FWD_ABL & 8)) {
-      static_for<0, 8>([&](auto ic) {
-        constexpr int i_ = decltype(ic)::value;
-        kf[i_ >> 2][i_ & 3] = lds_read_b128<op16x8, BUF * 2 * TILE_BYTES + (i_ >> 2) * 32 * 128>(k_rd[i_ & 3]);
+      static_for<0, 2 * NKS>([&](auto ic) {
+        constexpr int i_ = decltype(ic)::value, kt = i_ / NKS, ks = i_ % NKS;
+        kf[kt][ks] = lds_read_b128<op16x8, BUF * BUF_BYTES + kt * 32 * (ks < 4 ? 128 : 32)>(k_rd[ks]);
       });
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-      static_for<0, 8>([&](auto ic) {
-        constexpr int i_ = decltype(ic)::value, kt = i_ >> 2, ks = i_ & 3;
-        lds_wait<7 - i_>(kf[kt][ks]);
+      static_for<0, 2 * NKS>([&](auto ic) {
+        constexpr int i_ = decltype(ic)::value, kt = i_ / NKS, ks = i_ % NKS;
+        lds_wait<2 * NKS - 1 - i_>(kf[kt][ks]);
         s[kt] = TAD_MFMA_32x32x16(kf[kt][ks], qf[ks], s[kt]);
       });
       } else {
@@ -198,7 +217,7 @@ __global__ __launch_bounds__(256, TAD_FWD_ROWSUM_VALU ? 4 : 1) void attn_fwd_ker
 #pragma unroll
           for (int r = 0; r < 16; ++r) s[kt][r] = o[kt][r] * 1e-3f + (float)T;  // (something live and data dependent)
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks) kf[kt][ks] = qf[ks];
+          for (int ks = 0; ks < NKS; ++ks) kf[kt][ks] = qf[ks];
         }
       }
       if (kv0 + KV_TILE > N) {  // ragged last tile: mask keys >= N (one lane value against 32 literals: written with the key
@@ -229,7 +248,7 @@ __global__ __launch_bounds__(256, TAD_FWD_ROWSUM_VALU ? 4 : 1) void attn_fwd_ker
         m_run = m_new;
         l_run *= alpha;
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+        for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
           for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
       }
@@ -264,25 +283,28 @@ __global__ __launch_bounds__(256, TAD_FWD_ROWSUM_VALU ? 4 : 1) void attn_fwd_ker
       } else {
       // V^T fragments through the asm reads of common.h (the builtin made the compiler drain the DMA of the next tile here):
       // group g = 2 kt + s2 covers keys 16g .. 16g+15; the reads of group g+1 are issued before the MFMAs of group g
-      s16x4 vlo[2][2], vhi[2][2];  // [group parity][dt]
+      s16x4 vlo[2][NDT], vhi[2][NDT];  // [group parity][dt]
+      auto v_issue = [&](auto gc, auto pc) {
+        constexpr int g_ = decltype(gc)::value, par = decltype(pc)::value;
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        vlo[0][dt] = lds_tr16_b64<BUF * 2 * TILE_BYTES + TILE_BYTES>(v_rd[dt]);
-        vhi[0][dt] = lds_tr16_b64<BUF * 2 * TILE_BYTES + TILE_BYTES + 8 * 128>(v_rd[dt]);
-      }
+        for (int dt = 0; dt < 2; ++dt) {
+          vlo[par][dt] = lds_tr16_b64<BUF * BUF_BYTES + TILE_BYTES + g_ * 16 * 128>(v_rd[dt]);
+          vhi[par][dt] = lds_tr16_b64<BUF * BUF_BYTES + TILE_BYTES + g_ * 16 * 128 + 8 * 128>(v_rd[dt]);
+        }
+        if constexpr (X) {
+          vlo[par][NDT - 1] = lds_tr16_b64<BUF * BUF_BYTES + g_ * 16 * 32>(vs_rd);
+          vhi[par][NDT - 1] = lds_tr16_b64<BUF * BUF_BYTES + g_ * 16 * 32 + 8 * 32>(vs_rd);
+        }
+      };
+      v_issue(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
       static_for<0, 4>([&](auto gc) {
         constexpr int g_ = decltype(gc)::value, par = g_ & 1;
-        if constexpr (g_ < 3) {
+        if constexpr (g_ < 3) v_issue(std::integral_constant<int, g_ + 1>{}, std::integral_constant<int, par ^ 1>{});
+        if (!VSUM) rs = TAD_MFMA_16x16x32(sel, pf[g_ >> 1][g_ & 1], rs);
+        if constexpr (X) lds_wait<(g_ < 3 ? 6 : 0)>(vlo[par][0], vhi[par][0], vlo[par][1], vhi[par][1], vlo[par][NDT - 1], vhi[par][NDT - 1]);
+        else lds_wait<(g_ < 3 ? 4 : 0)>(vlo[par][0], vhi[par][0], vlo[par][1], vhi[par][1]);
 #pragma unroll
-          for (int dt = 0; dt < 2; ++dt) {
-            vlo[par ^ 1][dt] = lds_tr16_b64<BUF * 2 * TILE_BYTES + TILE_BYTES + (g_ + 1) * 16 * 128>(v_rd[dt]);
-            vhi[par ^ 1][dt] = lds_tr16_b64<BUF * 2 * TILE_BYTES + TILE_BYTES + (g_ + 1) * 16 * 128 + 8 * 128>(v_rd[dt]);
-          }
-        }
-        rs = TAD_MFMA_16x16x32(sel, pf[g_ >> 1][g_ & 1], rs);
-        lds_wait<(g_ < 3 ? 4 : 0)>(vlo[par][0], vhi[par][0], vlo[par][1], vhi[par][1]);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) o[dt] = TAD_MFMA_32x32x16(join_tr(vlo[par][dt], vhi[par][dt]), pf[g_ >> 1][g_ & 1], o[dt]);
+        for (int dt = 0; dt < NDT; ++dt) o[dt] = TAD_MFMA_32x32x16(join_tr(vlo[par][dt], vhi[par][dt]), pf[g_ >> 1][g_ & 1], o[dt]);
       });
       }
       if (VSUM) l_run += half_swap_sum((psum[0] + psum[1]) + (psum[2] + psum[3]));
@@ -317,12 +339,30 @@ __global__ __launch_bounds__(256, TAD_FWD_ROWSUM_VALU ? 4 : 1) void attn_fwd_ker
           const float v0 = o[dt][4 * r4 + 0] * inv, v1 = o[dt][4 * r4 + 1] * inv, v2 = o[dt][4 * r4 + 2] * inv, v3 = o[dt][4 * r4 + 3] * inv;
           pk[dt][r4].x = pack_op16x2(v0, v1);
           pk[dt][r4].y = pack_op16x2(v2, v3);
-          // what the 16-bit rounding dropped (see tad_attn_fwd: the backward's delta is taken of out + out_lo)
+          // what the 16-bit rounding dropped (see tad_attn_fwd: the backward's delta is taken of out + out_lo).  The packed words are
+          // made opaque first: with f16 operands the compiler otherwise re-derives the rounded value for this subtraction with
+          // v_fma_mixlo_f16 (ONE rounding of o * inv) while the stored word is v_cvt_pk_f16_f32 of the f32 product (two roundings) --
+          // on a tie of the f32 product the two land on different neighbours and out + out_lo is off by a whole f16 step.
+          asm volatile("" : "+v"(pk[dt][r4].x), "+v"(pk[dt][r4].y));
           lo[dt][r4].x = pack_op16x2(v0 - op16_lo_f32(pk[dt][r4].x), v1 - op16_hi_f32(pk[dt][r4].x));
           lo[dt][r4].y = pack_op16x2(v2 - op16_lo_f32(pk[dt][r4].y), v3 - op16_hi_f32(pk[dt][r4].y));
         }
       store_rows_via_lds(lds + wave * ROW_PATCH_BYTES, pk, (uint16_t*)out + obase0, (int64_t)H * HD, N - q0, lane);
       if (out_lo) store_rows_via_lds(lds + wave * ROW_PATCH_BYTES, lo, out_lo + obase0, (int64_t)H * HD, N - q0, lane);
+      if constexpr (X) {  // dims 64..79: registers 0..7 of the third d tile
+        uint2 pk2[2], lo2[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const float v0 = o[NDT - 1][4 * g + 0] * inv, v1 = o[NDT - 1][4 * g + 1] * inv, v2 = o[NDT - 1][4 * g + 2] * inv, v3 = o[NDT - 1][4 * g + 3] * inv;
+          pk2[g].x = pack_op16x2(v0, v1);
+          pk2[g].y = pack_op16x2(v2, v3);
+          asm volatile("" : "+v"(pk2[g].x), "+v"(pk2[g].y));
+          lo2[g].x = pack_op16x2(v0 - op16_lo_f32(pk2[g].x), v1 - op16_hi_f32(pk2[g].x));
+          lo2[g].y = pack_op16x2(v2 - op16_lo_f32(pk2[g].y), v3 - op16_hi_f32(pk2[g].y));
+        }
+        store_side16(pk2, (uint16_t*)out + obase0 + 64, (int64_t)H * HD, N - q0, lane);
+        if (out_lo) store_side16(lo2, out_lo + obase0 + 64, (int64_t)H * HD, N - q0, lane);
+      }
     }
   } else if (qrow < N) {
     const int64_t obase = (((int64_t)b * N + qrow) * H + head) * HD;
@@ -334,6 +374,12 @@ __global__ __launch_bounds__(256, TAD_FWD_ROWSUM_VALU ? 4 : 1) void attn_fwd_ker
         *reinterpret_cast<float4*>((float*)out + obase + d) =
             make_float4(o[dt][4 * r4 + 0] * inv, o[dt][4 * r4 + 1] * inv, o[dt][4 * r4 + 2] * inv, o[dt][4 * r4 + 3] * inv);
       }
+    if constexpr (X) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+        *reinterpret_cast<float4*>((float*)out + obase + 64 + 8 * g + 4 * h5) =
+            make_float4(o[NDT - 1][4 * g + 0] * inv, o[NDT - 1][4 * g + 1] * inv, o[NDT - 1][4 * g + 2] * inv, o[NDT - 1][4 * g + 3] * inv);
+    }
   }
   if (qrow < N && h5 == 0 && lse) lse[((int64_t)b * H + head) * N + qrow] = QS ? (m_run + __log2f(l_tot)) * 0.69314718055994530942f : m_run * scale + __logf(l_tot);
 }
@@ -348,7 +394,8 @@ extern "C" int tad_attn_fwd(const uint16_t* qkv, void* out, int out_dtype, uint1
                             float scale, int q_prescaled, float dropout_p, uint32_t seed, tad_stream_t stream) {
   TAD_REQUIRE(qkv && out, "attn_fwd: null pointer");
   TAD_REQUIRE(!out_lo || out_dtype == TAD_OP16, "attn_fwd: out_lo (the rounding residual) goes with a 16-bit output");
-  TAD_REQUIRE(d == HD, "attn_fwd: head_dim must be 64 (got %d)", d);
+  TAD_REQUIRE(d == 64 || d == 80, "attn_fwd: head_dim must be 64 or 80 (got %d)", d);
+  const int HD = d;
   TAD_REQUIRE(B > 0 && N > 0 && H > 0 && H <= 65535 && B <= 65535, "attn_fwd: bad shape B=%d N=%d H=%d", B, N, H);
   TAD_REQUIRE(out_dtype == TAD_F32 || out_dtype == TAD_OP16, "attn_fwd: bad out_dtype %d", out_dtype);
   TAD_REQUIRE(scale > 0.f, "attn_fwd: scale must be positive");
@@ -360,8 +407,9 @@ extern "C" int tad_attn_fwd(const uint16_t* qkv, void* out, int out_dtype, uint1
               (long long)B * N * 3 * H * HD * 2, B, N, H);
   TAD_REQUIRE((int64_t)((N + Q_BLOCK - 1) / Q_BLOCK) * H * B < (1ll << 31), "attn_fwd: grid too large");
   const dim3 grid((unsigned)(((N + Q_BLOCK - 1) / Q_BLOCK) * H * B)), block(256);
-#define LAUNCH_FWD__(O_, Q_, D_, M_) hipLaunchKernelGGL((attn_fwd_kernel<O_, Q_, D_, M_>), grid, block, 0, (hipStream_t)stream, qkv, out, out_lo, lse, N, H, B, scale, drop)
-#define LAUNCH_FWD_(O_, Q_, M_) { if (dropout_p > 0.f) LAUNCH_FWD__(O_, Q_, true, M_); else LAUNCH_FWD__(O_, Q_, false, M_); }
+#define LAUNCH_FWD___(H_, O_, Q_, D_, M_) hipLaunchKernelGGL((attn_fwd_kernel<H_, O_, Q_, D_, M_>), grid, block, 0, (hipStream_t)stream, qkv, out, out_lo, lse, N, H, B, scale, drop)
+#define LAUNCH_FWD__(O_, Q_, D_, M_) { if (d == 64) LAUNCH_FWD___(64, O_, Q_, D_, M_); else LAUNCH_FWD___(80, O_, Q_, D_, M_); }
+#define LAUNCH_FWD_(O_, Q_, M_) { if (dropout_p > 0.f) LAUNCH_FWD__(O_, Q_, true, M_) else LAUNCH_FWD__(O_, Q_, false, M_) }
 #define LAUNCH_FWD(M_)                                                                                \
   {                                                                                                   \
     if (out_dtype == TAD_OP16) { if (q_prescaled) LAUNCH_FWD_(true, true, M_) else LAUNCH_FWD_(true, false, M_) }    \
@@ -375,4 +423,5 @@ extern "C" int tad_attn_fwd(const uint16_t* qkv, void* out, int out_dtype, uint1
 #undef LAUNCH_FWD
 #undef LAUNCH_FWD_
 #undef LAUNCH_FWD__
+#undef LAUNCH_FWD___
 }

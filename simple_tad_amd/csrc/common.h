@@ -165,9 +165,17 @@ template <int N, typename A, typename B, typename C, typename D>
 __device__ __forceinline__ void lds_wait(A& a, B& b, C& c, D& d) {
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : TAD_LGKM(N));
 }
+template <int N, typename A, typename B, typename C>
+__device__ __forceinline__ void lds_wait(A& a, B& b, C& c) {
+  asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : TAD_LGKM(N));
+}
 template <int N, typename A, typename B, typename C, typename D, typename E>
 __device__ __forceinline__ void lds_wait(A& a, B& b, C& c, D& d, E& e) {
   asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : TAD_LGKM(N));
+}
+template <int N, typename A, typename B, typename C, typename D, typename E, typename F>
+__device__ __forceinline__ void lds_wait(A& a, B& b, C& c, D& d, E& e, F& f) {
+  asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : TAD_LGKM(N));
 }
 template <int N, typename A, typename B, typename C, typename D, typename E, typename F, typename G, typename H>
 __device__ __forceinline__ void lds_wait(A& a, B& b, C& c, D& d, E& e, F& f, G& g, H& h) {
@@ -232,6 +240,17 @@ inline bool make_drop(float p, uint32_t seed, Drop* d) {
 }
 // accumulator register r of lane half h holds row (r & 3) + 8 (r >> 2) + 4 h of a 32 x 32 tile
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// The 16 extra head dims of a head_dim-80 tile (dims 64..79), held the way ONE 32 x 32 accumulator tile leaves them with only its rows
+// 0..15 meaningful: lane (row lane & 31, half h5) has registers 0..7 = dims (r & 3) + 8 (r >> 2) + 4 h5, i.e. two groups of four
+// consecutive dims.  pk[g] = the packed group g (dims 8 g + 4 h5 .. +3); stored as 8-byte pieces (32 bytes per row in all).
+__device__ __forceinline__ void store_side16(const uint2 (&pk)[2], uint16_t* dst, int64_t row_stride, int rows_valid, int lane) {
+  const int rl = lane & 31, h5 = lane >> 5;
+  if (rl < rows_valid) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) *reinterpret_cast<uint2*>(dst + rl * row_stride + 8 * g + 4 * h5) = pk[g];
+  }
+}
 
 // compile-time loop: f(std::integral_constant<int, I>) for I in [BEGIN, END)
 template <int BEGIN, int END, typename F>

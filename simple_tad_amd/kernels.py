@@ -580,19 +580,19 @@ def colsum_bf16(a, out=None):
 
 # ----------------------------------------------------------------------------- attention
 def attn_fwd(qkv, B: int, N: int, H: int, scale: float, out_dtype=None, want_lse=True, want_lo=False, q_prescaled=False, drop_p: float = 0.0,
-             seed: int = 0):
-    """qkv [B*N, 3*H*64] bf16 or f16 (packed [B,N,3,H,64]) -> out [B*N, H*64], lse [B,H,N] f32.  want_lo: returns (out, lse, out_lo)
-    with out_lo = what the 16-bit rounding of out dropped (for attn_bwd's delta).  q_prescaled: the q third already carries
-    scale * log2(e) (linear_fwd_qkv's q_prescale = q_prescale_of(scale))"""
+             seed: int = 0, d: int = 64):
+    """qkv [B*N, 3*H*d] bf16 or f16 (packed [B,N,3,H,d], d = 64 or 80) -> out [B*N, H*d], lse [B,H,N] f32.  want_lo: returns
+    (out, lse, out_lo) with out_lo = what the 16-bit rounding of out dropped (for attn_bwd's delta).  q_prescaled: the q third already
+    carries scale * log2(e) (linear_fwd_qkv's q_prescale = q_prescale_of(scale))"""
     op = _req16(qkv, "attn.qkv")
     out_dtype = _out16(out_dtype, op)
-    if qkv.numel() != B * N * 3 * H * 64:
-        raise _lib.TadError(f"attn_fwd: qkv has {qkv.numel()} elements, expected {B * N * 3 * H * 64}")
-    out = torch.empty((B * N, H * 64), dtype=out_dtype, device=qkv.device)
+    if qkv.numel() != B * N * 3 * H * d:
+        raise _lib.TadError(f"attn_fwd: qkv has {qkv.numel()} elements, expected {B * N * 3 * H * d}")
+    out = torch.empty((B * N, H * d), dtype=out_dtype, device=qkv.device)
     lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device) if want_lse else None
     lo = torch.empty_like(out) if (want_lo and out.dtype in OP16_DTYPES) else None
-    with _timed("attn_fwd", 4.0 * B * H * N * N * 64, 2.0 * (4 + (lo is not None)) * B * N * H * 64):
-        check(_fn("tad_attn_fwd", op)(qkv.data_ptr(), out.data_ptr(), _dt(out), _p(lo), _p(lse), B, N, H, 64, float(scale), int(bool(q_prescaled)),
+    with _timed("attn_fwd", 4.0 * B * H * N * N * d, 2.0 * (4 + (lo is not None)) * B * N * H * d):
+        check(_fn("tad_attn_fwd", op)(qkv.data_ptr(), out.data_ptr(), _dt(out), _p(lo), _p(lse), B, N, H, int(d), float(scale), int(bool(q_prescaled)),
                                       float(drop_p), int(seed) & 0xffffffff, _stream()), "tad_attn_fwd")
     return (out, lse, lo) if want_lo else (out, lse)
 
@@ -603,17 +603,22 @@ def attn_tuning(**knobs):
         check(_lib.load().tad_attn_tuning(k.encode(), int(v)), f"tad_attn_tuning({k}={v})")
 
 
-def attn_bwd(qkv, out, dout, lse, B: int, N: int, H: int, scale: float, out_lo=None, q_prescaled=False, drop_p: float = 0.0, seed: int = 0):
+def attn_bwd(qkv, out, dout, lse, B: int, N: int, H: int, scale: float, out_lo=None, q_prescaled=False, drop_p: float = 0.0, seed: int = 0,
+             d: int = 64):
     """dqkv; its q slot is the gradient of the PLAIN q whether or not the q of `qkv` is pre-scaled"""
     op = _req16(qkv, "attn_bwd.qkv")
     for t, n in ((out, "out"), (dout, "dout")) + (((out_lo, "out_lo"),) if out_lo is not None else ()):
         _req16(t, "attn_bwd." + n, like=op)
+        if t.numel() != B * N * H * d:
+            raise _lib.TadError(f"attn_bwd: {n} has {t.numel()} elements, expected {B * N * H * d}")
     _req(lse, torch.float32, "attn_bwd.lse")
+    if qkv.numel() != B * N * 3 * H * d or lse.numel() != B * H * N:
+        raise _lib.TadError("attn_bwd: qkv / lse element count mismatch")
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((_lib.load().tad_attn_bwd_scratch_bytes(B, N, H) // 4,), dtype=torch.float32, device=qkv.device)  # -rowsum(dout*out), -lse/scale
-    with _timed("attn_bwd", 8.0 * B * H * N * N * 64, 2.0 * (8 + (out_lo is not None)) * B * N * H * 64):
+    with _timed("attn_bwd", 8.0 * B * H * N * N * d, 2.0 * (8 + (out_lo is not None)) * B * N * H * d):
         check(_fn("tad_attn_bwd", op)(qkv.data_ptr(), out.data_ptr(), _p(out_lo), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), delta.data_ptr(),
-                                       B, N, H, 64, float(scale), int(bool(q_prescaled)), float(drop_p), int(seed) & 0xffffffff, _stream()),
+                                       B, N, H, int(d), float(scale), int(bool(q_prescaled)), float(drop_p), int(seed) & 0xffffffff, _stream()),
               "tad_attn_bwd")
     return dqkv
 

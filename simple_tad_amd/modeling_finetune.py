@@ -129,7 +129,7 @@ class Attention(nn.Module):
 
     def _check(self):
         if self.head_dim not in (64, 80):
-            raise TadError(f"Attention: head_dim {self.head_dim} has no kernel (64: fused 16-bit MFMA kernels; 64 / 80: exact-f32 MFMA kernels)")
+            raise TadError(f"Attention: head_dim {self.head_dim} has no kernel (64 and 80 do: fused 16-bit MFMA kernels, exact-f32 MFMA kernels in precise mode)")
 
     def _dropout(self):
         """(p, seed) of attention dropout for this forward (modeling_finetune.py:99-101; the flash path passes dropout_p in training,

@@ -5,8 +5,7 @@ backward run on the HIP kernels (shared Block stack of ``modeling_finetune`` + t
 Reference lines are cited per class (modeling_pretrain.py).  Differences, by design:
   * ``forward(x, mask, num_masked=None)``: ``num_masked`` (masked tokens per clip, identical for every clip as the reference's
     ``reshape(B, -1, C)`` requires) may be passed to avoid one device sync; otherwise it is read from ``mask[0]``.
-  * There is no CPU path.  head_dim 64 (small / base / large) runs the fused bf16 MFMA attention kernels, head_dim 80 (huge) the generic
-    f32 attention kernels between bf16 MFMA Linears.
+  * There is no CPU path.  head_dim 64 (small / base / large) and head_dim 80 (huge) run the fused 16-bit MFMA attention kernels.
 """
 from __future__ import annotations
 

@@ -394,15 +394,26 @@ def set_attn_exact_delta(on: bool):
     _attn_exact_delta = bool(on)
 
 
+_attn_hd80_f32 = False
+
+
+def set_attn_hd80_f32(on: bool):
+    """A/B switch: head_dim 80 attention through the exact-f32 MFMA kernels (the round-3 route) instead of the 16-bit ones"""
+    global _attn_hd80_f32
+    _attn_hd80_f32 = bool(on)
+
+
 def _attn_fwd_core(xn, qkv_w, q_bias, v_bias, B, N, H, scale, train, drop=(0.0, 0)):
     """returns qkv, attention output, (lse, rounding residual of the output | None).  drop = (p, seed) of attention dropout."""
     qb = None if q_bias is None else _f32c(q_bias.detach())
     vb = None if v_bias is None else _f32c(v_bias.detach())
     hd = head_dim_of(qkv_w, H)
-    if hd != 64:
-        # Head dims without a 16-bit attention kernel (80: the "huge" configurations, modeling_finetune.py:390-398): the Linears stay on
-        # the 16-bit MFMA GEMMs, the scaled-dot-product core runs through the exact-f32 MFMA kernels (csrc/attn_f32.hip) on an f32 qkv.
-        # (Attention dropout, attn_drop > 0 in training, :99-101, runs inside the 16-bit kernels since round 4.)
+    if hd not in (64, 80):
+        raise TadError(f"attention: head_dim {hd} has no kernel (64 and 80 do)")
+    if hd == 80 and _attn_hd80_f32:
+        # The round-3 route for the "huge" configurations (head_dim 80, modeling_finetune.py:390-398), kept for A/B runs
+        # (set_attn_hd80_f32): the Linears stay on the 16-bit MFMA GEMMs, the scaled-dot-product core runs through the exact-f32 MFMA
+        # kernels (csrc/attn_f32.hip) on an f32 qkv.  Since round 4 head_dim 80 has 16-bit kernels of its own (the branch below).
         qkv = K.linear_fwd_qkv(xn, w_bf16(qkv_w, train), qb, vb, out_dtype=torch.float32)
         ao32, lse = K.attn_fwd_f32(qkv, B, N, H, scale, want_lse=train, d=hd, drop_p=drop[0], seed=drop[1])
         return qkv, K.cast_bf16(ao32), (lse, None)
@@ -411,7 +422,7 @@ def _attn_fwd_core(xn, qkv_w, q_bias, v_bias, B, N, H, scale, train, drop=(0.0, 
     # the plain q; only tad_attn_fwd / tad_attn_bwd read it)
     qkv = K.linear_fwd_qkv(xn, w_bf16(qkv_w, train), qb, vb, out_dtype=None, q_prescale=K.q_prescale_of(scale) if _attn_q_prescale else 1.0)
     r = K.attn_fwd(qkv, B, N, H, scale, out_dtype=None, want_lse=train, want_lo=train and _attn_exact_delta, q_prescaled=_attn_q_prescale,
-                   drop_p=drop[0], seed=drop[1])
+                   drop_p=drop[0], seed=drop[1], d=hd)
     return qkv, r[0], (r[1], r[2] if len(r) > 2 else None)
 
 
@@ -422,7 +433,8 @@ def _attn_bwd_core(d_ao, xn, qkv, ao, lse, qkv_w, has_qkv_bias, B, N, H, scale, 
         dqkv = K.cast_bf16(K.attn_bwd_f32(qkv, ao.float(), d_ao.float(), lse, B, N, H, scale, d=head_dim_of(qkv_w, H), drop_p=drop[0],
                                           seed=drop[1]))
     else:
-        dqkv = K.attn_bwd(qkv, ao, d_ao, lse, B, N, H, scale, out_lo=ao_lo, q_prescaled=_attn_q_prescale, drop_p=drop[0], seed=drop[1])
+        dqkv = K.attn_bwd(qkv, ao, d_ao, lse, B, N, H, scale, out_lo=ao_lo, q_prescaled=_attn_q_prescale, drop_p=drop[0], seed=drop[1],
+                          d=head_dim_of(qkv_w, H))
     dxn = K.linear_bwd_input(dqkv, wT_bf16(qkv_w, True), out_dtype=dx_dtype)
     if has_qkv_bias and qv_params is not None:
         ents = [_sink(qkv_w), _sink(qv_params[0]), _sink(qv_params[1])]

@@ -236,6 +236,9 @@ def test_attention_fwd_bwd(K, B, N, H, prescaled):
     assert (lse.cpu().double() - torch.logsumexp(s, -1)).abs().max().item() < (1e-3 if N >= 64 else 2e-3)
     out16, _ = K.attn_fwd(qd, B, N, H, scale, out_dtype=torch.bfloat16, **kw)
     check(out16.float().reshape(B, N, -1), ref, tol=BF16_ULP, what="attn fwd bf16")
+    # out_lo (both outputs leave through the same per-wave LDS patch, back to back): bit-exactly what the rounding of out dropped
+    o16, _, lo = K.attn_fwd(qd, B, N, H, scale, want_lo=True, **kw)
+    assert torch.equal(o16, out16) and torch.equal(lo.float(), (out32 - out16.float()).to(torch.bfloat16).float())
     dqkv = K.attn_bwd(qd, out16, dev(dout).to(torch.bfloat16), lse, B, N, H, scale, **kw)
     g = dqkv.float().cpu().reshape(B, N, 3, H, 64)
     r = ref_dqkv.reshape(B, N, 3, H, 64)
@@ -275,6 +278,50 @@ def test_attention_softmax_spike(K, prescaled):
     q4d = qkv.double().reshape(B, N, 3, H, 64)
     s = torch.einsum("bnhd,bmhd->bhnm", q4d[:, :, 0], q4d[:, :, 1]) * scale
     assert (lse.cpu().double() - torch.logsumexp(s, -1)).abs().max().item() < 5e-3  # (|lse| reaches ~100 here)
+
+
+@pytest.mark.parametrize("fmt", ["bf16", "f16"])
+@pytest.mark.parametrize("prescaled", [True, False], ids=["q_prescaled", "plain_q"])
+@pytest.mark.parametrize("B,N,H,p", [(2, 100, 2, 0.0), (1, 1568, 2, 0.0), (2, 8, 3, 0.0), (1, 129, 1, 0.0), (1, 393, 3, 0.0), (2, 200, 2, 0.25)])
+def test_attention_head_dim_80_fwd_bwd(K, B, N, H, p, prescaled, fmt):
+    """head_dim 80 (vit_huge: embed_dim 1280 / 16 heads, modeling_finetune.py:390-398) in the 16-bit MFMA attention kernels (round 4:
+    dims 0..63 in the head_dim-64 LDS images, dims 64..79 in 32-byte-row side images, a fifth k-step and a third d tile): forward,
+    lse and backward against the oracle, ragged N, both operand formats and q contracts, with and without attention dropout (the
+    oracle regenerates the keep mask).  Tolerances are those of the head_dim-64 tests."""
+    d, seed = 80, 424242
+    scale = d ** -0.5
+    dt = torch.bfloat16 if fmt == "bf16" else torch.float16
+    rnd = lambda t: t.to(dt).float()  # noqa: E731
+    qkv = rnd(R.tensor_for(f"att80.qkv{N}", (B * N, 3 * H * d), scale=1.0))
+    dout = rnd(R.tensor_for(f"att80.do{N}", (B * N, H * d)))
+    opnd = qkv
+    if prescaled:
+        opnd, qkv = prescaled_pair(qkv, B, N, H, scale, rnd, d=d)
+    qd = qkv.double().reshape(B, N, -1).requires_grad_()
+    ref = O.attention_core(qd, H, scale, drop_p=p, seed=seed) if p else O.attention_core(qd, H, scale)
+    ref.backward(dout.double().reshape(B, N, -1))
+    kw = dict(q_prescaled=prescaled, drop_p=p, seed=seed, d=d)
+    x = dev(opnd).to(dt)
+    out32, lse = K.attn_fwd(x, B, N, H, scale, out_dtype=torch.float32, **kw)
+    assert out32.shape == (B * N, H * d)
+    tol, tol_max = (ATT_TOL, ATT_TOL_MAX) if fmt == "bf16" else (6e-4, 1.2e-3)
+    check(out32.reshape(B, N, -1), ref.detach(), tol=tol, tol_max=tol_max, what="attn80 fwd f32")
+    q4 = qkv.double().reshape(B, N, 3, H, d)
+    sc = torch.einsum("bnhd,bmhd->bhnm", q4[:, :, 0], q4[:, :, 1]) * scale
+    assert (lse.cpu().double() - torch.logsumexp(sc, -1)).abs().max().item() < (1e-3 if N >= 64 else 2e-3)
+    out16, lse, lo = K.attn_fwd(x, B, N, H, scale, want_lo=True, **kw)
+    ulp = BF16_ULP if fmt == "bf16" else 2 * tol
+    check(out16.float().reshape(B, N, -1), ref.detach(), tol=ulp, what="attn80 fwd 16-bit")
+    # out_lo is exactly what the rounding dropped (bit-exact against the f32 output of the same kernel family)
+    assert torch.equal(lo.float(), (out32 - out16.float()).to(dt).float())
+    dqkv = K.attn_bwd(x, out16, dev(dout).to(dt), lse, B, N, H, scale, out_lo=lo, **kw)
+    g, r = dqkv.float().cpu().reshape(B, N, 3, H, d), qd.grad.reshape(B, N, 3, H, d)
+    for i, nm in enumerate("qkv"):
+        check(g[:, :, i], r[:, :, i], tol=2 * ulp, what=f"attn80 d{nm}")
+    # without out_lo (delta from the rounded output) the gradients stay inside the same band
+    dqkv2 = K.attn_bwd(x, out16, dev(dout).to(dt), lse, B, N, H, scale, **kw)
+    for i, nm in enumerate("qkv"):
+        check(dqkv2.float().cpu().reshape(B, N, 3, H, d)[:, :, i], r[:, :, i], tol=3 * ulp, what=f"attn80 d{nm} (rounded-output delta)")
 
 
 # ------------------------------------------------------------------ helpers

@@ -34,7 +34,8 @@ def _model(embed_dim, heads, depth=2, **kw):
 
 @pytest.mark.parametrize("D,H", [(384, 6), (1024, 16), (1280, 20), (1280, 16)])
 def test_other_widths_forward_backward(D, H):
-    """(1280, 16) is the "huge" geometry (modeling_finetune.py:390-398): head_dim 80, attention through the generic f32 kernels"""
+    """(1280, 16) is the "huge" geometry (modeling_finetune.py:390-398): head_dim 80, since round 4 through 16-bit MFMA attention
+    kernels of its own (the f32-kernel route of round 3 stays reachable for A/B: ops.set_attn_hd80_f32)"""
     m = _model(D, H).cuda().train()
     x = torch.randn(3, 3, 4, 32, 32)
     y = torch.tensor([0, 1, 1])
@@ -48,6 +49,17 @@ def test_other_widths_forward_backward(D, H):
     for k in ("blocks.0.attn.qkv.weight", "blocks.1.mlp.fc2.weight", "patch_embed.proj.weight", "blocks.0.attn.q_bias", "fc_norm.weight"):
         got = dict(m.named_parameters())[k].grad
         assert rell2(got, P[k].grad) < 4e-2, (k, rell2(got, P[k].grad))
+    if D // H == 80:  # the round-3 route (exact-f32 attention core between the 16-bit Linears) agrees within the 16-bit band
+        from simple_tad_amd import ops
+        ops.set_attn_hd80_f32(True)
+        try:
+            m.zero_grad()
+            l2 = m(x.cuda())
+            F.cross_entropy(l2, y.cuda()).backward()
+        finally:
+            ops.set_attn_hd80_f32(False)
+        assert rell2(l2, ref) < 1e-2 and rell2(l2, logits) < 1e-2
+        assert rell2(dict(m.named_parameters())["blocks.0.attn.qkv.weight"].grad, P["blocks.0.attn.qkv.weight"].grad) < 4e-2
 
 
 @pytest.mark.parametrize("precise", [False, True])
