@@ -104,6 +104,11 @@ __device__ __forceinline__ void stage_tile(const void* gbase, int gbytes, char* 
                          // other workgroups of the XCD are re-reading; measured 691.3 -> 695.8 clips/s over four alternating pairs of runs; 0 = default,
                          // 16 = sc1 measured neutral)
 #endif
+#ifndef TAD_EPI_DB
+#define TAD_EPI_DB 0  // 1: double-buffered transposition chunks in the persistent 256 x 256 kernel's LDS epilogues (see EPI_DB).  Measured null in
+                      // round 4 (tools/ab_gemm.py, eight in-model shapes: sum 1537.0 vs 1534.8 us; fc1 -3, dX(fc2) +3.5): the epilogue is bound by its
+                      // vector work (GELU polynomials, conversions), not by the chunk barriers -- off
+#endif
 #ifndef TAD_NT_PEEL
 #define TAD_NT_PEEL 1  // last K-tile of the persistent bias-only 16-bit kernel peeled (see PEEL in gemm_nt_kernel); 0 = the round-1 schedule
 #endif
@@ -160,9 +165,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
   static_assert(BM % (RPP * NW) == 0 && BN % (RPP * NW) == 0, "tile rows must split into whole DMA pieces per wave");
   // one epilogue chunk: CROWS rows of f32, padded stride.  The persistent kernel keeps ring slot 0 out of the epilogue's way
   // (the next tile's first K-tile lands there meanwhile), so its chunks must fit the LDS behind slot 0.
-  constexpr int CROWS = BM < 128 ? BM : (((BN > 128 || (NW == 4 && BM == 256)) && IS_RES && !OUT_BF16) ? 32 : (((PERSIST && BN > 128) || NW == 4) ? 64 : 128));
+  // EPI_DB (persistent 256 x 256 kernel): TWO chunk buffers of 32 rows, the accumulators of chunk q + 1 are dropped into one while the row
+  // pass of chunk q reads the other -- one barrier per chunk instead of two, and the LDS writes run beside the row pass
+  constexpr bool EPI_DB = TAD_EPI_DB && PERSIST && !DIRECT && !SPLITK && BM == 256 && BN == 256 && NW == 8;
+  constexpr int CROWS = EPI_DB ? 32 : BM < 128 ? BM : (((BN > 128 || (NW == 4 && BM == 256)) && IS_RES && !OUT_BF16) ? 32 : (((PERSIST && BN > 128) || NW == 4) ? 64 : 128));
   constexpr int EPI_OFF = PERSIST ? STAGE_BYTES : 0;
-  constexpr int EPI_BYTES = DIRECT ? 0 : CROWS * (BN * 4 + 16);
+  constexpr int EPI_BYTES = DIRECT ? 0 : (EPI_DB ? 2 : 1) * CROWS * (BN * 4 + 16);
   constexpr int LDS_BYTES = STAGES * STAGE_BYTES > EPI_OFF + EPI_BYTES ? STAGES * STAGE_BYTES : EPI_OFF + EPI_BYTES;
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
   __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
@@ -763,21 +771,29 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
   float gam[CPL];
 #pragma unroll
   for (int e = 0; e < CPL; ++e) gam[e] = (IS_RES && p.gamma && nvalid && (e < 4 || full)) ? p.gamma[n + e] : 1.f;
+  // (1) every wave drops its MREP_C x NREP fragments of chunk qq into chunk buffer qq & 1 (EPI_DB) / the one buffer
+#define DROP_CHUNK(qq)                                                                                                       \
+  _Pragma("unroll") for (int ii = 0; ii < MREP_C; ++ii) {                                                                    \
+    const int lr = wm * (16 * MREP_C) + ii * 16 + c;                                                                         \
+    _Pragma("unroll") for (int j = 0; j < NREP; ++j) {                                                                       \
+      const int cc = wn * WTN + (OUT_BF16 ? (32 * (j >> 1) + 8 * kq + 4 * (j & 1)) : (16 * j + 4 * kq));                     \
+      *reinterpret_cast<f32x4*>(epi_lds + (EPI_DB ? ((qq) & 1) * CROWS * CSTRIDE : 0) + lr * CSTRIDE + cc * 4) = acc[(qq) * MREP_C + ii][j]; \
+    }                                                                                                                        \
+  }
+  if (EPI_DB) {
+    DROP_CHUNK(0);
+    lds_barrier();
+  }
 #pragma unroll
   for (int q = 0; q < NCHUNK; ++q) {
-    // (1) every wave drops its MREP_C x NREP fragments of this chunk
-#pragma unroll
-    for (int ii = 0; ii < MREP_C; ++ii) {
-      const int lr = wm * (16 * MREP_C) + ii * 16 + c;
-#pragma unroll
-      for (int j = 0; j < NREP; ++j) {
-        const int cc = wn * WTN + (OUT_BF16 ? (32 * (j >> 1) + 8 * kq + 4 * (j & 1)) : (16 * j + 4 * kq));
-        *reinterpret_cast<f32x4*>(epi_lds + lr * CSTRIDE + cc * 4) = acc[q * MREP_C + ii][j];
-      }
+    if (!EPI_DB) {
+      DROP_CHUNK(q);
+      lds_barrier();
     }
-    lds_barrier();
-    STAMP(4 + 2 * q);
+    if (q < 6) { STAMP(4 + 2 * q); }
     if (q + 1 < NCHUNK) { ISSUE_EXTRA(q + 1, (q + 1) & 1); }
+    if (EPI_DB && q + 1 < NCHUNK) { DROP_CHUNK(q + 1); }  // (its barrier is the one that ends this chunk)
+    const char* const epi_rd = epi_lds + (EPI_DB ? (q & 1) * CROWS * CSTRIDE : 0);
     // (2) row-contiguous pass: local row lr <-> tile row (lr / (16*MREP_C))*WTM + 16*MREP_C*q + lr % (16*MREP_C)
 #pragma unroll
     for (int r0 = 0; r0 < NR; r0 += BATCH) {
@@ -790,7 +806,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
         off[b] = nvalid ? (uint32_t)m * (uint32_t)p.N + (uint32_t)n : OOB;
 #pragma unroll
         for (int e4 = 0; e4 < CPL / 4; ++e4) {
-          const f32x4 t = *reinterpret_cast<const f32x4*>(epi_lds + lr * CSTRIDE + col * 4 + 16 * e4);
+          const f32x4 t = *reinterpret_cast<const f32x4*>(epi_rd + lr * CSTRIDE + col * 4 + 16 * e4);
           v[b][4 * e4 + 0] = t[0]; v[b][4 * e4 + 1] = t[1]; v[b][4 * e4 + 2] = t[2]; v[b][4 * e4 + 3] = t[3];
         }
       }
@@ -855,9 +871,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
         }
       }
     }
-    STAMP(5 + 2 * q);
+    if (q < 6) { STAMP(5 + 2 * q); }
     if (q + 1 < NCHUNK) lds_barrier();
   }
+#undef DROP_CHUNK
   }  // epilogue
   STAMP(2);
 #ifdef TAD_GEMM_ABLATION

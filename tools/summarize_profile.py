@@ -63,6 +63,26 @@ def main():
                 d["calls"] += 1
                 d["total_ns"] += float(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
                 total += float(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            # Idle time of the device between kernels over the timed steps: span of the dispatches minus the union of their intervals, and
+            # which kernel the gaps sit in front of (a gap = the device has nothing running: launch latency, host-side bubbles, dependent-
+            # dispatch drain)
+            ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])) for r in csv.DictReader(open(tf[0])))
+            ev = ev[len(ev) * a.warmup // a.steps:]
+            if ev:
+                gaps = collections.defaultdict(lambda: [0, 0.0])
+                busy_end, idle = ev[0][1], 0.0
+                for s0, e0, k in ev[1:]:
+                    if s0 > busy_end:
+                        idle += s0 - busy_end
+                        gaps[k][0] += 1
+                        gaps[k][1] += s0 - busy_end
+                    busy_end = max(busy_end, e0)
+                nst = a.steps - a.warmup
+                span = ev[-1][1] - ev[0][0]
+                summary["timeline_timed_steps"] = {
+                    "span_ms_per_step": span / 1e6 / nst, "idle_ms_per_step": idle / 1e6 / nst, "dispatches_per_step": len(ev) / nst,
+                    "gaps_in_front_of": {k: {"per_step": v[0] / nst, "ms_per_step": v[1] / 1e6 / nst, "avg_us": v[1] / v[0] / 1e3}
+                                         for k, v in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:8]}}
         else:
             f = glob.glob(os.path.join(a.kt, "*", "*kernel_stats.csv"))[0]
             for r in csv.DictReader(open(f)):
@@ -117,7 +137,7 @@ def main():
         summary["gemm_nt_traffic_bytes_per_launch"] = fb + wb
         summary["gemm_nt_traffic_note"] = "FETCH_SIZE KiB x1024 x2 (gfx950 half-count correction) + WRITE_SIZE KiB x1024, averaged over all gemm_nt launches of bench.py"
     json.dump(summary, open(os.path.join(a.out, f"{a.round}_summary.json"), "w"), indent=1)
-    print(json.dumps({k: v for k, v in summary.items() if k.startswith("gemm_nt")}, indent=1))
+    print(json.dumps({k: v for k, v in summary.items() if k.startswith("gemm_nt") or k.startswith("timeline")}, indent=1))
 
 
 if __name__ == "__main__":
