@@ -1350,7 +1350,13 @@ int launch_gemm_nt(const GemmNT& p_in, hipStream_t st, void* ws = nullptr, size_
 }
 
 // TN: 1 = 256x256 (2x4) 2 stages; 3 = 256x128 (4x2) 3 stages.  Splits over the reduction dim target ~1 workgroup per CU.
-static int tn_variant() { return knobs::tn_variant ? knobs::tn_variant : 1; }
+// TAD_GEMM_TN_VARIANT forces one; by default the 128-wide tile serves shapes whose K the 256-wide one would pad by a third or more
+// (K = 384 = 1.5 tiles: ViT-S -- the weight gradients of its qkv / proj / fc1 Linears computed 2 x 256 columns for 384)
+static int tn_variant(int K = 0) {
+  if (knobs::tn_variant) return knobs::tn_variant;
+  const int pad256 = (K + 255) / 256 * 256, pad128 = (K + 127) / 128 * 128;
+  return (K > 0 && pad256 * 3 >= pad128 * 4) ? 3 : 1;
+}
 static int cu_count() {
   static const int n = [] {
     int dev = 0, v = 0;
@@ -1363,7 +1369,7 @@ static int cu_count() {
 // cu_count() + 1 costs two full rounds.  Pick the split count that minimises rounds x (reduction tiles per split + epilogue)
 // plus the slab-reduce pass, all in units of one reduction tile (~2 us on MI355X).
 static int tn_plan(int64_t Mr, int N, int K, int* splits, int* rows_per_split) {
-  const int bn = tn_variant() != 3 ? 256 : 128;
+  const int bn = tn_variant(K) != 3 ? 256 : 128;
   const int tiles = ((N + 255) / 256) * ((K + bn - 1) / bn);
   const int64_t ktiles = (Mr + BK - 1) / BK;
   const int cus = cu_count();
@@ -1388,7 +1394,7 @@ static int tn_plan(int64_t Mr, int N, int K, int* splits, int* rows_per_split) {
 size_t gemm_tn_workspace_bytes(int64_t Mr, int N, int K) {
   int s, r;
   tn_plan(Mr, N, K, &s, &r);
-  const int bn = tn_variant() != 3 ? 256 : 128;
+  const int bn = tn_variant(K) != 3 ? 256 : 128;
   return (size_t)s * ((size_t)N * (size_t)K + (size_t)((K + bn - 1) / bn) * (size_t)N) * sizeof(float);
 }
 
@@ -1404,10 +1410,10 @@ int launch_gemm_tn(const uint16_t* P, const uint16_t* Q, float* out, float* bias
   p.debug = gemm_debug;
   int splits;
   const int tiles = tn_plan(Mr, N, K, &splits, &p.rows_per_split);
-  const int tiles_k = (K + (tn_variant() != 3 ? 256 : 128) - 1) / (tn_variant() != 3 ? 256 : 128);
+  const int tiles_k = (K + (tn_variant(K) != 3 ? 256 : 128) - 1) / (tn_variant(K) != 3 ? 256 : 128);
   if (ws_bytes < (size_t)splits * ((size_t)N * K + (size_t)tiles_k * N) * sizeof(float)) { set_error("gemm_tn: workspace too small"); return TAD_ENOSPACE; }
   p.bias_slab = bias_out ? p.slab + (size_t)splits * N * K : nullptr;
-  if (tn_variant() == 1)
+  if (tn_variant(K) == 1)
     hipLaunchKernelGGL((gemm_tn_kernel<256, 256, 2, 4, 2>), dim3(tiles * splits), dim3(512), 0, st, p);
   else
     hipLaunchKernelGGL((gemm_tn_kernel<256, 128, 4, 2, 3>), dim3(tiles * splits), dim3(512), 0, st, p);
