@@ -317,6 +317,9 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_bwd_dq_kernel(cons
 #undef DMA_KV
 
 // ------------------------------------------------------------------------------------------------ dK, dV
+#ifndef TAD_DKV_ABL
+#define TAD_DKV_ABL 0  // timing experiments (experiments/README.md, round 4): 1 = a quarter of the row-constant LDS reads
+#endif
 template <int HD, bool QS, bool DROP, int DMA_MODE>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
                                                            const float* __restrict__ rowc_g, uint16_t* __restrict__ dqkv, int N, int H, int B,
@@ -458,8 +461,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
       op16x8 qa[NKS], da[NKS];
       static_for<0, 4>([&](auto r4c) {
         constexpr int r4 = decltype(r4c)::value;
-        si[r4] = lds_read_b128<f32x4, SO + (qt * 32 + 8 * r4) * 4>(rca);
-        di[r4] = lds_read_b128<f32x4, SO + 256 + (qt * 32 + 8 * r4) * 4>(rca);
+        if constexpr (!(TAD_DKV_ABL & 1) || r4 == 0) {
+          si[r4] = lds_read_b128<f32x4, SO + (qt * 32 + 8 * r4) * 4>(rca);
+          di[r4] = lds_read_b128<f32x4, SO + 256 + (qt * 32 + 8 * r4) * 4>(rca);
+        } else {  // (timing experiment: one quarter of the row-constant reads, values wrong)
+          si[r4] = si[0];
+          di[r4] = di[0];
+        }
       });
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
