@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256, TAD_FWD_ROWSUM_VALU ? 4 : 1) void attn_fwd_ker
   //
   // Round 4 tried to take the offset subtraction out of the vector pipe as well (accumulators started from a per-wave LDS table of
   // -m; or offset 0 with a separately compiled general body): 32 of ~110 vector instructions per tile less, and the kernel 1.4 %
-  // faster -- it is not bound by vector issue -- while every variant with two definitions of the score or
+  // faster -- it is not bound by vector issue (experiments/README.md r04) -- while every variant with two definitions of the score or
   // output registers cost 24-56 VGPRs (a wave per SIMD).  One body, one v_sub per score.
   const int nt = (N + KV_TILE - 1) / KV_TILE;
   const uint32_t drop_row = (uint32_t)((b * H + head) * N + min(q0 + ql, N - 1));  // (DROP) the lane's row of the keep mask

@@ -16,7 +16,7 @@
 // second launch for the remaining rows -- from a small cost model.  Epilogue (bias / GELU / residual / layer-scale /
 // drop-path scale / GELU-backward): accumulators transposed through the LDS so that global accesses cover whole rows,
 // raw buffer loads / stores without per-lane branches, what it reads fetched one chunk ahead; bias-only bf16 outputs are
-// stored straight from the MFMA layout instead.  DESIGN.md section 3.1 has the measurements behind each choice.
+// stored straight from the MFMA layout instead.  DESIGN.md section 3 and docs/DESIGN_HISTORY.md section 3.1 have the measurements behind each choice.
 #include <math.h>
 #include <stdlib.h>
 #include <string>

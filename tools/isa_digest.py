@@ -2,7 +2,7 @@
 """Compile one csrc/*.hip file to gfx950 assembly with the library's flags and print, per kernel, the register budget and a compact
 run-length digest of the instructions that decide whether a tile loop is pipelined: LDS-DMA issues, LDS reads, MFMAs, waits, barriers,
 ordinary global loads and scratch traffic.  This is how the compiler-inserted `s_waitcnt vmcnt(0)` in front of builtin transposed LDS
-reads, the per-row global load in the residual epilogue and the spill reloads inside K loops were found.
+reads, the per-row global load in the residual epilogue and the spill reloads inside K loops were found (docs/DESIGN_HISTORY.md 3.2 / 3.4).
 
     python tools/isa_digest.py attn_bwd [--kernel dkv] [--width 160]
     python tools/isa_digest.py gemm --kernel "gemm_nt_kernelILi256ELi256ELi2ELi4ELi2ELi64ELi1ELi2ELb0ELb1ELb0ELb0E"
