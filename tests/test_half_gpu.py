@@ -287,6 +287,42 @@ def test_half_mode_training_step_follows_the_oracle_with_loss_scaling():
     assert res["half"][1] < res["fast"][1]
 
 
+def test_head_dim_80_model_in_half_mode_follows_the_oracle_and_its_dropout_is_reproducible():
+    """The "huge" geometry (head_dim 80, modeling_finetune.py:390-398) through the f16 twins of the 16-bit attention kernels: loss and
+    gradients of a small model against the fp64 oracle inside the half-mode band, and attn_drop > 0 (same kernels, keep mask from the
+    torch RNG seed) reproducible in training and absent in eval."""
+    import simple_tad_amd as T
+    import torch.nn.functional as F
+    cfg = dict(img_size=32, patch_size=16, embed_dim=320, depth=2, num_heads=4, mlp_ratio=4, qkv_bias=True, all_frames=4, tubelet_size=2,
+               num_classes=2, init_scale=1.0)
+    torch.manual_seed(3)
+    m = T.VisionTransformer(**cfg).cuda().train()
+    assert m.blocks[0].attn.head_dim == 80
+    x, y = torch.randn(3, 3, 4, 32, 32), torch.tensor([1, 0, 1])
+    P = {k: v.detach().double().cpu().requires_grad_() for k, v in m.state_dict().items()}
+    ref = F.cross_entropy(O.forward(x.double(), P, depth=2, num_heads=4, tubelet=2, patch=16, eps=m.blocks[0].norm1.eps), y)
+    ref.backward()
+    T.set_precision("half")
+    try:
+        loss = F.cross_entropy(m(x.cuda()), y.cuda())
+        loss.backward()
+        rel = lambda a, b: float((a.double().cpu() - b).norm() / b.norm())  # noqa: E731
+        assert abs(loss.item() - ref.item()) < 3e-4
+        for k in ("blocks.0.attn.qkv.weight", "blocks.1.attn.proj.weight", "blocks.0.attn.q_bias", "blocks.0.mlp.fc1.weight"):
+            assert rel(dict(m.named_parameters())[k].grad, P[k].grad) < 5e-3, k
+        md = T.VisionTransformer(attn_drop_rate=0.2, **cfg).cuda().train()
+        md.load_state_dict(m.state_dict())
+        torch.manual_seed(11); a = md(x.cuda())
+        torch.manual_seed(11); b = md(x.cuda())
+        torch.manual_seed(12); c = md(x.cuda())
+        assert torch.equal(a, b) and not torch.equal(a, c) and bool(torch.isfinite(a).all())
+        md.eval(); m.eval()
+        with torch.no_grad():
+            assert torch.equal(md(x.cuda()), m(x.cuda()))
+    finally:
+        T.set_precision("fast")
+
+
 def test_overflowed_step_is_skipped_on_the_device_and_settled_one_call_later():
     """GradScaler's rules without its host sync: a loss scale that overflows half makes the gradients inf, the fused AdamW kernel skips
     the update by itself (grad_scale 0), and the NEXT call halves the scale and takes the optimizer's step count back before anything
