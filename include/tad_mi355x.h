@@ -152,7 +152,9 @@ int tad_linear_bwd_weight_qkv(const uint16_t* dy, const uint16_t* x, float* dW, 
  *   "split_tail"      1 = a Linear whose 256 x 256 tiles do not fill whole rounds of one workgroup per CU may run as two
  *                     launches (whole rounds + remaining rows) when the cost model says so (default); 0 = never; 2 = always
  *   "splitk_tail"     1 = with a workspace, the second of those launches may split its tiles along K (default); 0 = never;
- *                     2 = whenever eligible (this one changes the summation order over K of the rows it covers) */
+ *                     2 = whenever eligible (this one changes the summation order over K of the rows it covers)
+ *   "tn_pdeep"        1 = the weight-gradient GEMM requests its dy operand two reduction tiles ahead (three-slot ring, the whole
+ *                     160 KiB of LDS); 0 = two-stage ring (default: measured equal) */
 int tad_linear_tuning(const char* key, int value);
 /* Number of gemm_nt kernel launches issued so far by tad_linear_fwd* / tad_linear_bwd_input / tad_patch_embed_* (a call is one
  * launch, or two when the split-tail plan is taken): lets a profiler attribute event time to kernel launches. */

@@ -907,8 +907,15 @@ __device__ __forceinline__ int sw_tn(int row) { return ((row & 3) | ((row >> 1) 
 // Transposed 16x16x32 fragments from a [64 reduction rows][row bytes] tile: lane (g = lane>>4, li = lane&15) supplies rows
 // 32ks + 8g + (li>>2) (+4 for the second read), columns col0 + 4*(li&3); it receives column col0 + li, reduction rows 32ks + 8g + 0..7.
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
+// PDEEP (the 256 x 256 two-stage configuration): the P and Q halves of a stage live in rings of their own, THREE slots for P and two
+// for Q (3 x 32 + 2 x 32 KiB = the whole 160 KiB of LDS), and the P half is requested TWO reduction tiles ahead.  The loop is bound by
+// the round trip of a stage's DMA, not by its bytes (staging and barriers alone take 75 % of the kernel's time, docs/DESIGN_HISTORY.md
+// section 8): with 96 instead of 64 KiB in flight per CU a first-touch miss has half a tile longer to arrive.  Measured (round 4,
+// tools/exp_tn_pdeep.py): bit-identical and NOT faster (four dW shapes 716.4 vs 717.6 us) -- the staging is bound by its rate through
+// the DMA path (~37 GB/s per CU), not by latency; kept behind tad_linear_tuning("tn_pdeep"), off.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool PDEEP = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(const GemmTN p) {
+  static_assert(!PDEEP || STAGES == 2, "PDEEP extends the two-stage ring");
   constexpr int BKT = BK;
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
@@ -922,7 +929,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(const Ge
   static_assert(P_BYTES % (1024 * NW) == 0 && Q_BYTES % (1024 * NW) == 0, "tile must split into 1-KiB DMA pieces per wave");
   static_assert(P_LPR <= 64 && Q_LPR <= 64 && PROW >= 256 && QROW >= 256, "row length");
   constexpr int LOADS = P_PIECES + Q_PIECES;
-  __shared__ __attribute__((aligned(1024))) char lds[STAGES * STAGE_BYTES];
+  constexpr int LDS_BYTES_TN = PDEEP ? 3 * P_BYTES + 2 * Q_BYTES : STAGES * STAGE_BYTES;
+  static_assert(LDS_BYTES_TN <= 160 * 1024, "LDS budget");
+  __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES_TN];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -967,6 +976,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(const Ge
 #define STAGE_TN(buf, t) \
   stage_tile<P_PIECES, NW>(p.P, p_bytes, lds + (buf) * STAGE_BYTES, p_off, (uint32_t)(t) * BKT * (uint32_t)(p.N * 2), wave); \
   stage_tile<Q_PIECES, NW>(p.Q, q_bytes, lds + (buf) * STAGE_BYTES + P_BYTES, q_off, (uint32_t)(t) * BKT * (uint32_t)(p.K * 2), wave)
+  // PDEEP: P ring = slots 0..2 at the bottom of the LDS, Q ring = slots 0..1 behind it
+#define STAGE_P(slot, t) stage_tile<P_PIECES, NW>(p.P, p_bytes, lds + (slot) * P_BYTES, p_off, (uint32_t)(t) * BKT * (uint32_t)(p.N * 2), wave)
+#define STAGE_Q(slot, t) stage_tile<Q_PIECES, NW>(p.Q, q_bytes, lds + 3 * P_BYTES + (slot) * Q_BYTES, q_off, (uint32_t)(t) * BKT * (uint32_t)(p.K * 2), wave)
 
   // transposed fragment reads: 16-lane group g = lane>>4 covers reduction rows 8g..8g+7 of a 32-deep k-step;
   // lane i = lane&15 of the group supplies row (i>>2) (+4 for the second read), columns c0 + 4*(i&3) .. +3
@@ -1011,29 +1023,50 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(const Ge
   }
   const uint32_t lds0 = lds_addr(lds);
 
+  if (PDEEP) {
+    if (0 < nt) { STAGE_P(0, 0); STAGE_Q(0, 0); }
+    if (1 < nt) { STAGE_P(1, 1); }
+  } else {
 #pragma unroll
-  for (int st = 0; st < STAGES - 1; ++st)
-    if (st < nt) { STAGE_TN(st, st); }
+    for (int st = 0; st < STAGES - 1; ++st)
+      if (st < nt) { STAGE_TN(st, st); }
+  }
   int rd = 0, wr = STAGES - 1;
+  int p_rdslot = 0, q_rdslot = 0;  // (PDEEP) ring slots of reduction tile t
   for (int t = 0; t < nt; ++t) {
-    wait_stage<LOADS>(min(STAGES - 2, nt - 1 - t));
+    if (PDEEP) {
+      // outstanding, oldest first: P(t), Q(t), P(t+1) -- the first two have to be there, the pieces of P(t+1) may still be in flight
+      if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P_PIECES) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      wait_stage<LOADS>(min(STAGES - 2, nt - 1 - t));
+    }
     block_barrier();
     const uint32_t st_addr = lds0 + (uint32_t)(rd * STAGE_BYTES);
-    const bool more = t + STAGES - 1 < nt;
+    const uint32_t p_addr = PDEEP ? lds0 + (uint32_t)(p_rdslot * P_BYTES) : st_addr;
+    const uint32_t q_addr = PDEEP ? lds0 + (uint32_t)(3 * P_BYTES + q_rdslot * Q_BYTES) : st_addr;
+    constexpr int QIMM = PDEEP ? 0 : P_BYTES;  // where the Q half starts relative to q_addr
+    const bool more = PDEEP ? (t + 1 < nt) : (t + STAGES - 1 < nt);
     const bool bias_now = bias_on && (t % tiles_k == tk_);
     const int wr_now = wr, t_next = t + STAGES - 1;
     rd = (rd + 1 == STAGES) ? 0 : rd + 1;
     wr = (wr + 1 == STAGES) ? 0 : wr + 1;
+    // (PDEEP) what this tile's DMA point issues: Q(t+1) into the slot Q(t-1) left, then P(t+2) into the slot P(t-1) left -- in that
+    // order, so that P(t+2) is the youngest when the next tile waits
+    const int q_wrslot = q_rdslot ^ 1, p_wrslot = (p_rdslot == 0) ? 2 : p_rdslot - 1;
+    const bool more_p = t + 2 < nt;
+    q_rdslot ^= 1;
+    p_rdslot = (p_rdslot == 2) ? 0 : p_rdslot + 1;
 #define KSTEP_TN(ks) \
   if (!(DBG_BITS(p) & 8)) {                                                                                   \
     s16x4 ql_[NREP], qh_[NREP], pl_[MREP], ph_[MREP];                                                         \
     _Pragma("unroll") for (int j = 0; j < NREP; ++j) {                                                        \
-      ql_[j] = lds_tr16_b64<P_BYTES + (ks) * 32 * QROW>(st_addr + q_rd[j]);                                   \
-      qh_[j] = lds_tr16_b64<P_BYTES + (ks) * 32 * QROW + 4 * QROW>(st_addr + q_rd[j]);                        \
+      ql_[j] = lds_tr16_b64<QIMM + (ks) * 32 * QROW>(q_addr + q_rd[j]);                                       \
+      qh_[j] = lds_tr16_b64<QIMM + (ks) * 32 * QROW + 4 * QROW>(q_addr + q_rd[j]);                            \
     }                                                                                                         \
     _Pragma("unroll") for (int i = 0; i < MREP; ++i) {                                                        \
-      pl_[i] = lds_tr16_b64<(ks) * 32 * PROW>(st_addr + p_rd[i]);                                             \
-      ph_[i] = lds_tr16_b64<(ks) * 32 * PROW + 4 * PROW>(st_addr + p_rd[i]);                                  \
+      pl_[i] = lds_tr16_b64<(ks) * 32 * PROW>(p_addr + p_rd[i]);                                              \
+      ph_[i] = lds_tr16_b64<(ks) * 32 * PROW + 4 * PROW>(p_addr + p_rd[i]);                                   \
     }                                                                                                         \
     /* the four column fragments (8 reads), then one row fragment (2 reads) at a time as its MFMAs come up */ \
     lds_wait<2 * MREP>(ql_[0], qh_[0], ql_[1], qh_[1], ql_[2], qh_[2], ql_[3], qh_[3]);                       \
@@ -1057,10 +1090,18 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(const Ge
     const bool late = wave >= NW / 2;  // stagger the DMA issue of the two waves that share a SIMD (see gemm_nt_kernel)
     const bool dma = more && !(DBG_BITS(p) & 1);
     static_assert(KSTEPS == 2, "two 32-deep k-steps per stage");
-    if (dma && !late) { STAGE_TN(wr_now, t_next); }
+#define ISSUE_TN()                                             \
+  if (PDEEP) {                                                   \
+    STAGE_Q(q_wrslot, t + 1);                                    \
+    if (more_p) { STAGE_P(p_wrslot, t + 2); }                    \
+  } else {                                                       \
+    STAGE_TN(wr_now, t_next);                                    \
+  }
+    if (dma && !late) { ISSUE_TN(); }
     KSTEP_TN(0);
-    if (dma && late) { STAGE_TN(wr_now, t_next); }
+    if (dma && late) { ISSUE_TN(); }
     KSTEP_TN(1);
+#undef ISSUE_TN
   }
 
   if (bias_on && li == 0) {
@@ -1110,10 +1151,11 @@ int nt_splitk = getenv("TAD_GEMM_SPLITK_TAIL") ? env_int("TAD_GEMM_SPLITK_TAIL")
 int nt_variant = env_int("TAD_GEMM_NT_VARIANT");  // 0 = planned per shape (launch_gemm_nt), else the tile configuration for every launch
 int nt_group_m_knob = getenv("TAD_GEMM_GROUP_M") ? env_int("TAD_GEMM_GROUP_M") : 0;  // 0 = per-shape choice (nt_group_m)
 int tn_variant = env_int("TAD_GEMM_TN_VARIANT");
+int tn_pdeep = env_int("TAD_GEMM_TN_PDEEP");  // 1: gemm_tn 256 x 256 with the P operand two reduction tiles ahead (see PDEEP); measured null (round 4), off
 unsigned long long* nt_stamps = nullptr;
 long long nt_launches = 0;  // gemm_nt kernel launches so far (tad_linear_kernel_launches)
 #else
-extern int gemm_debug, nt_persist, nt_direct, nt_split, nt_splitk, nt_variant, nt_group_m_knob, tn_variant;
+extern int gemm_debug, nt_persist, nt_direct, nt_split, nt_splitk, nt_variant, nt_group_m_knob, tn_variant, tn_pdeep;
 extern unsigned long long* nt_stamps;
 extern long long nt_launches;
 #endif
@@ -1413,7 +1455,9 @@ int launch_gemm_tn(const uint16_t* P, const uint16_t* Q, float* out, float* bias
   const int tiles_k = (K + (tn_variant(K) != 3 ? 256 : 128) - 1) / (tn_variant(K) != 3 ? 256 : 128);
   if (ws_bytes < (size_t)splits * ((size_t)N * K + (size_t)tiles_k * N) * sizeof(float)) { set_error("gemm_tn: workspace too small"); return TAD_ENOSPACE; }
   p.bias_slab = bias_out ? p.slab + (size_t)splits * N * K : nullptr;
-  if (tn_variant(K) == 1)
+  if (tn_variant(K) == 1 && knobs::tn_pdeep)
+    hipLaunchKernelGGL((gemm_tn_kernel<256, 256, 2, 4, 2, true>), dim3(tiles * splits), dim3(512), 0, st, p);
+  else if (tn_variant(K) == 1)
     hipLaunchKernelGGL((gemm_tn_kernel<256, 256, 2, 4, 2>), dim3(tiles * splits), dim3(512), 0, st, p);
   else
     hipLaunchKernelGGL((gemm_tn_kernel<256, 128, 4, 2, 3>), dim3(tiles * splits), dim3(512), 0, st, p);
@@ -1493,6 +1537,7 @@ int tad_linear_tuning(const char* key, int value) {
   else if (k == "debug") gemm_debug = value;  // ablation bits (timing experiments; ignored by production builds)
   else if (k == "group_m") { TAD_REQUIRE(value >= 0 && value <= 1024, "linear_tuning: group_m=%d out of range", value); nt_group_m_knob = value; }
   else if (k == "variant") { TAD_REQUIRE(value >= 0 && value <= 5, "linear_tuning: variant=%d not in 0..5", value); nt_variant = value; }
+  else if (k == "tn_pdeep") { TAD_REQUIRE(value == 0 || value == 1, "linear_tuning: tn_pdeep=%d not in {0, 1}", value); tn_pdeep = value; }
   else if (k == "split_tail") { TAD_REQUIRE(value >= 0 && value <= 2, "linear_tuning: split_tail=%d not in 0..2", value); nt_split = value; }
   else { set_error("linear_tuning: unknown key '%s'", key); return TAD_EINVAL; }
   return TAD_OK;
