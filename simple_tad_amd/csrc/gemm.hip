@@ -223,7 +223,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
     n0 = (in_grp / gsz) * BN;                              \
   }
 
-  const int a_bytes = (int)((int64_t)p.M * p.K * 2), b_bytes = (int)((int64_t)p.N * p.K * 2);
+  // (debug 128, timing only: A rows 128 bytes further apart than K elements -- the caller over-allocates A -- to see what the row stride costs)
+  const uint32_t lda_b = (uint32_t)(p.K * 2) + ((DBG_BITS(p) & 128) ? 128u : 0u);
+  const int a_bytes = (int)((int64_t)p.M * lda_b), b_bytes = (int)((int64_t)p.N * p.K * 2);
 
   // ---- DMA addressing: one wave-instruction fills RPP LDS rows (1 KiB); lane -> (row lane/CPR, physical chunk lane%CPR)
   const int drow = lane / CPR, dchunk = lane % CPR;
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
   {                                                                                                                    \
     _Pragma("unroll") for (int i = 0; i < BM / (RPP * NW); ++i) {                                                      \
       const int row = (i * NW + wave) * RPP + drow;                                                                    \
-      a_off[i] = (uint32_t)(m0 + row) * (uint32_t)(p.K * 2) + (uint32_t)((dchunk ^ sw_nt(row)) * 16);           \
+      a_off[i] = (uint32_t)(((DBG_BITS(p) & 64) ? 0 : m0) + row) * lda_b + (uint32_t)((dchunk ^ sw_nt(row)) * 16);  /* (debug 64, timing only: every tile reads the A rows of tile 0 -- A always L2-resident) */ \
     }                                                                                                                  \
     _Pragma("unroll") for (int i = 0; i < BN / (RPP * NW); ++i) {                                                      \
       const int row = (i * NW + wave) * RPP + drow;                                                                    \

@@ -51,7 +51,7 @@ def timed(fn, iters):
 
 total = {i: 0.0 for i in range(len(cfgs))}
 for name, n, k, mode in SHAPES:
-    x = torch.randn(M, k, device=dev).to(bf)
+    x = torch.randn(M + M // 8 + 8, k, device=dev).to(bf)[:M]  # (over-allocated: the ablation build's debug bit 128 reads rows 128 bytes further apart)
     w = (torch.randn(n, k, device=dev) * 0.02).to(bf)
     bias = torch.randn(n, device=dev)
     res = torch.randn(M, n, device=dev) if mode == "res" else None
