@@ -153,6 +153,8 @@ int tad_linear_bwd_weight_qkv(const uint16_t* dy, const uint16_t* x, float* dW, 
  *                     launches (whole rounds + remaining rows) when the cost model says so (default); 0 = never; 2 = always
  *   "splitk_tail"     1 = with a workspace, the second of those launches may split its tiles along K (default); 0 = never;
  *                     2 = whenever eligible (this one changes the summation order over K of the rows it covers)
+ *   "splitk_defer"    1 = a split-K tail runs as three launches -- its partial tiles, the whole rounds, its combine + epilogue -- so
+ *                     that the partial tiles travel through memory beside the whole rounds (default); 0 = one launch that combines inside
  *   "tn_pdeep"        1 = the weight-gradient GEMM requests its dy operand two reduction tiles ahead (three-slot ring, the whole
  *                     160 KiB of LDS); 0 = two-stage ring (default: measured equal) */
 int tad_linear_tuning(const char* key, int value);

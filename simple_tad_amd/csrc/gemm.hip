@@ -71,6 +71,8 @@ struct GemmNT {
   unsigned* sk_cnt;
   unsigned* sk_err;
   int sk_splits;
+  int sk_mode;  // 0: partial tiles combined inside the launch (arrival counters); 1: this launch only leaves the partial tiles (no wait);
+                // 2: this launch only combines what a mode-1 launch left (no K loop) -- the "deferred" split-K plan, see launch_gemm_nt
   int group_m;        // tile raster: row panels swept per column panel before moving to the next column panel (L2 reuse)
   unsigned long long* stamps;  // debug timeline (tad_linear_debug_stamps): per workgroup 64 slots of 4 x s_memrealtime, or null
 };
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
 
   const int nk_all = p.K / BKT;
   const int kt0 = SPLITK ? sk_share * nk_all / p.sk_splits : 0;                       // this workgroup's K-tiles: [kt0, kt0 + nk)
-  const int nk = SPLITK ? (sk_share + 1) * nk_all / p.sk_splits - kt0 : nk_all;
+  const int nk = SPLITK ? (p.sk_mode == 2 ? 0 : (sk_share + 1) * nk_all / p.sk_splits - kt0) : nk_all;
 #define FRAG_A(dst, base, ks) \
   _Pragma("unroll") for (int i = 0; i < MREP; ++i)  \
       dst[i] = *reinterpret_cast<const op16x8*>((base) + a_rd[i] + ((((KSTEPS > 1 ? 4 * (ks) : 0) + kq) ^ a_sw[i]) << 4))
@@ -645,6 +647,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
     const int S = p.sk_splits;
     float* const part = p.sk_ws + ((size_t)etile * S + sk_share) * (size_t)(BM * BN);
     const auto part_rs = __builtin_amdgcn_make_buffer_rsrc((void*)part, 0, BM * BN * 4, 0x00020000);
+    if (p.sk_mode != 2) {
 #pragma unroll
     for (int q = 0; q < NCHUNK; ++q) {
 #pragma unroll
@@ -665,14 +668,19 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
         for (int e4 = 0; e4 < CPL / 4; ++e4) {
           const u32x4 t = *reinterpret_cast<const u32x4*>(epi_lds + lr * CSTRIDE + col * 4 + 16 * e4);
           // write-through (sc1): the partial tile leaves the XCD's L2 as it is stored, so publishing it needs no agent-scope release
-          // (a release fence writes back EVERY dirty line of the L2: 8 us and more with 256 KB freshly written per workgroup)
-          __builtin_amdgcn_raw_buffer_store_b128(t, part_rs, (uint32_t)((trow * BN + col + 4 * e4) * 4), 0, 16);
+          // (a release fence writes back EVERY dirty line of the L2: 8 us and more with 256 KB freshly written per workgroup).
+          // The deferred plan (sk_mode 1) is ordered by the kernel boundary and stores with the ordinary output policy.
+          if (p.sk_mode == 0) __builtin_amdgcn_raw_buffer_store_b128(t, part_rs, (uint32_t)((trow * BN + col + 4 * e4) * 4), 0, 16);
+          else __builtin_amdgcn_raw_buffer_store_b128(t, part_rs, (uint32_t)((trow * BN + col + 4 * e4) * 4), 0, ST_AUX);
         }
       }
       if (q + 1 < NCHUNK) lds_barrier();
     }
+    }
+    if (p.sk_mode == 1) break;  // (deferred plan: a later launch combines; the kernel boundary orders the two)
     // ---- (2) publish, wait for the other shares of this tile (Guideline 16, form R1: write-through stores, every storing wave
     // drains them, barrier, ONE lane adds to the counter; ONE relaxed poll, one agent-scope acquire, barrier, then plain loads)
+    if (p.sk_mode == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
@@ -689,6 +697,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
+    }
     // ---- (3) this workgroup's rows of the tile: sum over the shares (share 0 carries the bias), epilogue, store
     float gam[CPL];
 #pragma unroll
@@ -1149,6 +1158,7 @@ int gemm_debug = env_int("TAD_GEMM_DEBUG");  // ablation bits (GemmNT::debug); o
 int nt_persist = !env_int("TAD_GEMM_NO_PERSIST");
 int nt_direct = getenv("TAD_GEMM_DIRECT_EPI") ? env_int("TAD_GEMM_DIRECT_EPI") : 1;
 int nt_split = getenv("TAD_GEMM_SPLIT_TAIL") ? env_int("TAD_GEMM_SPLIT_TAIL") : 1;
+int nt_sk_defer = getenv("TAD_GEMM_SPLITK_DEFER") ? env_int("TAD_GEMM_SPLITK_DEFER") : 1;  // 1 = split-K tails leave their partial tiles in front of the whole-round launch and are combined behind it; 0 = combined inside one launch
 int nt_splitk = getenv("TAD_GEMM_SPLITK_TAIL") ? env_int("TAD_GEMM_SPLITK_TAIL") : 1;  // 1 = the tail launch of the split plan may split its tiles along K (needs a workspace); 0 = never; 2 = whenever eligible
 int nt_variant = env_int("TAD_GEMM_NT_VARIANT");  // 0 = planned per shape (launch_gemm_nt), else the tile configuration for every launch
 int nt_group_m_knob = getenv("TAD_GEMM_GROUP_M") ? env_int("TAD_GEMM_GROUP_M") : 0;  // 0 = per-shape choice (nt_group_m)
@@ -1157,7 +1167,7 @@ int tn_pdeep = env_int("TAD_GEMM_TN_PDEEP");  // 1: gemm_tn 256 x 256 with the P
 unsigned long long* nt_stamps = nullptr;
 long long nt_launches = 0;  // gemm_nt kernel launches so far (tad_linear_kernel_launches)
 #else
-extern int gemm_debug, nt_persist, nt_direct, nt_split, nt_splitk, nt_variant, nt_group_m_knob, tn_variant, tn_pdeep;
+extern int gemm_debug, nt_persist, nt_direct, nt_split, nt_splitk, nt_variant, nt_group_m_knob, tn_variant, tn_pdeep, nt_sk_defer;
 extern unsigned long long* nt_stamps;
 extern long long nt_launches;
 #endif
@@ -1224,15 +1234,16 @@ static void launch_nt_variant(int v, GemmNT& p, hipStream_t st) {
 // [arrival counters, one per tile | error word][partial tiles].  The counters are zeroed on the stream in front of the launch.
 constexpr size_t SK_HEADER_BYTES = 4096;  // counters (<= 1008 tiles) + the error word at byte 4032
 constexpr size_t SK_TILE_BYTES = 256 * 256 * sizeof(float);
-static int launch_gemm_nt_splitk(GemmNT p, int splits, void* ws, hipStream_t st) {
+static int launch_gemm_nt_splitk(GemmNT p, int splits, void* ws, hipStream_t st, int mode = 0) {
   ++nt_launches;
   const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
   p.sk_splits = splits;
+  p.sk_mode = mode;
   p.sk_cnt = (unsigned*)ws;
   p.sk_err = (unsigned*)((char*)ws + 4032);
   p.sk_ws = (float*)((char*)ws + SK_HEADER_BYTES);
   p.group_m = nt_group_m((p.M + 255) / 256, (p.N + 255) / 256, p.K);
-  if (hipMemsetAsync(ws, 0, SK_HEADER_BYTES, st) != hipSuccess) { set_error("gemm_nt: split-K counter reset failed"); return TAD_ELAUNCH; }
+  if (mode == 0 && hipMemsetAsync(ws, 0, SK_HEADER_BYTES, st) != hipSuccess) { set_error("gemm_nt: split-K counter reset failed"); return TAD_ELAUNCH; }
   const dim3 grid(tiles * splits), block(512);
   if (p.epi == EPI_PLAIN && p.c_bf16) hipLaunchKernelGGL((gemm_nt_kernel<256, 256, 2, 4, 2, EPI_PLAIN, true, false, false, true>), grid, block, 0, st, p);
   else if (p.epi == EPI_PLAIN) hipLaunchKernelGGL((gemm_nt_kernel<256, 256, 2, 4, 2, EPI_PLAIN, false, false, false, true>), grid, block, 0, st, p);
@@ -1248,6 +1259,12 @@ static int nt_splitk_plan(const GemmNT& t, size_t ws_bytes, double* cost_us) {
   // measured (tools/exp_splitk.py, round 4): the 78-tile tails of ViT-B's N = 768 Linears (30 % of the CUs busy for one K loop) do NOT
   // gain -- three shares of 16 K-tiles + the combine take as long as one 256 x 128 K loop of 48 -- while the 16-tile tails of ViT-L's
   // N = 1024 Linears (6 % of the CUs) do: auto mode takes tails of at most a quarter of the CUs whose K loop is long enough
+  // Deferred plan (nt_sk_defer, launch_gemm_nt): the partial tiles are left by a launch IN FRONT of the whole-round launch and combined by a
+  // launch BEHIND it, so their way through memory (58 MB each way for 76 tiles x 3 shares) runs beside two rounds of matrix work instead of
+  // at the end of a 26 us kernel.  Measured (kernel trace, ViT-B dX(fc1), 76 tiles x 3 shares): partial-tile launch 54 us with write-through
+  // stores, whole rounds 190, combine 15 -- against 190 + 47 for the 256 x 128 tail: the 58 MB of partial tiles cost what the balanced
+  // K loop saves, so the rule for WHICH tails split stays what it was; the deferred form is the better way to run those that do
+  // (ViT-L fc2 421 -> 388 us against 392 combined in the launch, dX(fc1) 387 -> 364 against 376).
   if (nt_splitk == 1 && (tiles > cus / 4 || nk < 64)) return 0;  // (K = 3072 at 16 tiles: 289 -> 297 us; K = 4096: 424 -> 392, 387 -> 376)
   if (!((t.epi == EPI_PLAIN) || (t.epi == EPI_RESIDUAL && !t.c_bf16 && t.res_mod <= 0))) return 0;
   if (t.rowscale && t.rows_per_scale < 256) return 0;
@@ -1256,7 +1273,7 @@ static int nt_splitk_plan(const GemmNT& t, size_t ws_bytes, double* cost_us) {
   if (s > nk / 2) s = nk / 2;
   if (s > 8) s = 8;
   if (s < 2 || ws_bytes < SK_HEADER_BYTES + (size_t)tiles * s * SK_TILE_BYTES) return 0;
-  *cost_us = (double)((nk + s - 1) / s) * 1.65 + 14.0 + 3.0;
+  *cost_us = nt_sk_defer ? (double)((nk + s - 1) / s) * 1.45 + 10.0 + 16.0 : (double)((nk + s - 1) / s) * 1.65 + 14.0 + 3.0;
   return s;
 }
 
@@ -1383,9 +1400,16 @@ int launch_gemm_nt(const GemmNT& p_in, hipStream_t st, void* ws = nullptr, size_
   }
   if (nt_split == 2 && main_rows > 0) cost_c = 0.0;  // forced (experiments)
   if (cost_c < cost_a && cost_c < cost_b) {
+    const GemmNT t = row_range(p, main_rows, p.M - main_rows);
+    if (tail_splits && nt_sk_defer) {  // partial tiles of the tail | whole rounds | combine + epilogue of the tail
+      int rc = launch_gemm_nt_splitk(t, tail_splits, ws, st, 1);
+      if (rc) return rc;
+      rc = launch_gemm_nt_one(row_range(p, 0, main_rows), 1, st);
+      if (rc) return rc;
+      return launch_gemm_nt_splitk(t, tail_splits, ws, st, 2);
+    }
     int rc = launch_gemm_nt_one(row_range(p, 0, main_rows), 1, st);
     if (rc) return rc;
-    const GemmNT t = row_range(p, main_rows, p.M - main_rows);
     if (tail_splits) return launch_gemm_nt_splitk(t, tail_splits, ws, st);
     if (t.M < 2048) return launch_gemm_nt_one(t, 2, st);
     return launch_gemm_nt_one(t, nt_cost(1, t.epi, t.c_bf16, t.M, t.N, t.K) < nt_cost(3, t.epi, t.c_bf16, t.M, t.N, t.K) ? 1 : 3, st);
@@ -1539,6 +1563,7 @@ int tad_linear_tuning(const char* key, int value) {
   else if (k == "debug") gemm_debug = value;  // ablation bits (timing experiments; ignored by production builds)
   else if (k == "group_m") { TAD_REQUIRE(value >= 0 && value <= 1024, "linear_tuning: group_m=%d out of range", value); nt_group_m_knob = value; }
   else if (k == "variant") { TAD_REQUIRE(value >= 0 && value <= 5, "linear_tuning: variant=%d not in 0..5", value); nt_variant = value; }
+  else if (k == "splitk_defer") { TAD_REQUIRE(value == 0 || value == 1, "linear_tuning: splitk_defer=%d not in {0, 1}", value); nt_sk_defer = value; }
   else if (k == "tn_pdeep") { TAD_REQUIRE(value == 0 || value == 1, "linear_tuning: tn_pdeep=%d not in {0, 1}", value); tn_pdeep = value; }
   else if (k == "split_tail") { TAD_REQUIRE(value >= 0 && value <= 2, "linear_tuning: split_tail=%d not in 0..2", value); nt_split = value; }
   else { set_error("linear_tuning: unknown key '%s'", key); return TAD_EINVAL; }

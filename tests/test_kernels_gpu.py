@@ -521,14 +521,17 @@ def test_qkv_linear_q_prescale_every_schedule(K, M, D, Kd):
     assert float((y0[rows].double() - ref).abs().max() / ref.abs().max()) < 2 * BF16_ULP
 
 
+@pytest.mark.parametrize("defer", [1, 0], ids=["deferred_combine", "combine_in_launch"])
 @pytest.mark.parametrize("M,N,Kd,mode", [(50176, 768, 3072, "plain"), (50176 - 37, 768, 2304, "plain_f32"), (50176, 768, 3072, "res"),
                                          (50176, 768, 768, "res"), (50176, 1024, 1024, "plain"), (25088 + 5, 768, 1024, "res")])
-def test_linear_splitk_tail_matches_the_single_launch_plans(K, M, N, Kd, mode):
+def test_linear_splitk_tail_matches_the_single_launch_plans(K, M, N, Kd, mode, defer):
     """The under-filled last round of tiles as a split-K launch (tad_linear_fwd's `ws`; csrc/gemm.hip SPLITK): every tile of the tail
     is computed by several workgroups over shares of the K-tiles, their f32 partial tiles are combined inside the launch (arrival
     counter, agent-scope release / acquire).  Against the plan without it the result differs only in the summation order over K
     (tolerance-identical: the f32 accumulators of the shares are added in f32); rows of the main launch are bit-identical; the wait
-    never gave up (error word 0); twice in a row gives identical bits (the combine order is fixed: share 0, 1, 2 ...)."""
+    never gave up (error word 0); twice in a row gives identical bits (the combine order is fixed: share 0, 1, 2 ...).
+    defer = 1 (the default plan): the partial tiles are left by a launch in front of the whole-round launch and combined by a third
+    launch behind it -- same arithmetic, same order, so both forms must agree to the bit."""
     g = torch.Generator().manual_seed(M + N + Kd)
     x = dev(torch.randn(M, Kd, generator=g)).to(torch.bfloat16)
     w = dev(torch.randn(N, Kd, generator=g) * 0.05).to(torch.bfloat16)
@@ -549,11 +552,13 @@ def test_linear_splitk_tail_matches_the_single_launch_plans(K, M, N, Kd, mode):
     try:
         K.linear_tuning(**{**K.LINEAR_TUNING_DEFAULTS, "splitk_tail": 0})
         y0 = run().clone()
-        K.linear_tuning(**{**K.LINEAR_TUNING_DEFAULTS, "splitk_tail": 2, "split_tail": 2})
+        K.linear_tuning(**{**K.LINEAR_TUNING_DEFAULTS, "splitk_tail": 2, "split_tail": 2, "splitk_defer": defer})
         launches = K.linear_kernel_launches()
         y1 = run().clone()
-        assert K.linear_kernel_launches() - launches == 2  # main rounds + the split-K tail
+        assert K.linear_kernel_launches() - launches == (3 if defer else 2)  # (partial tiles of the tail +) main rounds + the split-K tail
         y2 = run().clone()
+        K.linear_tuning(**{**K.LINEAR_TUNING_DEFAULTS, "splitk_tail": 2, "split_tail": 2, "splitk_defer": 1 - defer})
+        assert torch.equal(run(), y1)  # the other form of the combine: bit-identical
     finally:
         K.linear_tuning(**K.LINEAR_TUNING_DEFAULTS)
     torch.cuda.synchronize()

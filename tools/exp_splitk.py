@@ -16,6 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--M", type=int, default=32 * 1568)
+ap.add_argument("--only", default="", help="substring filter on the shape names")
 a = ap.parse_args()
 dev, bf, M = "cuda", torch.bfloat16, a.M
 torch.manual_seed(0)
@@ -41,6 +42,7 @@ shapes = [("ViT-B proj fwd   N 768 K 768  +res", 768, 768, "res"), ("ViT-B fc2 f
           ("ViT-L proj fwd   N 1024 K 1024 +res", 1024, 1024, "res"), ("ViT-L fc2 fwd    N 1024 K 4096 +res", 1024, 4096, "res"),
           ("ViT-L dX(fc1)    N 1024 K 4096 bf16", 1024, 4096, "plain"), ("ViT-L dX(qkv)    N 1024 K 3072 bf16", 1024, 3072, "plain"),
           ("ViT-S fc2 fwd    N 384 K 1536 +res", 384, 1536, "res"), ("ViT-S dX(qkv)    N 384 K 1152 bf16", 384, 1152, "plain")]
+shapes = [sh for sh in shapes if a.only in sh[0]]
 print(f"{'shape':40s} {'off us':>9s} {'auto us':>9s} {'forced us':>10s}")
 tot = [0.0, 0.0, 0.0]
 try:
