@@ -116,22 +116,23 @@ def test_attention_random_shapes(K, seed):
     rs = np.random.RandomState(400 + seed)
     B, H = int(rs.randint(1, 4)), int(rs.randint(1, 5))
     N = int(rs.choice([1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 191, 193, 392, 500, 1000]))
-    scale = 0.125
+    d = 80 if seed % 3 == 2 else 64  # every third seed: the "huge" head dim (side images, fifth k-step)
+    scale = d ** -0.5
     g = torch.Generator().manual_seed(seed)
-    qkv = rnd(g, (B * N, 3 * H * 64))
-    dout = rnd(g, (B * N, H * 64))
+    qkv = rnd(g, (B * N, 3 * H * d))
+    dout = rnd(g, (B * N, H * d))
     pre = bool(seed & 1)  # odd seeds: the production contract (q third pre-scaled by scale * log2e), even: plain q
     opnd = qkv
     if pre:
-        opnd, qkv = prescaled_pair(qkv, B, N, H, scale, lambda t: t.to(torch.bfloat16).float())
+        opnd, qkv = prescaled_pair(qkv, B, N, H, scale, lambda t: t.to(torch.bfloat16).float(), d=d)
     q = qkv.double().reshape(B, N, -1).requires_grad_()
     ref = O.attention_core(q, H, scale)
     ref.backward(dout.double().reshape(B, N, -1))
     qd = opnd.cuda().to(torch.bfloat16)
-    out32, _ = K.attn_fwd(qd, B, N, H, scale, out_dtype=torch.float32, q_prescaled=pre)
+    out32, _ = K.attn_fwd(qd, B, N, H, scale, out_dtype=torch.float32, q_prescaled=pre, d=d)
     assert rel(out32.reshape(B, N, -1), ref) <= 4e-3, ("attn fwd f32", B, N, H, rel(out32.reshape(B, N, -1), ref))  # (P is rounded to bf16 inside: ATT_TOL)
-    out, lse = K.attn_fwd(qd, B, N, H, scale, q_prescaled=pre)
+    out, lse = K.attn_fwd(qd, B, N, H, scale, q_prescaled=pre, d=d)
     assert rel(out.float().reshape(B, N, -1), ref) <= 4e-3 + BF16_ULP / 2, ("attn fwd bf16", B, N, H, rel(out.float().reshape(B, N, -1), ref))
-    dqkv = K.attn_bwd(qd, out, dout.cuda().to(torch.bfloat16), lse, B, N, H, scale, q_prescaled=pre)
+    dqkv = K.attn_bwd(qd, out, dout.cuda().to(torch.bfloat16), lse, B, N, H, scale, q_prescaled=pre, d=d)
     e = ((dqkv.float().cpu().double().reshape(B, N, -1) - q.grad).abs().max() / q.grad.abs().max()).item()
     assert e <= 2 * BF16_ULP, ("attn bwd", B, N, H, e)
