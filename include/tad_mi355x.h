@@ -232,6 +232,15 @@ int tad_scale_cast_bf16(const float* x, uint16_t* y, const float* gamma, const f
  * partials in ws (tad_sumsq_workspace_bytes()), added in a fixed order; no atomics. */
 size_t tad_sumsq_workspace_bytes(void);
 int tad_sumsq_f32(const float* x, int64_t n, float* out, void* ws, size_t ws_bytes, tad_stream_t stream);
+/* NativeScalerWithGradNormCount's unscale + clip + overflow decision (utils.py:386-412: GradScaler.unscale_, clip_grad_norm_, the
+ * "found inf" skip) as two launches on the flat gradient buffer, nothing read back by the host:
+ *   out3[0] = ||x||_2 * inv_scale                                  (the gradient norm with the loss scale removed)
+ *   out3[1] = inv_scale * min(1, max_norm / (out3[0] + 1e-6))       (max_norm <= 0: inv_scale) -- tad_adamw_step's grad_scale operand;
+ *             0 when the norm is inf / NaN: the optimizer kernel then skips the step
+ *   out3[2] = 1 when the norm is inf / NaN, else 0                  (read by the host one step late)
+ * ws: tad_sumsq_workspace_bytes().  Deterministic (fixed order, no atomics). */
+int tad_grad_norm_coef(const float* x, int64_t n, float inv_scale, float max_norm, float* out3, void* ws, size_t ws_bytes,
+                       tad_stream_t stream);
 
 /* Batched bf16 transpose: every [R,C] matrix of a flat buffer -> [C,R] at the same offset of a second flat buffer, one launch (the
  * transposed operand copies W^T that the input-gradient GEMMs of all Linear layers read; refreshed once per optimizer step).

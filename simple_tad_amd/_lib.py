@@ -52,6 +52,7 @@ SIGNATURES = {
     "tad_scale_cast_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp]),
     "tad_sumsq_workspace_bytes": (_sz, []),
     "tad_sumsq_f32": (_i, [_vp, _i64, _vp, _vp, _sz, _vp]),
+    "tad_grad_norm_coef": (_i, [_vp, _i64, _f, _f, _vp, _vp, _sz, _vp]),
     "tad_transpose_bf16_batched": (_i, [_vp, _vp, _vp, _i, _vp]),
     "tad_adamw_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(_f), C.POINTER(_f), _i, C.POINTER(C.c_int32), _f, _f, _f, _vp, _vp,
                        _vp]),

@@ -66,7 +66,8 @@ struct GemmNT {
               // 8 = (gemm_tn) no fragment reads and no MFMA: staging and barriers only, 16 = (gemm_tn) unswizzled DMA source
   // split-K launch (SPLITK kernels: the under-filled last round of a Linear, see launch_gemm_nt): every 256 x 256 tile is computed by
   // sk_splits workgroups, each over its share of the K-tiles; sk_ws holds their f32 partial tiles [tile][split][256][256], sk_cnt one
-  // arrival counter per tile (zeroed by the launcher), sk_err a word that is set if a wait gave up
+  // arrival counter per tile (zeroed by the launcher), sk_err a word IN PINNED HOST MEMORY that is set if a wait gave up: the host looks at
+  // it at the start of every later Linear launch and fails that call loudly (launch_gemm_nt)
   float* sk_ws;
   unsigned* sk_cnt;
   unsigned* sk_err;
@@ -689,7 +690,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
       while (__hip_atomic_load(p.sk_cnt + etile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)S) {
         __builtin_amdgcn_s_sleep(4);
         if (++spins > (1u << 22)) {  // (seconds: a share of this tile is not running -- the grid was not resident) give up loudly
-          __hip_atomic_store(p.sk_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(p.sk_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (pinned host memory: sk_error_word)
           break;
         }
       }
@@ -1232,15 +1233,51 @@ static void launch_nt_variant(int v, GemmNT& p, hipStream_t st) {
 
 // Split-K launch of a (small) problem: tiles x splits workgroups, all resident (the caller checked tiles * splits <= CUs).  Workspace:
 // [arrival counters, one per tile | error word][partial tiles].  The counters are zeroed on the stream in front of the launch.
-constexpr size_t SK_HEADER_BYTES = 4096;  // counters (<= 1008 tiles) + the error word at byte 4032
+constexpr size_t SK_HEADER_BYTES = 4096;  // counters (<= 1008 tiles)
 constexpr size_t SK_TILE_BYTES = 256 * 256 * sizeof(float);
+// The in-launch combine (mode 0) waits for the other shares of its tile with a bounded spin; a share that never arrives (the grid was
+// not co-resident: a side stream or another process held CUs) leaves stale partial sums in the output.  The kernel then sets this word,
+// which lives in pinned, device-mapped host memory so that the host can see it without a synchronisation: every later gemm_nt launch
+// checks it first and returns TAD_ELAUNCH (the word used to sit in the workspace, where nobody read it).
+static unsigned* sk_error_word(unsigned** dev_ptr) {
+  static unsigned* host = nullptr;
+  static unsigned* dev = nullptr;
+  if (!host) {
+    void* h = nullptr;
+    void* d = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&d, h, 0) != hipSuccess) return nullptr;
+    host = (unsigned*)h;
+    dev = (unsigned*)d;
+    *host = 0u;
+  }
+  if (dev_ptr) *dev_ptr = dev;
+  return host;
+}
+static bool sk_error_pending_armed = false;  // (the word exists only once a mode-0 launch has been made)
+static int sk_check_pending_error() {
+  if (!sk_error_pending_armed) return TAD_OK;
+  unsigned* host = sk_error_word(nullptr);
+  if (host && __atomic_load_n(host, __ATOMIC_RELAXED)) {
+    __atomic_store_n(host, 0u, __ATOMIC_RELAXED);
+    set_error("gemm_nt: an earlier in-launch split-K combine (tad_linear_tuning(\"splitk_defer\", 0)) gave up waiting for a share of its tile -- "
+              "its grid was not co-resident (another stream or process held CUs); the output of that Linear is INVALID.  Use the default "
+              "deferred plan (splitk_defer = 1), which has no residency requirement");
+    return TAD_ELAUNCH;
+  }
+  return TAD_OK;
+}
+
 static int launch_gemm_nt_splitk(GemmNT p, int splits, void* ws, hipStream_t st, int mode = 0) {
   ++nt_launches;
   const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
   p.sk_splits = splits;
   p.sk_mode = mode;
   p.sk_cnt = (unsigned*)ws;
-  p.sk_err = (unsigned*)((char*)ws + 4032);
+  p.sk_err = nullptr;
+  if (mode == 0) {
+    if (!sk_error_word(&p.sk_err)) { set_error("gemm_nt: split-K error word allocation failed"); return TAD_ELAUNCH; }
+    sk_error_pending_armed = true;
+  }
   p.sk_ws = (float*)((char*)ws + SK_HEADER_BYTES);
   p.group_m = nt_group_m((p.M + 255) / 256, (p.N + 255) / 256, p.K);
   if (mode == 0 && hipMemsetAsync(ws, 0, SK_HEADER_BYTES, st) != hipSuccess) { set_error("gemm_nt: split-K counter reset failed"); return TAD_ELAUNCH; }
@@ -1332,6 +1369,7 @@ static double nt_cost(int v, int epi, int c_bf16, int M, int N, int K) {
 
 int launch_gemm_nt(const GemmNT& p_in, hipStream_t st, void* ws = nullptr, size_t ws_bytes = 0) {
   GemmNT p = p_in;
+  if (const int rc = sk_check_pending_error()) return rc;
   if (!(p.M > 0 && p.N > 0 && p.K > 0)) { set_error("gemm_nt: empty problem"); return TAD_EINVAL; }
   if (p.K % BK) { set_error("gemm_nt: K=%d must be a multiple of %d", p.K, BK); return TAD_EINVAL; }
   if (p.N % 4) { set_error("gemm_nt: N=%d must be a multiple of 4", p.N); return TAD_EINVAL; }

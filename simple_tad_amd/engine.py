@@ -147,16 +147,23 @@ class NativeScalerWithGradNormCount:
         self.growth_factor, self.backoff_factor, self.growth_interval = float(growth_factor), float(backoff_factor), int(growth_interval)
         self.growth_tracker = 0
         self.skipped_steps = 0
-        self._pending = None  # (found-inf flag on the device, optimizer) of the last fused step, not yet read
+        self._pending = None  # (found-inf flag in pinned host memory, the event behind its copy, optimizer) of the last fused step, not yet read
+        self._flag_host = None
 
     def _settle(self):
-        """read the previous fused step's found-inf flag (computed a whole step ago: the GPU is long past it, no bubble) and bring the
-        scale and, after a skipped step, the optimizer's step counts up to date"""
+        """read the previous fused step's found-inf flag and bring the scale and, after a skipped step, the optimizer's step counts up
+        to date.  The flag travelled to pinned host memory by an asynchronous copy issued right behind the norm kernel, and an event
+        recorded there is what the host waits for -- NOT the stream: by the time this runs the forward of the next step is already
+        queued, so the GPU keeps working through the wait.  (Round 4 read the flag with ``.item()``: a copy queued BEHIND that forward,
+        i.e. a full stream drain in front of every backward pass -- 0.5-1.0 ms of idle GPU per step in the kernel trace,
+        profiles/r05_kernel_stats_half.txt.)"""
         if self._pending is None:
             return
-        flag, optimizer = self._pending
+        flag, event, optimizer = self._pending
         self._pending = None
-        found_inf = bool(flag.item())
+        if event is not None:
+            event.synchronize()
+        found_inf = bool(flag[0].item() != 0)  # (pinned host memory behind its event, or a CPU tensor: no device round trip)
         self._update_scale(found_inf)
         if found_inf:
             optimizer.rollback_step()
@@ -193,14 +200,18 @@ class NativeScalerWithGradNormCount:
             # the coefficient (1 / scale) * min(1, max_norm / (norm + 1e-6)) of GradScaler.unscale_ + clip_grad_norm_ stays on the device
             clip = clip_grad is not None and clip_grad > 0
             if clip or scaling:
-                acc = torch.zeros(1, dtype=torch.float32, device=optimizer.flat_grad.device)
-                norm = K.sumsq(optimizer.flat_grad, acc).sqrt()[0] * inv
-                coef = (torch.clamp(clip_grad / (norm + 1e-6), max=1.0) if clip else torch.ones_like(norm)) * inv
-                if scaling:  # an overflowed step is skipped inside the kernel (grad_scale 0); the flag is read at the next call
-                    bad = ~torch.isfinite(norm)
-                    coef = torch.where(bad, torch.zeros_like(coef), coef)
-                    self._pending = (bad, optimizer)
-                optimizer.step(grad_scale=coef.reshape(1).float())
+                # ONE pass over the flat gradients + a one-thread finish: norm, coefficient (0 = overflow: the kernel skips the step)
+                # and the found-inf flag, all on the device (tad_grad_norm_coef)
+                nc = K.grad_norm_coef(optimizer.flat_grad, inv, clip_grad if clip else 0.0)
+                norm = nc[0]
+                if scaling:  # the flag is read at the next call, from pinned host memory behind an event (see _settle)
+                    if self._flag_host is None:
+                        self._flag_host = torch.zeros(1, dtype=torch.float32).pin_memory()
+                    self._flag_host.copy_(nc[2:3], non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    self._pending = (self._flag_host, ev, optimizer)
+                optimizer.step(grad_scale=nc[1:2])
             else:
                 norm = optimizer.step(want_sumsq=True).sqrt()
             return norm

@@ -186,7 +186,7 @@ def workspace(nbytes: int, device) -> torch.Tensor:
 def workspace_refs(device, stream=None):
     """every scratch buffer (live and retired) of one (device, stream): what a graph captured on that stream may point into"""
     ent = _workspaces.get(_ws_key(device, stream))
-    return [] if ent is None else [t for t in [ent["ws"], *ent["retired"]] if t is not None]
+    return [] if ent is None else [t for t in [ent["ws"], ent.get("lin"), *ent["retired"]] if t is not None]
 
 
 def release_workspace(device, stream=None) -> None:
@@ -455,17 +455,20 @@ def _pad_reduction(a, b, mult: int = 64):
 LINEAR_TUNING_DEFAULTS = dict(persistent=1, direct_epilogue=1, split_tail=1, splitk_tail=1, group_m=0, variant=0, tn_pdeep=0, splitk_defer=1)
 
 
-_lin_ws = {}
-
-
 def linear_workspace(nbytes: int, device) -> torch.Tensor:
-    """scratch of the split-K Linear tails, one per (device, stream); apart from `workspace`, so that neither buffer's growth retires
-    the other"""
+    """scratch of the split-K Linear tails, one per (device, stream): a buffer of its own (neither buffer's growth retires the other)
+    inside the SAME per-(device, stream) entry as `workspace`, so that `workspace_refs` reports it to holders of captured graphs and
+    `release_workspace` drops it with the rest"""
     key = _ws_key(device)
-    buf = _lin_ws.get(key)
+    ent = _workspaces.get(key)
+    if ent is None:
+        ent = _workspaces[key] = {"ws": None, "retired": []}
+    buf = ent.get("lin")
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            ent["retired"].append(buf)
         buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _lin_ws[key] = buf
+        ent["lin"] = buf
     return buf
 
 
@@ -647,6 +650,20 @@ def sumsq(x, out):
     lib = _lib.load()
     ws = workspace(lib.tad_sumsq_workspace_bytes(), x.device)
     check(lib.tad_sumsq_f32(x.data_ptr(), x.numel(), out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "tad_sumsq_f32")
+    return out
+
+
+def grad_norm_coef(x, inv_scale: float, max_norm: float = 0.0, out=None):
+    """[norm of x with the loss scale removed, grad_scale coefficient for adamw_step (0 = skip: overflow), found-inf flag] as one f32[3]
+    device tensor (tad_grad_norm_coef); nothing is read back"""
+    _req(x, torch.float32, "grad_norm_coef.x")
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty(3, dtype=torch.float32, device=x.device)
+    ws = workspace(lib.tad_sumsq_workspace_bytes(), x.device)
+    with _timed("sumsq", 0.0, 4.0 * x.numel()):
+        check(lib.tad_grad_norm_coef(x.data_ptr(), x.numel(), float(inv_scale), float(max_norm or 0.0), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                     _stream()), "tad_grad_norm_coef")
     return out
 
 

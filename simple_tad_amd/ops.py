@@ -384,7 +384,8 @@ _attn_q_prescale = True  # the qkv Linear writes q * scale * log2(e) (False: pla
 
 
 def set_attn_q_prescale(on: bool):
-    """must not change between a forward and its backward"""
+    """takes effect at the next forward; every autograd node remembers the contract its own forward ran under (ctx.qpre), so a toggle
+    between a forward and its backward cannot mis-read the saved qkv"""
     global _attn_q_prescale
     _attn_q_prescale = bool(on)
 
@@ -426,14 +427,18 @@ def _attn_fwd_core(xn, qkv_w, q_bias, v_bias, B, N, H, scale, train, drop=(0.0, 
     return qkv, r[0], (r[1], r[2] if len(r) > 2 else None)
 
 
-def _attn_bwd_core(d_ao, xn, qkv, ao, lse, qkv_w, has_qkv_bias, B, N, H, scale, dx_dtype, qv_params=None, ao_lo=None, drop=(0.0, 0)):
-    """returns dxn, dWqkv, dq_bias, dv_bias (None for what went into gradient sinks)"""
+def _attn_bwd_core(d_ao, xn, qkv, ao, lse, qkv_w, has_qkv_bias, B, N, H, scale, dx_dtype, qv_params=None, ao_lo=None, drop=(0.0, 0),
+                   q_prescaled=None):
+    """returns dxn, dWqkv, dq_bias, dv_bias (None for what went into gradient sinks).  q_prescaled: the q contract of the forward
+    that produced `qkv` (ctx.qpre)"""
+    if q_prescaled is None:
+        q_prescaled = _attn_q_prescale
     D = xn.shape[1]
     if qkv.dtype == torch.float32:  # generic head dim (see _attn_fwd_core)
         dqkv = K.cast_bf16(K.attn_bwd_f32(qkv, ao.float(), d_ao.float(), lse, B, N, H, scale, d=head_dim_of(qkv_w, H), drop_p=drop[0],
                                           seed=drop[1]))
     else:
-        dqkv = K.attn_bwd(qkv, ao, d_ao, lse, B, N, H, scale, out_lo=ao_lo, q_prescaled=_attn_q_prescale, drop_p=drop[0], seed=drop[1],
+        dqkv = K.attn_bwd(qkv, ao, d_ao, lse, B, N, H, scale, out_lo=ao_lo, q_prescaled=q_prescaled, drop_p=drop[0], seed=drop[1],
                           d=head_dim_of(qkv_w, H))
     dxn = K.linear_bwd_input(dqkv, wT_bf16(qkv_w, True), out_dtype=dx_dtype)
     if has_qkv_bias and qv_params is not None:
@@ -464,6 +469,7 @@ class AttentionFn(_Fn):
         ctx.drop = (float(drop_p), int(drop_seed))
         xb = K.cast_bf16(_f32c(x).reshape(B * N, C))
         qkv, ao, (lse, ao_lo) = _attn_fwd_core(xb, qkv_w, q_bias, v_bias, B, N, H, scale, train, ctx.drop)
+        ctx.qpre = _attn_q_prescale  # (the contract `qkv` was written under: read back by the backward)
         y, _ = K.linear_fwd(ao, w_bf16(proj_w, train), _f32c(proj_b), out_dtype=torch.float32)
         if train:
             ctx.save_for_backward(xb, qkv, ao, lse, qkv_w, proj_w, ao_lo)
@@ -480,7 +486,7 @@ class AttentionFn(_Fn):
         d_ao = K.linear_bwd_input(dyb, wT_bf16(proj_w, True))
         dWp, dbp = linear_dw(dyb, ao, proj_w, ctx.proj_b)
         dx, dWqkv, dqb, dvb = _attn_bwd_core(d_ao, xb, qkv, ao, lse, qkv_w, has_qb, B, N, H, scale, torch.float32, ctx.qv, ao_lo=ao_lo,
-                                             drop=ctx.drop)
+                                             drop=ctx.drop, q_prescaled=ctx.qpre)
         return dx.reshape(B, N, -1), dWqkv, dqb, dvb, dWp, dbp, None, None, None, None
 
 
@@ -580,6 +586,7 @@ class BlockFn(_Fn):
         g1, b1, g2, b2 = _f32c(n1w), _f32c(n1b), _f32c(n2w), _f32c(n2b)
         xn1, mean1, rstd1 = K.layernorm_fwd(x0, g1, b1, eps, save_stats=train)
         qkv, ao, (lse, ao_lo) = _attn_fwd_core(xn1, qkv_w, q_bias, v_bias, B, N, H, scale, train)
+        ctx.qpre = _attn_q_prescale  # (the contract `qkv` was written under: read back by the backward)
         x1, _ = K.linear_fwd(ao, w_bf16(proj_w, train), _f32c(proj_b), out_dtype=torch.float32, epilogue=EPI_BIAS_RESIDUAL, residual=x0,
                              rowscale=_f32c(dp1), rows_per_scale=N)
         xn2, mean2, rstd2 = K.layernorm_fwd(x1, g2, b2, eps, save_stats=train)
@@ -630,7 +637,7 @@ class BlockFn(_Fn):
         # ---- attention branch
         d_ao = K.linear_bwd_input(gpb, wT_bf16(proj_w, True))
         dWp, _ = linear_dw(gpb, ao, proj_w)
-        dxn1, dWqkv, dqb, dvb = _attn_bwd_core(d_ao, xn1, qkv, ao, lse, qkv_w, has_qb, B, N, H, scale, None, ctx.qv, ao_lo=ao_lo)
+        dxn1, dWqkv, dqb, dvb = _attn_bwd_core(d_ao, xn1, qkv, ao, lse, qkv_w, has_qb, B, N, H, scale, None, ctx.qv, ao_lo=ao_lo, q_prescaled=ctx.qpre)
         prev = ctx.prev_link
         if prev is not None:
             gin, ginb, dg1, dbeta1, _ = layernorm_bwd_sunk(dxn1, x0, g1, mean1, rstd1, n1w, n1b, dres=gmid, want_bf16=True, rowscale=prev.dp2,

@@ -104,7 +104,7 @@ class DataParallel(nn.Module):
     """Replicated-model data parallelism with bucketed, overlapped gradient all-reduce."""
 
     def __init__(self, module: nn.Module, bucket_mb: float = 64.0, process_group=None, broadcast: bool = True, overlap: bool = True,
-                 reduce_avg: Optional[bool] = None, tail_mb: Optional[float] = 16.0):
+                 reduce_avg: Optional[bool] = None, tail_mb: Optional[float] = 16.0, linear_schedule: Optional[str] = None):
         """``tail_mb``: the buckets that complete LAST (block 0 and the patch embedding: backward produces gradients head first) are cut
         to this size.  Every earlier bucket's all-reduce runs beside the rest of backward; the last one has nothing left to hide behind,
         so its size IS the exposed time of the exchange (a ring all-reduce is per-link bound on xGMI: ~64 MiB takes ~1.1 ms at 8
@@ -129,14 +129,17 @@ class DataParallel(nn.Module):
                 for p in module.parameters():
                     p.copy_(flat[off:off + p.numel()].view_as(p))
                     off += p.numel()
+        self.linear_schedule = None
         if self.world > 1 and dev.type == "cuda":
             # The persistent Linear kernels expect one workgroup per CU with a fixed tile list each (132-147 KB of LDS, every VGPR).
             # While an RCCL collective runs beside the backward pass it holds some CUs, the workgroups meant for them start a
             # whole kernel late and their tile lists double that kernel's time; the per-tile grid lets the dispatcher balance
             # instead.  (Costs the next-tile prefetch and the peeled last K-tile: 0.2 % of a single-GPU step on the round-2 build.)
-            from . import kernels as _K
-            _K.linear_tuning(persistent=0)
-            _K.set_linear_splitk(False)  # (the split-K tail launch needs all of its workgroups resident at once: same reason)
+            # That choice was made with two gloo ranks sharing one GPU, never with RCCL on separate GPUs: `linear_schedule="persistent"`
+            # (bench.py --linear-schedule) keeps the single-GPU schedule so that the first multi-GPU run can report both.
+            # Split-K tails stay ON in their deferred three-launch form, which is ordered by kernel boundaries and needs no
+            # co-residency; only the in-launch combine (splitk_defer=0) does, so it is pinned off here.
+            self.set_linear_schedule(linear_schedule or "per-tile")
         # flat gradient buffer (layout shared with the fused optimizer: flat.FlatSpace)
         self.space = FlatSpace(params)
         self.flat_grad = self.space.ensure_grads()
@@ -246,6 +249,24 @@ class DataParallel(nn.Module):
         if self._drain_first:
             torch.cuda.current_stream().synchronize()
         return dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op)
+
+    def set_linear_schedule(self, schedule: str):
+        """'per-tile' (one workgroup per tile, the dispatcher balances around CUs an RCCL kernel holds) or 'persistent' (one workgroup
+        per CU walks a tile list: the single-GPU schedule).  Process-wide knobs of the library (tad_linear_tuning): `close()` puts the
+        single-GPU defaults back."""
+        from . import kernels as _K
+        if schedule not in ("per-tile", "persistent"):
+            raise ValueError(f"linear_schedule must be 'per-tile' or 'persistent', got {schedule!r}")
+        _K.linear_tuning(persistent=int(schedule == "persistent"), splitk_defer=1)
+        self.linear_schedule = schedule
+
+    def close(self):
+        """undo the process-wide Linear scheduling knobs this wrapper set (a later single-GPU model in the same process gets the
+        defaults back)"""
+        if self.linear_schedule is not None:
+            from . import kernels as _K
+            _K.linear_tuning(persistent=_K.LINEAR_TUNING_DEFAULTS["persistent"], splitk_defer=_K.LINEAR_TUNING_DEFAULTS["splitk_defer"])
+            self.linear_schedule = None
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)

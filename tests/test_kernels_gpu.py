@@ -347,6 +347,65 @@ def test_meanpool_colsum_scale_sumsq(K):
     assert abs(out.item() - (v.double() ** 2).sum().item()) < 1e-4 * (v.double() ** 2).sum().item()
 
 
+def test_sumsq_alignment_tails_and_grad_norm_coef(K):
+    """the vectorised sum of squares for every alignment of the first element and every tail length, its determinism, and
+    tad_grad_norm_coef (GradScaler.unscale_ + clip_grad_norm_ + the found-inf decision of utils.py:386-412 on the device) against
+    the same arithmetic in torch"""
+    from simple_tad_amd import _lib
+    base = dev(R.tensor_for("ss2.x", (70001,)))
+    for off in (0, 1, 2, 3, 5):
+        for n in (1, 2, 3, 4, 7, 1023, 4096 * 3 + off, 70001 - 8):
+            v = base[off:off + n]
+            out = torch.zeros(1, device="cuda")
+            K.sumsq(v, out)
+            ref = (v.double() ** 2).sum().item()
+            assert abs(out.item() - ref) <= 2e-6 * ref, (off, n, out.item(), ref)
+    big = dev(R.tensor_for("ss2.big", (3_000_017,)))
+    a, b = torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")
+    K.sumsq(big, a)
+    K.sumsq(big, b)
+    assert torch.equal(a, b), "fixed-order reduction: two runs must agree bit for bit"
+    g = dev(R.tensor_for("gnc.g", (123457,), scale=300.0))
+    nrm = g.double().norm().item()
+    for inv, mx in ((1.0 / 1024.0, 0.0), (1.0 / 1024.0, 5.0), (1.0, 1e9), (0.5, 1e-3)):
+        o = K.grad_norm_coef(g, inv, mx).cpu()
+        n_ref = nrm * inv
+        c_ref = inv * (min(mx / (n_ref + 1e-6), 1.0) if mx > 0 else 1.0)
+        assert abs(o[0].item() - n_ref) <= 2e-6 * n_ref and abs(o[1].item() - c_ref) <= 4e-6 * c_ref and o[2].item() == 0.0, (inv, mx, o)
+    for poison in (float("inf"), float("nan"), 3e38):  # (3e38 squared overflows f32: the norm is inf, as torch's)
+        h = g.clone()
+        h[777] = poison
+        o = K.grad_norm_coef(h, 1.0 / 65536.0, 1.0).cpu()
+        assert not math.isfinite(o[0].item()) and o[1].item() == 0.0 and o[2].item() == 1.0, (poison, o)
+    with pytest.raises(_lib.TadError):
+        K.grad_norm_coef(torch.zeros(8), 1.0)
+
+
+def test_patch_embed_bwd_entry_point_is_the_weight_gradient_gemm(K):
+    """include/tad_mi355x.h declares tad_patch_embed_bwd (the Conv3d weight gradient, modeling_finetune.py:169-205 backward) beside the
+    Linear entry points; the product reaches the same kernels through ops.linear_dw.  Called through the C ABI here: dW, db against
+    the oracle on the bf16-rounded operands, and bit for bit what tad_linear_bwd_weight returns (exported, bound, never called)"""
+    from simple_tad_amd import _lib
+    lib = _lib.load()
+    M, D, Kc = 2 * 392, 128, 1536
+    dy = bf(R.tensor_for("peb.dy", (M, D), scale=0.1))
+    cols = bf(R.tensor_for("peb.cols", (M, Kc)))
+    dyd, cd = dev(dy).to(torch.bfloat16), dev(cols).to(torch.bfloat16)
+    st = torch.cuda.current_stream().cuda_stream
+    nb = lib.tad_patch_embed_bwd_workspace_bytes(M, D, Kc)
+    assert nb == lib.tad_linear_bwd_weight_workspace_bytes(M, D, Kc) and nb > 0
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    dW, db = torch.full((D, Kc), 7.0, device="cuda"), torch.full((D,), 7.0, device="cuda")  # (overwritten, not accumulated)
+    assert lib.tad_patch_embed_bwd(dyd.data_ptr(), cd.data_ptr(), dW.data_ptr(), db.data_ptr(), ws.data_ptr(), nb, M, D, Kc, st) == 0, lib.tad_last_error_string()
+    check(dW, dy.double().t() @ cols.double(), what="patch_embed_bwd dW")
+    check(db, dy.double().sum(0), what="patch_embed_bwd db")
+    dW2, db2 = torch.empty(D, Kc, device="cuda"), torch.empty(D, device="cuda")
+    assert lib.tad_linear_bwd_weight(dyd.data_ptr(), cd.data_ptr(), dW2.data_ptr(), db2.data_ptr(), 0, ws.data_ptr(), nb, M, D, Kc, st) == 0
+    assert torch.equal(dW, dW2) and torch.equal(db, db2)
+    rc = lib.tad_patch_embed_bwd(dyd.data_ptr(), cd.data_ptr(), dW.data_ptr(), db.data_ptr(), ws.data_ptr(), 16, M, D, Kc, st)
+    assert rc != 0 and b"workspace" in lib.tad_last_error_string()
+
+
 def test_errors_are_loud(K):
     from simple_tad_amd._lib import TadError
     with pytest.raises(TadError):

@@ -25,12 +25,14 @@ from simple_tad_amd import kernels as K, _lib  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--out", default=None)
 ap.add_argument("--seconds", type=float, default=2.0)
+ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"], help="operand format: the bf16 kernels or their IEEE-half twins (VERDICT r04 item 1)")
 a = ap.parse_args()
 lib = _lib.load()
-dev, bf = "cuda", torch.bfloat16
+dev, bf = "cuda", (torch.float16 if a.dtype == "f16" else torch.bfloat16)
+K.set_operand_dtype(bf)
 M = 50176
 res = {"method": "s_memtime / s_memrealtime x 100 MHz around the loop, one stamped launch after >= %.1f s of back-to-back launches on "
-                 "random data; median over workgroups (and tiles)" % a.seconds, "nominal_mhz": 2400, "device": K.device_info()}
+                 "random data; median over workgroups (and tiles)" % a.seconds, "nominal_mhz": 2400, "operands": a.dtype, "device": K.device_info()}
 
 
 def soak(fn, seconds):

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3, help="warm-up steps of the kernel-trace run")
     ap.add_argument("--pmc-steps", type=int, default=3)
     ap.add_argument("--out", default="profiles")
+    ap.add_argument("--cmd", default="python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras", help="the profiled command (header line)")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     import hashlib
@@ -104,7 +105,7 @@ def main():
                                                   "max_launch_us": st["max_ns"] / 1e3,
                                                   "avg_launch_us_without_max": (st["total_ns"] - st["max_ns"]) / (st["calls"] - 1) / 1e3}
         rows = sorted(agg.items(), key=lambda kv: -kv[1]["total_ns"])
-        lines = [f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras   ({a.steps} steps incl. warm-up)",
+        lines = [f"# rocprofv3 --kernel-trace --stats -- {a.cmd}   ({a.steps} steps incl. warm-up)",
                  f"# total kernel time {total / 1e6:.1f} ms = {total / 1e6 / a.steps:.2f} ms/step",
                  f"{'kernel':44s} {'calls':>7s} {'ms/step':>9s} {'avg us':>9s} {'share':>7s}"]
         for k, d in rows[:40]:
