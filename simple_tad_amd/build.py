@@ -10,10 +10,14 @@ CSRC = os.path.join(HERE, "csrc")
 #   TAD_BUILD_LIB=libtad_spread.so TAD_BUILD_DEFINES="-DTAD_DMA_SPREAD=1" python -m simple_tad_amd.build --force
 # and TAD_LIB=<path> selects the library a process loads (_lib.py).
 LIB = os.path.join(HERE, os.environ.get("TAD_BUILD_LIB", "libtad_mi355x.so"))
-SOURCES = ["capi.hip", "elementwise.hip", "layernorm.hip", "gemm.hip", "attn_fwd.hip", "attn_bwd.hip", "attn_f32.hip", "precise.hip", "optim.hip", "mae.hip", "metrics.hip", "collective.hip"]
+SOURCES = ["capi.hip", "elementwise.hip", "layernorm.hip", "gemm.hip", "gemm_w4.hip", "attn_fwd.hip", "attn_bwd.hip", "attn_f32.hip", "precise.hip", "optim.hip", "mae.hip", "metrics.hip", "collective.hip"]
 # Sources that touch 16-bit GEMM / attention operands are compiled a second time with -DTAD_OPND_F16: the same kernels for IEEE half
 # operands, exported as tad_*_f16 (csrc/common.h, csrc/opnd_f16_names.h; include/tad_mi355x.h "IEEE half operand twins").
-F16_SOURCES = ["elementwise.hip", "layernorm.hip", "gemm.hip", "attn_fwd.hip", "attn_bwd.hip", "optim.hip"]
+F16_SOURCES = ["elementwise.hip", "layernorm.hip", "gemm.hip", "gemm_w4.hip", "attn_fwd.hip", "attn_bwd.hip", "optim.hip"]
+# gemm_w4.hip (four waves of 128 x 128 outputs: 256 accumulator registers per lane) needs its accumulators in the AGPR half of the register
+# file: compiled without the vgpr-form switch below.  It includes gemm.hip for the kernel template.
+NO_VGPR_FORM = {"gemm_w4.hip"}
+EXTRA_DEPS = {"gemm_w4.hip": ["gemm.hip"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result",
          # keep MFMA accumulators in the (unified) VGPR file: without it the compiler parks them in AGPRs and pays a
          # v_accvgpr_read/write per element around every softmax / epilogue
@@ -48,9 +52,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
         src, half = job
         obj = os.path.join(objdir, src.replace(".hip", "_f16.o" if half else ".o"))
         srcp = os.path.join(CSRC, src)
-        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(p) for p in [srcp, *headers]):
+        deps = [srcp, *headers, *[os.path.join(CSRC, d) for d in EXTRA_DEPS.get(src, [])]]
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(p) for p in deps):
             return obj
-        cmd = [hipcc, *FLAGS, *(["-DTAD_OPND_F16"] if half else []), *(["-DTAD_GEMM_ABLATION"] if os.environ.get("TAD_BUILD_ABLATION") == "1" else []),
+        flags = [f for f in FLAGS if f not in ("-mllvm", "-amdgpu-mfma-vgpr-form=1")] if src in NO_VGPR_FORM else FLAGS
+        cmd = [hipcc, *flags, *(["-DTAD_OPND_F16"] if half else []), *(["-DTAD_GEMM_ABLATION"] if os.environ.get("TAD_BUILD_ABLATION") == "1" else []),
                *os.environ.get("TAD_BUILD_DEFINES", "").split(), "-c", srcp, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)

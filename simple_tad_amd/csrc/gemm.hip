@@ -78,6 +78,10 @@ struct GemmNT {
   unsigned long long* stamps;  // debug timeline (tad_linear_debug_stamps): per workgroup 64 slots of 4 x s_memrealtime, or null
 };
 
+int launch_gemm_nt_w4(const GemmNT& p, int grid_persist, hipStream_t st);  // csrc/gemm_w4.hip: the four-wave 256 x 256 kernels
+struct GemmTN;
+int launch_gemm_tn_w4(const GemmTN& p, int grid, hipStream_t st);
+
 constexpr int BK = 64;             // K-tile depth (bf16 elements) -> 128-byte LDS rows
 constexpr int ROW_BYTES = BK * 2;  // 128
 
@@ -115,6 +119,14 @@ __device__ __forceinline__ void stage_tile(const void* gbase, int gbytes, char* 
 #ifndef TAD_NT_PEEL
 #define TAD_NT_PEEL 1  // last K-tile of the persistent bias-only 16-bit kernel peeled (see PEEL in gemm_nt_kernel); 0 = the round-1 schedule
 #endif
+
+// One 1-KiB LDS-DMA piece of the four-wave kernel (W4 in gemm_nt_kernel): `dst` = LDS address of the piece, `off` = the lane's byte offset
+// into the operand (swizzled), `add` = the K-tile's advance along the row (scalar offset: see SCALAR_ADD above).  A function, not a macro
+// inside the kernel's nested generic lambdas: with the builtin called there, the HOST pass of hipcc dropped the kernel's launch stub
+// without a diagnostic.
+__device__ __forceinline__ void w4_dma_piece(const void* gbase, int gbytes, char* dst, uint32_t off, uint32_t add) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(gbase), 0, gbytes, 0x00020000), LDS_PTR(dst), 16, off, add, 0, 0);
+}
 
 // wait until at most `stages_in_flight` later stages (LOADS DMA instructions each, per wave) plus EXTRA younger vector-memory
 // instructions are still outstanding
@@ -156,6 +168,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
   constexpr int BKT = BK;
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr bool IS_RES = (EPI == EPI_RESIDUAL || EPI == EPI_RESMOD);
+  // W4: FOUR waves, one per SIMD, 128 x 128 outputs each (256 accumulator registers in the AGPR half of the unified file, so this
+  // instantiation lives in a translation unit of its own, csrc/gemm_w4.hip, compiled without -amdgpu-mfma-vgpr-form) and a K loop whose
+  // order of LDS reads, LDS-DMA pieces and matrix instructions is written out by hand (see W4 below).  Against the 8-wave form a
+  // K-tile needs a third fewer LDS fragment bytes per matrix instruction (32 x 16-byte reads per 128 MFMAs instead of 24 per 64).
+  constexpr bool W4 = NW == 4 && BM == 256 && BN == 256 && STAGES == 2 && !SPLITK && !DIRECT;
   constexpr int ROWB = BKT * 2;               // bytes per LDS row
   constexpr int RPP = 1024 / ROWB;            // rows per 1-KiB DMA piece
   constexpr int CPR = ROWB / 16;              // 16-byte chunks per row
@@ -429,7 +446,104 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
 #pragma unroll
     for (int i = 0; i < MREP; ++i) acc[i][j] = b4;
   }
-  {
+  if constexpr (W4) {
+    // ---- W4 K loop.  Per K-tile and wave: 128 MFMAs (16 x 16 x 32) in two halves of 64 -- k-step 0 and k-step 1, each as 8 groups of
+    // 8 (one x fragment against the 8 w fragments) -- with two fragment sets: while the matrix pipe works through one k-step the 16
+    // fragments of the next one arrive (two 16-byte reads behind every group), so the only place the wave waits for the LDS is a counted
+    // wait at the half boundary, by which time the data has had 64 MFMAs to land.  K-tile kt + 2 is requested (two LDS-DMA pieces per
+    // group) into the ring slot of K-tile kt during kt's SECOND half, behind the one barrier of the tile: every wave has its k-step-1
+    // fragments of that slot in registers by then, and the k-step-0 fragments were taken during the previous tile.  So a piece has a
+    // whole tile (about 1.1 us) to arrive, one barrier per K-tile orders everything, and nothing but the half-boundary waits separates
+    // two matrix instructions.  Every LDS read is inline asm with an immediate offset (common.h): addresses are 32 lane constants
+    // computed once per kernel ([slot][k-step][fragment & 3]; fragment q + 4 lies 8 KiB behind fragment q with the same swizzle).
+    // (the ring slot is toggled in the address REGISTERS, one v_xor each per K-tile, and in a scalar for the DMA destination: two copies
+    //  of the body selected by a branch make the compiler route the 256 accumulators and the fragments through PHI copies and spill)
+    static_assert(STAGE_BYTES == 65536, "slot toggle = bit 16 of the LDS address");
+    uint32_t a_ad[2][4], b_ad[2][4];  // [k-step][fragment & 3], pointing into the slot that is being read
+    {
+      const uint32_t l0 = lds_addr(lds);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          a_ad[ks][q] = l0 + a_rd[q] + (uint32_t)((((4 * ks) + kq) ^ a_sw[q]) << 4);
+          b_ad[ks][q] = l0 + (uint32_t)A_BYTES + b_rd[q] + (uint32_t)((((4 * ks) + kq) ^ b_sw[q]) << 4);
+        }
+    }
+    static_assert(MREP == 8 && NREP == 8 && LOADS == 16, "W4 geometry");
+    op16x8 fa[2][8], fb[2][8];  // [fragment set = k-step][fragment]
+    // one LDS-DMA piece of K-tile kt into the ring slot at byte offset SLOT: pieces 0..7 are x rows, 8..15 w rows (stage_tile's layout).
+#define W4_PIECE(SLOT, idx, kt_)                                                                                                          \
+  if ((idx) < 8) w4_dma_piece(p.A, a_bytes, lds + (SLOT) + (((idx) & 7) * NW + wave) * 1024, a_off[(idx) & 7], (uint32_t)(kt_) * ROWB);    \
+  else w4_dma_piece(p.B, b_bytes, lds + (SLOT) + A_BYTES + (((idx) & 7) * NW + wave) * 1024, b_off[(idx) & 7], (uint32_t)(kt_) * ROWB)
+    // K-tile 1 (K-tile 0 is on its way: issued before the loop, or under the previous tile's epilogue); nk >= 2 (the launcher's rule)
+    static_for<0, 16>([&](auto ic) { W4_PIECE(STAGE_BYTES, decltype(ic)::value, 1); });
+    first_tile = false;
+    wait_stage<LOADS>(1);
+    block_barrier();
+    static_for<0, 8>([&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      fb[0][g] = lds_read_b128<op16x8, (g >> 2) * 8192>(b_ad[0][g & 3]);
+      fa[0][g] = lds_read_b128<op16x8, (g >> 2) * 8192>(a_ad[0][g & 3]);
+    });
+    int slot = 0;  // byte offset of the ring slot of K-tile kt
+    // NEXT / NEXT2 (compile-time): there is a K-tile kt + 1 / kt + 2.  The steady state is ONE copy of the body inside the loop; the last
+    // two K-tiles follow it as straight-line code.
+    auto w4_tile = [&](auto NEXTC, auto NEXT2C, int kt) {
+      constexpr bool NEXT = decltype(NEXTC)::value, NEXT2 = decltype(NEXT2C)::value;
+      // ---- first half: k-step 0 products; the k-step-1 fragments of this slot are requested behind each group
+      lds_wait<0>(fb[0][0], fb[0][1], fb[0][2], fb[0][3], fb[0][4], fb[0][5], fb[0][6], fb[0][7]);
+      lds_wait<0>(fa[0][0], fa[0][1], fa[0][2], fa[0][3], fa[0][4], fa[0][5], fa[0][6], fa[0][7]);
+      static_for<0, 8>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        fb[1][g] = lds_read_b128<op16x8, (g >> 2) * 8192>(b_ad[1][g & 3]);
+        fa[1][g] = lds_read_b128<op16x8, (g >> 2) * 8192>(a_ad[1][g & 3]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[g][j] = TAD_MFMA_16x16x32(fb[0][j], fa[0][g], acc[g][j]);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      // ---- second half: k-step 1 products; K-tile kt + 1 has landed -> its k-step-0 fragments; K-tile kt + 2 requested into this slot
+      lds_wait<0>(fb[1][0], fb[1][1], fb[1][2], fb[1][3], fb[1][4], fb[1][5], fb[1][6], fb[1][7]);
+      lds_wait<0>(fa[1][0], fa[1][1], fa[1][2], fa[1][3], fa[1][4], fa[1][5], fa[1][6], fa[1][7]);
+      if constexpr (NEXT) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        block_barrier();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { a_ad[ks][q] ^= (uint32_t)STAGE_BYTES; b_ad[ks][q] ^= (uint32_t)STAGE_BYTES; }
+      } else if constexpr (HAS_EXTRA) {
+        ISSUE_EXTRA(0, 0);  // (last K-tile) what the epilogue's first chunk reads besides the accumulators
+      }
+      static_for<0, 8>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        if constexpr (NEXT2) {
+          W4_PIECE(slot, 2 * g, kt + 2);
+          W4_PIECE(slot, 2 * g + 1, kt + 2);
+        }
+        if constexpr (NEXT) {
+          fb[0][g] = lds_read_b128<op16x8, (g >> 2) * 8192>(b_ad[0][g & 3]);
+          fa[0][g] = lds_read_b128<op16x8, (g >> 2) * 8192>(a_ad[0][g & 3]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[g][j] = TAD_MFMA_16x16x32(fb[1][j], fa[1][g], acc[g][j]);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      slot ^= STAGE_BYTES;
+    };
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) w4_tile(std::true_type{}, std::true_type{}, kt);
+    w4_tile(std::true_type{}, std::false_type{}, kt);
+    w4_tile(std::false_type{}, std::false_type{}, kt + 1);
+    // (persistent: the address registers must point at slot 0 again for the next tile, whose K-tile 0 lands there)
+    if ((nk & 1) == 0) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { a_ad[ks][q] ^= (uint32_t)STAGE_BYTES; b_ad[ks][q] ^= (uint32_t)STAGE_BYTES; }
+    }
+#undef W4_PIECE
+  } else {
     // K-tile 0 is already on its way (issued before the loop, or under the previous tile's epilogue); with the DIRECT epilogue
     // (which leaves the LDS alone) so are the other prologue stages of every tile but the first
     if (!DIRECT || first_tile) {
@@ -1142,6 +1256,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_kernel(const Ge
   }
 }
 
+#ifndef TAD_GEMM_W4_TU  // (csrc/gemm_w4.hip includes this file for the kernel templates and parameter blocks only)
 // ------------------------------------------------------------------------------------------------------------
 
 static int cu_count();
@@ -1164,11 +1279,12 @@ int nt_splitk = getenv("TAD_GEMM_SPLITK_TAIL") ? env_int("TAD_GEMM_SPLITK_TAIL")
 int nt_variant = env_int("TAD_GEMM_NT_VARIANT");  // 0 = planned per shape (launch_gemm_nt), else the tile configuration for every launch
 int nt_group_m_knob = getenv("TAD_GEMM_GROUP_M") ? env_int("TAD_GEMM_GROUP_M") : 0;  // 0 = per-shape choice (nt_group_m)
 int tn_variant = env_int("TAD_GEMM_TN_VARIANT");
+int tn_w4 = getenv("TAD_GEMM_TN_W4") ? env_int("TAD_GEMM_TN_W4") : 1;  // 1: the 256 x 256 weight-gradient GEMM runs as four waves of 128 x 128 (gemm_w4.hip)
 int tn_pdeep = env_int("TAD_GEMM_TN_PDEEP");  // 1: gemm_tn 256 x 256 with the P operand two reduction tiles ahead (see PDEEP); measured null (round 4), off
 unsigned long long* nt_stamps = nullptr;
 long long nt_launches = 0;  // gemm_nt kernel launches so far (tad_linear_kernel_launches)
 #else
-extern int gemm_debug, nt_persist, nt_direct, nt_split, nt_splitk, nt_variant, nt_group_m_knob, tn_variant, tn_pdeep, nt_sk_defer;
+extern int gemm_debug, nt_persist, nt_direct, nt_split, nt_splitk, nt_variant, nt_group_m_knob, tn_variant, tn_pdeep, nt_sk_defer, tn_w4;
 extern unsigned long long* nt_stamps;
 extern long long nt_launches;
 #endif
@@ -1196,7 +1312,7 @@ template <int EPI, bool OUT_BF16>
 static void launch_nt_variant(int v, GemmNT& p, hipStream_t st) {
   auto tiles = [&](int bm, int bn) { return ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
   const int no_persist = !nt_persist;
-  if (((EPI == EPI_RESIDUAL && OUT_BF16) || EPI == EPI_RESMOD) && v == 1) v = 3;  // (not instantiated: no registers / never needed)
+  if (((EPI == EPI_RESIDUAL && OUT_BF16) || EPI == EPI_RESMOD) && (v == 1 || v == 7)) v = 3;  // (not instantiated: no registers / never needed)
   if (v != 2 && v != 4 && v != 5 && p.rowscale && p.rows_per_scale < 256) v = 2;  // the 256-row tiles take at most two row-scale groups per tile
   const int grid_p = cu_count() & ~7;
   const int bn = v == 1 ? 256 : 128;
@@ -1218,6 +1334,12 @@ static void launch_nt_variant(int v, GemmNT& p, hipStream_t st) {
       if (persist) { if (direct) NT_LAUNCH(256, 128, 4, 2, 3, true, true, grid_p, 512); else NT_LAUNCH(256, 128, 4, 2, 3, true, false, grid_p, 512); }
       else { if (direct) NT_LAUNCH(256, 128, 4, 2, 3, false, true, tiles(256, 128), 512); else NT_LAUNCH(256, 128, 4, 2, 3, false, false, tiles(256, 128), 512); }
       break;
+    case 7: {  // the four-wave 256 x 256 kernels (gemm_w4.hip); persistent under the same rule as variant 1
+      if (p.K < 2 * BK) { NT_LAUNCH(256, 256, 2, 4, 2, false, false, tiles(256, 256), 512); break; }  // (its K loop is written for >= 2 K-tiles)
+      const bool per7 = !no_persist && grid_p >= 8 && tiles(256, 256) > grid_p + grid_p / 2;
+      (void)launch_gemm_nt_w4(p, per7 ? grid_p : 0, st);
+      break;
+    }
     case 4:
       if (direct) NT_LAUNCH(128, 64, 2, 2, 2, false, true, tiles(128, 64), 256); else NT_LAUNCH(128, 64, 2, 2, 2, false, false, tiles(128, 64), 256);
       break;
@@ -1519,7 +1641,12 @@ int launch_gemm_tn(const uint16_t* P, const uint16_t* Q, float* out, float* bias
   const int tiles_k = (K + (tn_variant(K) != 3 ? 256 : 128) - 1) / (tn_variant(K) != 3 ? 256 : 128);
   if (ws_bytes < (size_t)splits * ((size_t)N * K + (size_t)tiles_k * N) * sizeof(float)) { set_error("gemm_tn: workspace too small"); return TAD_ENOSPACE; }
   p.bias_slab = bias_out ? p.slab + (size_t)splits * N * K : nullptr;
-  if (tn_variant(K) == 1 && knobs::tn_pdeep)
+  // 256 x 256 tiles: the four-wave kernel (gemm_w4.hip; bit-identical results) unless switched off (tad_linear_tuning("tn_w4", 0)); its loop
+  // is written for at least two reduction tiles per workgroup
+  if (tn_variant(K) == 1 && knobs::tn_w4 && !knobs::tn_pdeep && p.rows_per_split >= 2 * BK && !p.debug) {
+    const int rc = launch_gemm_tn_w4(p, tiles * splits, st);
+    if (rc) return rc;
+  } else if (tn_variant(K) == 1 && knobs::tn_pdeep)
     hipLaunchKernelGGL((gemm_tn_kernel<256, 256, 2, 4, 2, true>), dim3(tiles * splits), dim3(512), 0, st, p);
   else if (tn_variant(K) == 1)
     hipLaunchKernelGGL((gemm_tn_kernel<256, 256, 2, 4, 2>), dim3(tiles * splits), dim3(512), 0, st, p);
@@ -1600,8 +1727,9 @@ int tad_linear_tuning(const char* key, int value) {
   else if (k == "direct_epilogue") { TAD_REQUIRE(value >= 0 && value <= 2, "linear_tuning: direct_epilogue=%d not in 0..2", value); nt_direct = value; }
   else if (k == "debug") gemm_debug = value;  // ablation bits (timing experiments; ignored by production builds)
   else if (k == "group_m") { TAD_REQUIRE(value >= 0 && value <= 1024, "linear_tuning: group_m=%d out of range", value); nt_group_m_knob = value; }
-  else if (k == "variant") { TAD_REQUIRE(value >= 0 && value <= 5, "linear_tuning: variant=%d not in 0..5", value); nt_variant = value; }
+  else if (k == "variant") { TAD_REQUIRE(value >= 0 && value <= 7 && value != 6, "linear_tuning: variant=%d not one of 0..5, 7", value); nt_variant = value; }
   else if (k == "splitk_defer") { TAD_REQUIRE(value == 0 || value == 1, "linear_tuning: splitk_defer=%d not in {0, 1}", value); nt_sk_defer = value; }
+  else if (k == "tn_w4") { TAD_REQUIRE(value == 0 || value == 1, "linear_tuning: tn_w4=%d not in {0, 1}", value); tn_w4 = value; }
   else if (k == "tn_pdeep") { TAD_REQUIRE(value == 0 || value == 1, "linear_tuning: tn_pdeep=%d not in {0, 1}", value); tn_pdeep = value; }
   else if (k == "split_tail") { TAD_REQUIRE(value >= 0 && value <= 2, "linear_tuning: split_tail=%d not in 0..2", value); nt_split = value; }
   else { set_error("linear_tuning: unknown key '%s'", key); return TAD_EINVAL; }
@@ -1687,3 +1815,4 @@ int tad_patch_embed_bwd(const uint16_t* dy_bf16, const uint16_t* cols, float* dW
 }
 
 }  // extern "C"
+#endif  // TAD_GEMM_W4_TU

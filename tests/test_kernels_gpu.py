@@ -517,7 +517,9 @@ def test_linear_persistent_schedule_is_bit_identical(K, M, N, Kd, mode):
         base = dict(persistent=0, direct_epilogue=0, split_tail=0, splitk_tail=0)  # (the split-K tail changes the summation order: its own test)
         for name, cfg in [("tile", {}), ("tile_direct", dict(direct_epilogue=2)), ("persist", dict(persistent=1)),
                           ("persist_direct", dict(persistent=1, direct_epilogue=2)), ("split", dict(persistent=1, split_tail=2)),
-                          ("default", {**K.LINEAR_TUNING_DEFAULTS, "splitk_tail": 0})]:
+                          ("default", {**K.LINEAR_TUNING_DEFAULTS, "splitk_tail": 0}),
+                          # the four-wave kernels (csrc/gemm_w4.hip: 128 x 128 outputs per wave, hand-ordered K loop), per tile and persistent
+                          ("w4_tile", dict(variant=7)), ("w4_persist", dict(variant=7, persistent=1))]:
             K.linear_tuning(**{**base, **cfg})
             y, pre = run()
             torch.cuda.synchronize()
@@ -525,7 +527,7 @@ def test_linear_persistent_schedule_is_bit_identical(K, M, N, Kd, mode):
     finally:
         K.linear_tuning(**K.LINEAR_TUNING_DEFAULTS)
     y0, p0 = outs["tile"]
-    for name in ("tile_direct", "persist", "persist_direct", "split", "default"):
+    for name in ("tile_direct", "persist", "persist_direct", "split", "default", "w4_tile", "w4_persist"):
         y1, p1 = outs[name]
         assert torch.equal(y0, y1), f"{name}: output differs from per-tile scheduling"
         if p0 is not None:
@@ -545,6 +547,41 @@ def test_linear_persistent_schedule_is_bit_identical(K, M, N, Kd, mode):
     got = y0[rows].double()
     tol = TOL if y0.dtype == torch.float32 else 2 * BF16_ULP
     assert float((got - ref).abs().max() / ref.abs().max()) < tol
+
+
+@pytest.mark.parametrize("M,N,Kd", [(50176, 768, 768), (25088 + 70, 2304, 768), (12544, 768 + 8, 3072 - 8), (1024, 512, 256), (40000, 384, 1536)])
+def test_weight_gradient_four_wave_kernel_is_bit_identical(K, M, N, Kd):
+    """gemm_tn_w4_kernel (csrc/gemm_w4.hip: four waves of 128 x 128, one per SIMD, the default for 256-wide tiles) against the eight-wave
+    gemm_tn_kernel: dW and the bias column sums bit for bit (same instruction, same order over the reduction rows), ragged N / K / M edges,
+    the qkv entry point with its split bias, accumulate mode; and dW right against an f64 product of the same operands."""
+    g = torch.Generator().manual_seed(M + N + Kd)
+    dy = dev(torch.randn(M, N, generator=g)).to(torch.bfloat16)
+    x = dev(torch.randn(M, Kd, generator=g)).to(torch.bfloat16)
+    outs = {}
+    try:
+        for v in (0, 1):
+            K.linear_tuning(**{**K.LINEAR_TUNING_DEFAULTS, "tn_w4": v})
+            dW, db = K.linear_bwd_weight(dy, x, want_bias=True)
+            acc = torch.full((N, Kd), 0.5, device="cuda")
+            dba = torch.full((N,), 0.25, device="cuda")
+            K.linear_bwd_weight(dy, x, want_bias=True, dW=acc, db=dba, accumulate=True)
+            extra = None
+            if N % 3 == 0:
+                dWq, dq, dv = torch.zeros(N, Kd, device="cuda"), torch.zeros(N // 3, device="cuda"), torch.zeros(N // 3, device="cuda")
+                K.linear_bwd_weight_qkv(dy, x, dWq, dq, dv, accumulate=False)
+                extra = (dWq.clone(), dq.clone(), dv.clone())
+            torch.cuda.synchronize()
+            outs[v] = (dW.clone(), db.clone(), acc.clone(), dba.clone(), extra)
+    finally:
+        K.linear_tuning(**K.LINEAR_TUNING_DEFAULTS)
+    for a_, b_ in zip(outs[0][:4], outs[1][:4]):
+        assert torch.equal(a_, b_)
+    if outs[0][4] is not None:
+        assert all(torch.equal(a_, b_) for a_, b_ in zip(outs[0][4], outs[1][4]))
+    rows = torch.randint(0, N, (16,), generator=g).tolist() + [0, N - 1]
+    ref = dy[:, rows].double().t() @ x.double()
+    check(outs[1][0][rows], ref, what="dW (four-wave kernel)")
+    check(outs[1][1], dy.double().sum(0), what="db (four-wave kernel)")
 
 
 @pytest.mark.parametrize("M,D,Kd", [(25088 + 5, 768, 768), (20000 + 3, 384, 384), (300, 128, 128), (40000, 1024, 256)])

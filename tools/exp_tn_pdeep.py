@@ -17,8 +17,10 @@ ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--D", type=int, default=768)
 ap.add_argument("--M", type=int, default=50176)
+ap.add_argument("--knob", default="tn_pdeep", help="tn_pdeep (round 4) or tn_w4 (round 5: the four-wave kernel of csrc/gemm_w4.hip)")
+ap.add_argument("--dtype", default="bf16")
 a = ap.parse_args()
-M, D, dev, bf = a.M, a.D, "cuda", torch.bfloat16
+M, D, dev, bf = a.M, a.D, "cuda", (torch.float16 if a.dtype == "f16" else torch.bfloat16)
 torch.manual_seed(0)
 
 
@@ -33,14 +35,14 @@ def timeit(fn):
 
 
 tot = [0.0, 0.0]
-print(f"{'dW shape':28s} {'ring 2 us':>10s} {'P deep us':>10s}  bit-identical")
+print(f"{'dW shape':28s} {a.knob + '=0 us':>12s} {a.knob + '=1 us':>12s}  bit-identical   ({a.dtype})")
 try:
     for name, n, k in (("qkv  [3D, D]", 3 * D, D), ("proj [D, D]", D, D), ("fc1  [4D, D]", 4 * D, D), ("fc2  [D, 4D]", D, 4 * D)):
         dy, x = torch.randn(M, n, device=dev).to(bf), torch.randn(M, k, device=dev).to(bf)
         fn = lambda: K.linear_bwd_weight(dy, x, want_bias=True)  # noqa: E731
         outs = []
         for v in (0, 1):
-            K.linear_tuning(**{**K.LINEAR_TUNING_DEFAULTS, "tn_pdeep": v})
+            K.linear_tuning(**{**K.LINEAR_TUNING_DEFAULTS, a.knob: v})
             dW, db = fn()
             outs.append((dW.clone(), db.clone()))
             for _ in range(3):
@@ -49,12 +51,12 @@ try:
         t = [[], []]
         for _ in range(a.rounds):
             for v in (0, 1):
-                K.linear_tuning(**{**K.LINEAR_TUNING_DEFAULTS, "tn_pdeep": v})
+                K.linear_tuning(**{**K.LINEAR_TUNING_DEFAULTS, a.knob: v})
                 t[v].append(timeit(fn))
         m0, m1 = statistics.median(t[0]), statistics.median(t[1])
         tot[0] += m0
         tot[1] += m1
-        print(f"{name:28s} {m0:10.1f} {m1:10.1f}  {same}", flush=True)
+        print(f"{name:28s} {m0:12.1f} {m1:12.1f}  {same}   {2.0 * M * n * k / m0 / 1e6:6.0f} -> {2.0 * M * n * k / m1 / 1e6:6.0f} TFLOP/s", flush=True)
 finally:
     K.linear_tuning(**K.LINEAR_TUNING_DEFAULTS)
-print(f"{'sum':28s} {tot[0]:10.1f} {tot[1]:10.1f}")
+print(f"{'sum':28s} {tot[0]:12.1f} {tot[1]:12.1f}")
