@@ -30,6 +30,19 @@ __device__ __forceinline__ void mfma_16x16x32_vgpr(f32x4& d, const op16x8& a, co
 #endif
 }
 
+// timing experiments (compile-time, wrong results): the loop without its LDS-DMA pieces / fragment reads / wait + barrier
+#ifndef TNW4_ABL_NO_DMA
+#define TNW4_ABL_NO_DMA 0
+#endif
+#ifndef TNW4_ABL_NO_READS
+#define TNW4_ABL_NO_READS 0
+#endif
+#ifndef TNW4_ABL_NO_SYNC
+#define TNW4_ABL_NO_SYNC 0
+#endif
+#ifndef TNW4_DMA_GROUPS
+#define TNW4_DMA_GROUPS 8  // groups of the second half over which the 16 LDS-DMA pieces of a reduction tile are spread: 8, 4 or 2
+#endif
 __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(const GemmTN p) {
   constexpr int NW = 4, BM = 256, BN = 256, PROW = BM * 2, QROW = BN * 2, P_BYTES = BK * PROW, Q_BYTES = BK * QROW, STAGE_BYTES = P_BYTES + Q_BYTES;
   static_assert(STAGE_BYTES == 65536 && PROW == 512, "slot toggle = bit 16 of the LDS address");
@@ -117,7 +130,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(const GemmTN p) {
     lds_wait<0>(pl[0][4], ph[0][4], pl[0][5], ph[0][5], pl[0][6], ph[0][6], pl[0][7], ph[0][7]);
     static_for<0, 8>([&](auto gc) {
       constexpr int i = decltype(gc)::value;
-      TNW4_READ(1, 1, i);
+      if constexpr (!TNW4_ABL_NO_READS) { TNW4_READ(1, 1, i); }
       const op16x8 pf = join_tr(pl[0][i], ph[0][i]);
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[i][j] = TAD_MFMA_16x16x32(join_tr(ql[0][j], qh[0][j]), pf, acc[i][j]);
@@ -135,18 +148,26 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(const GemmTN p) {
     lds_wait<0>(pl[1][0], ph[1][0], pl[1][1], ph[1][1], pl[1][2], ph[1][2], pl[1][3], ph[1][3]);
     lds_wait<0>(pl[1][4], ph[1][4], pl[1][5], ph[1][5], pl[1][6], ph[1][6], pl[1][7], ph[1][7]);
     if constexpr (NEXT) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      block_barrier();
+      if constexpr (!TNW4_ABL_NO_SYNC) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        block_barrier();
+      }
 #pragma unroll
       for (int i = 0; i < 8; ++i) { p_rd[i] ^= (uint32_t)STAGE_BYTES; q_rd[i] ^= (uint32_t)STAGE_BYTES; }
     }
     static_for<0, 8>([&](auto gc) {
       constexpr int i = decltype(gc)::value;
       if constexpr (NEXT2) {
-        TNW4_PIECE(slot, 2 * i, t + 2);
-        TNW4_PIECE(slot, 2 * i + 1, t + 2);
+        // the 16 pieces of the tile after next go out behind the first TNW4_DMA_GROUPS groups (the last piece is needed one half tile
+        // + one tile later: spread over all eight groups it had 0.9 us to land)
+        if constexpr (i < TNW4_DMA_GROUPS && !TNW4_ABL_NO_DMA) {
+          static_for<0, 16 / TNW4_DMA_GROUPS>([&](auto pc) {
+            constexpr int piece = i * (16 / TNW4_DMA_GROUPS) + decltype(pc)::value;
+            TNW4_PIECE(slot, piece, t + 2);
+          });
+        }
       }
-      if constexpr (NEXT) { TNW4_READ(0, 0, i); }
+      if constexpr (NEXT && !TNW4_ABL_NO_READS) { TNW4_READ(0, 0, i); }
       const op16x8 pf = join_tr(pl[1][i], ph[1][i]);
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[i][j] = TAD_MFMA_16x16x32(join_tr(ql[1][j], qh[1][j]), pf, acc[i][j]);
