@@ -65,6 +65,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-all-cores", action="store_true", help="also time the CPU baseline on ALL host cores (a 256-thread pool on a "
                     "batch of 2 oversubscribes: minutes per batch on the pool's 256-core host; off by default)")
+    ap.add_argument("--cpu-baseline-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the all-host-cores leg of the CPU baseline (it is bounded to ~60 s and on by default)")
     ap.add_argument("--linear-schedule", default="auto", choices=["auto", "per-tile", "persistent"], help="world > 1 only: the Linear GEMMs' grid while an "
                     "RCCL kernel may hold CUs (auto = per-tile; parallel.DataParallel)")
@@ -166,10 +167,49 @@ def cpu_baseline(state_dict, frames, reps=3, all_cores=True):
            "sample": f"ViT-B/16 16x224x224 fwd+bwd (CE loss), batch 2, fp32, {r} reps after 1 warm-up, oracle/vit_oracle.py "
                      f"on {n32} of {ncpu} host cores; {dt:.2f} s per batch"}
     if ncpu > n32 and all_cores:
-        r2, dt2 = timed(ncpu)
-        out["all_cores"] = {"value": round(2 / dt2, 4), "unit": "clips/sec", "cores": ncpu, "reps": r2, "s_per_batch": round(dt2, 2),
-                            "note": "same sample on every host core (os.cpu_count() threads); `value` above is the faster-per-core 32-thread pool"}
+        # BASELINE.md section 3 asks for os.cpu_count() threads.  On this batch of two clips a 256-thread pool oversubscribes so badly that
+        # ONE pass can take minutes (196 s measured), so the leg runs in a child process (CPU only: it never touches the GPU) that is
+        # killed after 60 s; what it managed within the limit is what the line carries.
+        import subprocess
+        torch.set_num_threads(n32)
+        try:
+            pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", str(ncpu), "--frames", str(frames)],
+                                capture_output=True, text=True, timeout=60, env={**os.environ, "HIP_VISIBLE_DEVICES": "", "TAD_CPU_CHILD": "1"})
+            d = json.loads(pr.stdout.strip().splitlines()[-1])
+            out["all_cores"] = {"value": round(2 / d["s_per_batch"], 4), "unit": "clips/sec", "cores": ncpu, "reps": d["reps"], "s_per_batch": round(d["s_per_batch"], 2),
+                                "note": "same sample on every host core (os.cpu_count() threads), in a child process; `value` above is the faster-per-core 32-thread pool"}
+        except subprocess.TimeoutExpired:
+            out["all_cores"] = {"value": None, "cores": ncpu, "note": f"one warm-up + one timed pass of the same sample did not finish within 60 s on a {ncpu}-thread pool "
+                                                                       "(oversubscription at batch 2; 196 s per pass measured once): `value` above is the 32-thread pool"}
+        except Exception as e:  # noqa: BLE001
+            out["all_cores"] = {"value": None, "cores": ncpu, "error": repr(e)}
     return out
+
+
+def cpu_baseline_child(threads, frames):
+    """the all-host-cores leg of cpu_baseline, run as `python bench.py --cpu-baseline-child N` by the parent (which kills it after 60 s):
+    the same seeded ViT-B/16 (the module surface constructs on the CPU; the oracle does the arithmetic), 1 warm-up + 1 timed pass"""
+    import torch
+    import simple_tad_amd as T
+    from oracle import vit_oracle as O
+    torch.manual_seed(0)
+    m = T.create_model("vit_base_patch16_224", pretrained=False, num_classes=2, all_frames=frames, tubelet_size=2, final_reduction="fc_norm",
+                       drop_path_rate=0.0, init_scale=0.001, use_flash_attn=True)
+    P = {k: v.detach().float().requires_grad_() for k, v in m.state_dict().items()}
+    torch.manual_seed(0)
+    x = torch.randn(2, 3, frames, 224, 224)
+    y = torch.randint(0, 2, (2,))
+    torch.set_num_threads(threads)
+
+    def one():
+        for p_ in P.values():
+            p_.grad = None
+        torch.nn.functional.cross_entropy(O.forward(x, P, depth=12, num_heads=12, tubelet=2, patch=16), y).backward()
+
+    one()
+    t0 = time.perf_counter()
+    one()
+    print(json.dumps({"s_per_batch": time.perf_counter() - t0, "reps": 1, "threads": threads}), flush=True)
 
 
 # --------------------------------------------------------------------------------------------------------------- parity vs golden G11
@@ -231,6 +271,9 @@ def parity_vs_golden(T, dev, modes, loss_scale=4096.0):
 
 def main():
     args = parse_args()
+    if args.cpu_baseline_child:
+        cpu_baseline_child(args.cpu_baseline_child, args.frames)
+        return
     self_launch(args)
 
     import torch

@@ -119,10 +119,14 @@ int tad_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float*
  * preact [M,N] bf16 (nullable): x W^T + b before GELU (saved for backward).
  * residual [M,N] f32, gamma [N] f32 (nullable), rowscale f32 [ceil(M/rows_per_scale)] (nullable). */
 /* ws (nullable; tad_linear_workspace_bytes(M, N, K) bytes, private to the call's stream until the launches have run): scratch for the
- * split-K form of an under-filled last round of tiles -- an N = 768 Linear at 50176 rows is 588 tiles of 256 x 256 = 2.3 rounds of
- * one workgroup per CU; with a workspace the last 78 tiles run as 3 shares each on 234 CUs (their f32 partial tiles are combined
- * inside the launch) instead of one K loop on 156 CUs.  The launch then needs its grid resident at once: pass NULL while other
- * kernels (an overlapped RCCL exchange) hold CUs.  Results differ from the ws == NULL plan only in the summation order over K. */
+ * split-K form of an under-filled last round of tiles -- a Linear whose 256 x 256 tiles do not fill whole rounds of one workgroup per
+ * CU may run its last tiles as several shares of their K-tiles each, whose f32 partial tiles travel through this buffer.  Two plans:
+ * the default (tad_linear_tuning("splitk_defer", 1)) is THREE launches -- partial tiles, the whole rounds, combine + epilogue -- ordered
+ * by kernel boundaries, with no residency requirement: safe beside other kernels (an overlapped RCCL exchange, side streams).  The
+ * in-launch combine ("splitk_defer", 0; experiments) waits for the other shares of a tile inside ONE launch and needs its whole grid
+ * resident at once: if a share never arrives the kernel gives up, flags it in host-visible memory, and the NEXT tad_linear_* call on
+ * the process returns TAD_ELAUNCH (the output of the affected Linear is invalid).  Results differ from the ws == NULL plan only in the
+ * summation order over K. */
 size_t tad_linear_workspace_bytes(int64_t M, int N, int K);
 int tad_linear_fwd(const uint16_t* x, const uint16_t* w, const float* bias, void* y, int y_dtype,
                    int epilogue, uint16_t* preact, const float* residual, const float* gamma,
@@ -155,6 +159,11 @@ int tad_linear_bwd_weight_qkv(const uint16_t* dy, const uint16_t* x, float* dW, 
  *                     2 = whenever eligible (this one changes the summation order over K of the rows it covers)
  *   "splitk_defer"    1 = a split-K tail runs as three launches -- its partial tiles, the whole rounds, its combine + epilogue -- so
  *                     that the partial tiles travel through memory beside the whole rounds (default); 0 = one launch that combines inside
+ *   "variant"         0 = tile configuration planned per shape (default); 1 / 3 / 2 / 4 / 5 = 256 x 256, 256 x 128, 128 x 128, 128 x 64,
+ *                     64 x 64 tiles for every launch; 7 = the four-wave 256 x 256 kernels (128 x 128 outputs per wave, one wave per SIMD;
+ *                     csrc/gemm_w4.hip) -- all bit-identical
+ *   "tn_w4"           1 = the 256 x 256 weight-gradient GEMM runs as four waves of 128 x 128 outputs (default; bit-identical, 8 % faster);
+ *                     0 = eight waves of 128 x 64
  *   "tn_pdeep"        1 = the weight-gradient GEMM requests its dy operand two reduction tiles ahead (three-slot ring, the whole
  *                     160 KiB of LDS); 0 = two-stage ring (default: measured equal) */
 int tad_linear_tuning(const char* key, int value);
@@ -176,7 +185,7 @@ int tad_linear_bwd_weight(const uint16_t* dy, const uint16_t* x, float* dW, floa
  * replaces Attention._naive_attn's q@k^T/softmax/attn@v (modeling_finetune.py:96-103) and
  * FlashAttention.forward -> flash_attn_varlen_qkvpacked_func (flash_attention_class.py:47-50)
  * with equal-length sequences (cu_seqlens = arange(0,(B+1)N,N)).
- * qkv [B,N,3,H,d] bf16 packed (the qkv Linear's output, column order [3][H][d]); d must be 64.
+ * qkv [B,N,3,H,d] bf16 packed (the qkv Linear's output, column order [3][H][d]); d = 64 or 80 (the `d` argument).
  * out [B,N,H,d] in out_dtype; lse [B,H,N] f32 = log(sum_j exp(scale * q.k_j)) (natural log).
  * out_lo (nullable, 16-bit outputs only): [B,N,H,d] = what the rounding of out dropped (out + out_lo carries 16 / 22 significant
  * bits), for tad_attn_bwd's delta.

@@ -1,17 +1,24 @@
 #!/bin/bash
 # The whole profiles/<round>_* set from ONE gpurun call on the final tree (run ON the GPU box from the repo root):
-#   tools/collect_final.sh r04
+#   tools/collect_final.sh r05
 # Order matters: the in-kernel clock (ablation build, made in the build container beforehand) and the rocprofv3 summaries are
 # installed into profiles/ BEFORE `python bench.py` runs, so the bench line's `from_profiles` entries are current for the sources
 # it runs on.  Everything is written under gpurun_out/<round>_final/profiles/ too (what travels back).
 set -o pipefail
-R="${1:-r04}"; O="gpurun_out/${R}_final"; P="$O/profiles"; mkdir -p "$P"; export TMPDIR=/tmp
+R="${1:-r05}"; O="gpurun_out/${R}_final"; P="$O/profiles"; mkdir -p "$P"; export TMPDIR=/tmp
 if [ -f simple_tad_amd/libtad_ablation.so ]; then
   TAD_LIB=simple_tad_amd/libtad_ablation.so timeout -k 10 300 python3 tools/exp_clock.py --out "$P/${R}_clock.json" > "$O/clock.log" 2>&1 || { echo "clock failed"; tail -5 "$O/clock.log"; exit 1; }
   cp "$P/${R}_clock.json" profiles/
 fi
+if [ -f simple_tad_amd/libtad_ablation.so ]; then  # the IEEE-half twins' clock: not read by bench.py, kept beside the bf16 one
+  TAD_LIB=simple_tad_amd/libtad_ablation.so timeout -k 10 300 python3 tools/exp_clock.py --dtype f16 --out "$P/${R}_clock_f16.json" > "$O/clock_f16.log" 2>&1 && cp "$P/${R}_clock_f16.json" profiles/ || echo "f16 clock failed"
+fi
 echo "[collect_final] clock done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > "$O/kt.log" 2>&1 || { echo "kernel trace failed"; tail -5 "$O/kt.log"; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt_half" -- python3 bench.py --precision half --steps 10 --warmup 3 --no-cpu-baseline --no-extras > "$O/kt_half.log" 2>&1 \
+  && python3 tools/summarize_profile.py --round "${R}_half" --kt "$O/kt_half" --steps 13 --warmup 3 --out "$O" --cmd "python3 bench.py --precision half --steps 10 --warmup 3 --no-cpu-baseline --no-extras" > "$O/summarize_half.log" 2>&1 \
+  && cp "$O/${R}_half_kernel_stats.txt" "profiles/${R}_kernel_stats_half.txt" && cp "$O/${R}_half_kernel_stats.txt" "$P/${R}_kernel_stats_half.txt" || echo "half kernel trace failed"
+find "$O/kt_half" -name "*.csv" -size +8M -delete 2>/dev/null
 echo "[collect_final] kernel trace done"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O/fetch" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-live-profile --no-extras > "$O/fetch.log" 2>&1 || { echo "FETCH pass failed"; tail -5 "$O/fetch.log"; exit 1; }
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O/write" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-live-profile --no-extras > "$O/write.log" 2>&1 || { echo "WRITE pass failed"; tail -5 "$O/write.log"; exit 1; }
