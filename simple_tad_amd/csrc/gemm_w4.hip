@@ -40,6 +40,12 @@ __device__ __forceinline__ void mfma_16x16x32_vgpr(f32x4& d, const op16x8& a, co
 #ifndef TNW4_ABL_NO_SYNC
 #define TNW4_ABL_NO_SYNC 0
 #endif
+#ifndef TNW4_2BAR
+#define TNW4_2BAR 1  // 1: TWO barriers per reduction tile (top and half) and ONE LDS-DMA piece behind every fragment group of BOTH halves -- the
+                     // k-step-0 rows of a ring slot are released at the top of the tile, the k-step-1 rows at the half, so the tile after next
+                     // streams into them as they become free and every wait leaves a whole tile's pieces (16) in flight; 0: one barrier, the 16
+                     // pieces behind the groups of the second half, vmcnt(0)
+#endif
 #ifndef TNW4_DMA_GROUPS
 #define TNW4_DMA_GROUPS 8  // groups of the second half over which the 16 LDS-DMA pieces of a reduction tile are spread: 8, 4 or 2
 #endif
@@ -108,8 +114,14 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(const GemmTN p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  static_for<0, 16>([&](auto ic) { TNW4_PIECE(0, decltype(ic)::value, 0); });
-  static_for<0, 16>([&](auto ic) { TNW4_PIECE(STAGE_BYTES, decltype(ic)::value, 1); });
+  // piece order inside a tile: the k-step-0 rows first (P pieces 0..3, Q pieces 0..3 of this wave), then the k-step-1 rows -- vmcnt counts in
+  // issue order, and the k-step-0 rows are needed half a tile earlier
+#define TNW4_K0IDX(g) ((g) < 4 ? (g) : 8 + ((g) - 4))
+#define TNW4_K1IDX(g) ((g) < 4 ? 4 + (g) : 12 + ((g) - 4))
+  static_for<0, 8>([&](auto ic) { TNW4_PIECE(0, TNW4_K0IDX(decltype(ic)::value), 0); });
+  static_for<0, 8>([&](auto ic) { TNW4_PIECE(0, TNW4_K1IDX(decltype(ic)::value), 0); });
+  static_for<0, 8>([&](auto ic) { TNW4_PIECE(STAGE_BYTES, TNW4_K0IDX(decltype(ic)::value), 1); });
+  static_for<0, 8>([&](auto ic) { TNW4_PIECE(STAGE_BYTES, TNW4_K1IDX(decltype(ic)::value), 1); });
   asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
   block_barrier();
   s16x4 pl[2][8], ph[2][8], ql[2][8], qh[2][8];  // [fragment set = k-step][fragment]: the two 8-byte halves of a fragment
@@ -128,8 +140,16 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(const GemmTN p) {
     lds_wait<0>(ql[0][4], qh[0][4], ql[0][5], qh[0][5], ql[0][6], qh[0][6], ql[0][7], qh[0][7]);
     lds_wait<0>(pl[0][0], ph[0][0], pl[0][1], ph[0][1], pl[0][2], ph[0][2], pl[0][3], ph[0][3]);
     lds_wait<0>(pl[0][4], ph[0][4], pl[0][5], ph[0][5], pl[0][6], ph[0][6], pl[0][7], ph[0][7]);
+    if constexpr (TNW4_2BAR && !TNW4_ABL_NO_SYNC) {
+      // top of the tile: every wave holds this tile's k-step-0 fragments -> those rows of the slot are free; this tile's k-step-1 rows
+      // (requested two tiles ago, 16 younger pieces behind them) have landed
+      if constexpr (NEXT2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      block_barrier();
+    }
     static_for<0, 8>([&](auto gc) {
       constexpr int i = decltype(gc)::value;
+      if constexpr (TNW4_2BAR && NEXT2 && !TNW4_ABL_NO_DMA) { TNW4_PIECE(slot, TNW4_K0IDX(i), t + 2); }
       if constexpr (!TNW4_ABL_NO_READS) { TNW4_READ(1, 1, i); }
       const op16x8 pf = join_tr(pl[0][i], ph[0][i]);
 #pragma unroll
@@ -149,7 +169,8 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(const GemmTN p) {
     lds_wait<0>(pl[1][4], ph[1][4], pl[1][5], ph[1][5], pl[1][6], ph[1][6], pl[1][7], ph[1][7]);
     if constexpr (NEXT) {
       if constexpr (!TNW4_ABL_NO_SYNC) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (TNW4_2BAR && NEXT2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // (the next tile's k-step-0 rows; 16 younger pieces stay in flight)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         block_barrier();
       }
 #pragma unroll
@@ -160,7 +181,9 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(const GemmTN p) {
       if constexpr (NEXT2) {
         // the 16 pieces of the tile after next go out behind the first TNW4_DMA_GROUPS groups (the last piece is needed one half tile
         // + one tile later: spread over all eight groups it had 0.9 us to land)
-        if constexpr (i < TNW4_DMA_GROUPS && !TNW4_ABL_NO_DMA) {
+        if constexpr (TNW4_2BAR) {
+          if constexpr (!TNW4_ABL_NO_DMA) { TNW4_PIECE(slot, TNW4_K1IDX(i), t + 2); }
+        } else if constexpr (i < TNW4_DMA_GROUPS && !TNW4_ABL_NO_DMA) {
           static_for<0, 16 / TNW4_DMA_GROUPS>([&](auto pc) {
             constexpr int piece = i * (16 / TNW4_DMA_GROUPS) + decltype(pc)::value;
             TNW4_PIECE(slot, piece, t + 2);
