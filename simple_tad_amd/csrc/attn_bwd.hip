@@ -317,6 +317,11 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_bwd_dq_kernel(cons
 #undef DMA_KV
 
 // ------------------------------------------------------------------------------------------------ dK, dV
+#ifndef TAD_DKV_STREAM
+#define TAD_DKV_STREAM 0  // 1: head_dim 64 streams the tile after next into the ring in two batches (see STREAM in attn_bwd_dkv_kernel).  Measured in
+                          // round 5 (tools/ab_attn.py, same results): backward pair 832.6 us without, 836.1 with -- the wait in front of the tile
+                          // barrier is wave skew, not DMA latency (the scheme that gave the four-wave weight-gradient GEMM 6 %); off
+#endif
 #ifndef TAD_DKV_ABL
 #define TAD_DKV_ABL 0  // timing experiments (experiments/README.md, round 4): 1 = a quarter of the row-constant LDS reads
 #endif
@@ -404,6 +409,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
     }                                                                                                      \
   }
 #define LOAD_QDO(buf, q0) { LOAD_Q_(buf, q0); LOAD_DO_RC_(buf, q0); }
+  // STREAM (head_dim 64): the Q / dO rows of a tile travel as TWO batches -- rows 0..31 (piece 0 of Q and of dO per wave) and rows 32..63
+  // (piece 1 of each, plus the row constants of the whole tile) -- and the tile after next streams into a ring slot as each half of it is
+  // released: rows 0..31 behind a barrier between the two half tiles, rows 32..63 behind the barrier at the end of the tile.  Every piece has
+  // at least one and a half tiles to land, and the one wait of a tile is counted (vmcnt(2): the batch requested half a tile ago stays in
+  // flight) instead of vmcnt(0) on a tile requested one tile ago.
+#define LOAD_HALF0_(buf, q0)                                                                                                   \
+  {                                                                                                                            \
+    char* ql_ = lds + (buf) * STAGE;                                                                                           \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_qkv, LDS_PTR(ql_ + wave * 1024), 16, dma_q[0] + (uint32_t)(q0) * q_step, 0, 0, 0);              \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_do, LDS_PTR(ql_ + TILE_BYTES + wave * 1024), 16, dma_do[0] + (uint32_t)(q0) * do_step, 0, 0, 0); \
+  }
+#define LOAD_HALF1_(buf, q0)                                                                                                   \
+  {                                                                                                                            \
+    char* ql_ = lds + (buf) * STAGE;                                                                                           \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_qkv, LDS_PTR(ql_ + (wave + 4) * 1024), 16, dma_q[1] + (uint32_t)(q0) * q_step, 0, 0, 0);              \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_do, LDS_PTR(ql_ + TILE_BYTES + (wave + 4) * 1024), 16, dma_do[1] + (uint32_t)(q0) * do_step, 0, 0, 0); \
+    if (wave < 2) /* wave-uniform */                                                                                           \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_rc, LDS_PTR(ql_ + 2 * TILE_BYTES + wave * 256), 4, rc_off + (uint32_t)(q0) * 4u, 0, 0, 0); \
+  }
 
   f32x16 dk[NDT], dv[NDT];  // (HD 80: of dk[2] / dv[2] only rows 0..15 = dims 64..79 mean something)
 #pragma unroll
@@ -429,7 +453,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
   const uint32_t qtr_s = lds0 + (uint32_t)(SIDE_OFF + (4 * (lane >> 5) + ((lane & 15) >> 2)) * 32 + 8 * (lane & 3));
 
   const int nt = (N + 63) / 64;
+  constexpr bool STREAM = TAD_DKV_STREAM && !X && DMA_MODE == 0;
   LOAD_QDO(0, 0);
+  if (STREAM && 1 < nt) { LOAD_HALF0_(1, 64); LOAD_HALF1_(1, 64); }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   asm volatile("" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -448,10 +474,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
     const bool more = t + 1 < nt;     // is there a tile to request during this one?
     constexpr int nbuf = BUF ^ 1;     // its ring slot ...
     const int nq0 = (t + 1) * 64;     // ... and first query row
-    if (more && DMA_MODE == 0) LOAD_QDO(nbuf, nq0);
-    if (wave_live)  // (see the dQ kernel: waves whose 32 keys all lie past the sequence only stage tiles)
+    if (more && DMA_MODE == 0 && !STREAM) LOAD_QDO(nbuf, nq0);
+    const bool more2 = t + 2 < nt;  // (STREAM) is there a tile after next to request into this slot?
     static_for<0, 2>([&](auto qtc) {
       constexpr int qt = decltype(qtc)::value;
+      if constexpr (STREAM && qt == 1) {
+        // every wave is done with rows 0..31 of this slot (their fragments were consumed by the first half tile's MFMAs): the tile
+        // after next starts to stream into them
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (more2) LOAD_HALF0_(BUF, (t + 2) * 64);
+      }
+      if (!wave_live) return;  // (see the dQ kernel: waves whose 32 keys all lie past the sequence only stage tiles)
       constexpr int HT = qt * 32 * 128;  // byte offset of the half tile inside a tile
       if (t * 64 + 32 * qt >= N) return;  // half tile of query rows past the sequence: P = dS = 0 there anyway
       // batch 1: initial accumulators (per-row constants; accumulator register r <-> row (r&3) + 8*(r>>2) + 4*h5) and row fragments
@@ -565,8 +600,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
 #undef TR_ISSUE
 #undef TR_MFMA
     });
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if constexpr (STREAM) {
+      // the next tile has landed (its second batch was requested a whole tile ago; only the two pieces requested between the half tiles
+      // of this one may still be in flight); every wave is done with this slot: its rows 32..63 and row constants take the tile after next
+      if (more2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (more2) LOAD_HALF1_(BUF, (t + 2) * 64);
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
   };
   for (int t = 0; t < nt; t += 2) {
     dkv_tile(std::integral_constant<int, 0>{}, t);
