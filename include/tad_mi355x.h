@@ -162,6 +162,8 @@ int tad_linear_bwd_weight_qkv(const uint16_t* dy, const uint16_t* x, float* dW, 
  *   "variant"         0 = tile configuration planned per shape (default); 1 / 3 / 2 / 4 / 5 = 256 x 256, 256 x 128, 128 x 128, 128 x 64,
  *                     64 x 64 tiles for every launch; 7 = the four-wave 256 x 256 kernels (128 x 128 outputs per wave, one wave per SIMD;
  *                     csrc/gemm_w4.hip) -- all bit-identical
+ *   "w4_plain"        K_min > 0: bias-only Linears whose reduction is at least K_min long run their whole rounds of 256 x 256 tiles on the
+ *                     four-wave kernel (default 128; bit-identical, 5-8 % faster on the N = 768 input-gradient Linears); 0 = eight waves
  *   "tn_w4"           1 = the 256 x 256 weight-gradient GEMM runs as four waves of 128 x 128 outputs (default; bit-identical, 8 % faster);
  *                     0 = eight waves of 128 x 64
  *   "tn_pdeep"        1 = the weight-gradient GEMM requests its dy operand two reduction tiles ahead (three-slot ring, the whole

@@ -1279,12 +1279,15 @@ int nt_splitk = getenv("TAD_GEMM_SPLITK_TAIL") ? env_int("TAD_GEMM_SPLITK_TAIL")
 int nt_variant = env_int("TAD_GEMM_NT_VARIANT");  // 0 = planned per shape (launch_gemm_nt), else the tile configuration for every launch
 int nt_group_m_knob = getenv("TAD_GEMM_GROUP_M") ? env_int("TAD_GEMM_GROUP_M") : 0;  // 0 = per-shape choice (nt_group_m)
 int tn_variant = env_int("TAD_GEMM_TN_VARIANT");
+// > 0: bias-only Linears with K >= this run their whole rounds on the four-wave kernel.  Measured (tools/exp_w4_plain.py, planned launches at M = 50176):
+// qkv forward 176.9 / 177.2 us (eight / four waves), dX(proj) 78.0 / 73.9, dX(qkv) 159.0 / 148.4, dX(fc1) 225.4 / 208.5 -- on by default
+int nt_w4_plain = getenv("TAD_GEMM_W4_PLAIN") ? env_int("TAD_GEMM_W4_PLAIN") : 128;
 int tn_w4 = getenv("TAD_GEMM_TN_W4") ? env_int("TAD_GEMM_TN_W4") : 1;  // 1: the 256 x 256 weight-gradient GEMM runs as four waves of 128 x 128 (gemm_w4.hip)
 int tn_pdeep = env_int("TAD_GEMM_TN_PDEEP");  // 1: gemm_tn 256 x 256 with the P operand two reduction tiles ahead (see PDEEP); measured null (round 4), off
 unsigned long long* nt_stamps = nullptr;
 long long nt_launches = 0;  // gemm_nt kernel launches so far (tad_linear_kernel_launches)
 #else
-extern int gemm_debug, nt_persist, nt_direct, nt_split, nt_splitk, nt_variant, nt_group_m_knob, tn_variant, tn_pdeep, nt_sk_defer, tn_w4;
+extern int gemm_debug, nt_persist, nt_direct, nt_split, nt_splitk, nt_variant, nt_group_m_knob, tn_variant, tn_pdeep, nt_sk_defer, tn_w4, nt_w4_plain;
 extern unsigned long long* nt_stamps;
 extern long long nt_launches;
 #endif
@@ -1489,6 +1492,13 @@ static double nt_cost(int v, int epi, int c_bf16, int M, int N, int K) {
   return (double)((tiles + 2 * cus - 1) / (2 * cus)) * (nk * 1.3 + 5.0) + 3.0;
 }
 
+// Which 256 x 256 kernel runs the whole rounds of a planned launch: the eight-wave one (1), or -- tad_linear_tuning("w4_plain", K_min): for
+// bias-only epilogues whose reduction is at least K_min long -- the four-wave one (7), whose faster K loop outweighs its slower epilogue only
+// on long reductions (csrc/gemm_w4.hip; bit-identical either way)
+static int nt_main_variant(const GemmNT& p) {
+  return (nt_w4_plain > 0 && p.epi == EPI_PLAIN && p.K >= nt_w4_plain && p.K >= 2 * BK) ? 7 : 1;
+}
+
 int launch_gemm_nt(const GemmNT& p_in, hipStream_t st, void* ws = nullptr, size_t ws_bytes = 0) {
   GemmNT p = p_in;
   if (const int rc = sk_check_pending_error()) return rc;
@@ -1564,17 +1574,17 @@ int launch_gemm_nt(const GemmNT& p_in, hipStream_t st, void* ws = nullptr, size_
     if (tail_splits && nt_sk_defer) {  // partial tiles of the tail | whole rounds | combine + epilogue of the tail
       int rc = launch_gemm_nt_splitk(t, tail_splits, ws, st, 1);
       if (rc) return rc;
-      rc = launch_gemm_nt_one(row_range(p, 0, main_rows), 1, st);
+      rc = launch_gemm_nt_one(row_range(p, 0, main_rows), nt_main_variant(p), st);
       if (rc) return rc;
       return launch_gemm_nt_splitk(t, tail_splits, ws, st, 2);
     }
-    int rc = launch_gemm_nt_one(row_range(p, 0, main_rows), 1, st);
+    int rc = launch_gemm_nt_one(row_range(p, 0, main_rows), nt_main_variant(p), st);
     if (rc) return rc;
     if (tail_splits) return launch_gemm_nt_splitk(t, tail_splits, ws, st);
     if (t.M < 2048) return launch_gemm_nt_one(t, 2, st);
     return launch_gemm_nt_one(t, nt_cost(1, t.epi, t.c_bf16, t.M, t.N, t.K) < nt_cost(3, t.epi, t.c_bf16, t.M, t.N, t.K) ? 1 : 3, st);
   }
-  return launch_gemm_nt_one(p, cost_b < cost_a ? 1 : 3, st);
+  return launch_gemm_nt_one(p, cost_b < cost_a ? nt_main_variant(p) : 3, st);
 }
 
 // TN: 1 = 256x256 (2x4) 2 stages; 3 = 256x128 (4x2) 3 stages.  Splits over the reduction dim target ~1 workgroup per CU.
@@ -1729,6 +1739,7 @@ int tad_linear_tuning(const char* key, int value) {
   else if (k == "group_m") { TAD_REQUIRE(value >= 0 && value <= 1024, "linear_tuning: group_m=%d out of range", value); nt_group_m_knob = value; }
   else if (k == "variant") { TAD_REQUIRE(value >= 0 && value <= 7 && value != 6, "linear_tuning: variant=%d not one of 0..5, 7", value); nt_variant = value; }
   else if (k == "splitk_defer") { TAD_REQUIRE(value == 0 || value == 1, "linear_tuning: splitk_defer=%d not in {0, 1}", value); nt_sk_defer = value; }
+  else if (k == "w4_plain") { TAD_REQUIRE(value >= 0, "linear_tuning: w4_plain=%d must be >= 0", value); nt_w4_plain = value; }
   else if (k == "tn_w4") { TAD_REQUIRE(value == 0 || value == 1, "linear_tuning: tn_w4=%d not in {0, 1}", value); tn_w4 = value; }
   else if (k == "tn_pdeep") { TAD_REQUIRE(value == 0 || value == 1, "linear_tuning: tn_pdeep=%d not in {0, 1}", value); tn_pdeep = value; }
   else if (k == "split_tail") { TAD_REQUIRE(value >= 0 && value <= 2, "linear_tuning: split_tail=%d not in 0..2", value); nt_split = value; }
