@@ -164,6 +164,8 @@ int tad_linear_bwd_weight_qkv(const uint16_t* dy, const uint16_t* x, float* dW, 
  *                     csrc/gemm_w4.hip) -- all bit-identical
  *   "w4_plain"        K_min > 0: bias-only Linears whose reduction is at least K_min long run their whole rounds of 256 x 256 tiles on the
  *                     four-wave kernel (default 128; bit-identical, 5-8 % faster on the N = 768 input-gradient Linears); 0 = eight waves
+ *   "w4_epilogues"    bit mask of the other epilogues whose whole rounds take the four-wave kernel: bit 1 GELU, 2 residual with f32 output
+ *                     (default: 4), 3 GELU backward
  *   "tn_w4"           1 = the 256 x 256 weight-gradient GEMM runs as four waves of 128 x 128 outputs (default; bit-identical, 8 % faster);
  *                     0 = eight waves of 128 x 64
  *   "tn_pdeep"        1 = the weight-gradient GEMM requests its dy operand two reduction tiles ahead (three-slot ring, the whole

@@ -512,8 +512,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
           for (int q = 0; q < 4; ++q) { a_ad[ks][q] ^= (uint32_t)STAGE_BYTES; b_ad[ks][q] ^= (uint32_t)STAGE_BYTES; }
-      } else if constexpr (HAS_EXTRA) {
-        ISSUE_EXTRA(0, 0);  // (last K-tile) what the epilogue's first chunk reads besides the accumulators
       }
       static_for<0, 8>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
@@ -535,6 +533,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
     for (; kt + 2 < nk; ++kt) w4_tile(std::true_type{}, std::true_type{}, kt);
     w4_tile(std::true_type{}, std::false_type{}, kt);
     w4_tile(std::false_type{}, std::false_type{}, kt + 1);
+    // what the epilogue's first chunk reads besides the accumulators: requested BEHIND the K loop here, not inside its last K-tile as in the
+    // eight-wave kernels -- beside two live fragment sets the prefetch registers made the residual / DGELU instantiations spill
+    if constexpr (HAS_EXTRA) { ISSUE_EXTRA(0, 0); }
     // (persistent: the address registers must point at slot 0 again for the next tile, whose K-tile 0 lands there)
     if ((nk & 1) == 0) {
 #pragma unroll
@@ -1282,12 +1283,16 @@ int tn_variant = env_int("TAD_GEMM_TN_VARIANT");
 // > 0: bias-only Linears with K >= this run their whole rounds on the four-wave kernel.  Measured (tools/exp_w4_plain.py, planned launches at M = 50176):
 // qkv forward 176.9 / 177.2 us (eight / four waves), dX(proj) 78.0 / 73.9, dX(qkv) 159.0 / 148.4, dX(fc1) 225.4 / 208.5 -- on by default
 int nt_w4_plain = getenv("TAD_GEMM_W4_PLAIN") ? env_int("TAD_GEMM_W4_PLAIN") : 128;
+// bit mask: which other epilogues' whole rounds take the four-wave kernel (see nt_main_variant).  Measured (tools/exp_gemm_knobs.py --configs
+// "w4_epilogues=0;w4_epilogues=14", eight / four waves): proj + residual 96.0 / 96.9 us, fc2 + residual 250.4 / 241.1, fc1 GELU 278.1 / 282.1, dX(fc2) GELU backward
+// 291.2 / 338.8 -- the residual epilogue (bit 2) is on by default, the vector-heavy GELU ones stay on eight waves
+int nt_w4_epilogues = getenv("TAD_GEMM_W4_EPILOGUES") ? env_int("TAD_GEMM_W4_EPILOGUES") : 4;
 int tn_w4 = getenv("TAD_GEMM_TN_W4") ? env_int("TAD_GEMM_TN_W4") : 1;  // 1: the 256 x 256 weight-gradient GEMM runs as four waves of 128 x 128 (gemm_w4.hip)
 int tn_pdeep = env_int("TAD_GEMM_TN_PDEEP");  // 1: gemm_tn 256 x 256 with the P operand two reduction tiles ahead (see PDEEP); measured null (round 4), off
 unsigned long long* nt_stamps = nullptr;
 long long nt_launches = 0;  // gemm_nt kernel launches so far (tad_linear_kernel_launches)
 #else
-extern int gemm_debug, nt_persist, nt_direct, nt_split, nt_splitk, nt_variant, nt_group_m_knob, tn_variant, tn_pdeep, nt_sk_defer, tn_w4, nt_w4_plain;
+extern int gemm_debug, nt_persist, nt_direct, nt_split, nt_splitk, nt_variant, nt_group_m_knob, tn_variant, tn_pdeep, nt_sk_defer, tn_w4, nt_w4_plain, nt_w4_epilogues;
 extern unsigned long long* nt_stamps;
 extern long long nt_launches;
 #endif
@@ -1496,7 +1501,11 @@ static double nt_cost(int v, int epi, int c_bf16, int M, int N, int K) {
 // bias-only epilogues whose reduction is at least K_min long -- the four-wave one (7), whose faster K loop outweighs its slower epilogue only
 // on long reductions (csrc/gemm_w4.hip; bit-identical either way)
 static int nt_main_variant(const GemmNT& p) {
-  return (nt_w4_plain > 0 && p.epi == EPI_PLAIN && p.K >= nt_w4_plain && p.K >= 2 * BK) ? 7 : 1;
+  if (p.K < 2 * BK) return 1;
+  if (p.epi == EPI_PLAIN) return (nt_w4_plain > 0 && p.K >= nt_w4_plain) ? 7 : 1;
+  // the other epilogues: tad_linear_tuning("w4_epilogues", mask) -- bit 1 GELU, 2 residual (f32 output), 3 GELU backward
+  const int bit = p.epi == EPI_GELU ? 1 : (p.epi == EPI_RESIDUAL && !p.c_bf16 && p.res_mod <= 0) ? 2 : p.epi == EPI_DGELU ? 3 : -1;
+  return (bit > 0 && ((nt_w4_epilogues >> bit) & 1)) ? 7 : 1;
 }
 
 int launch_gemm_nt(const GemmNT& p_in, hipStream_t st, void* ws = nullptr, size_t ws_bytes = 0) {
@@ -1739,6 +1748,7 @@ int tad_linear_tuning(const char* key, int value) {
   else if (k == "group_m") { TAD_REQUIRE(value >= 0 && value <= 1024, "linear_tuning: group_m=%d out of range", value); nt_group_m_knob = value; }
   else if (k == "variant") { TAD_REQUIRE(value >= 0 && value <= 7 && value != 6, "linear_tuning: variant=%d not one of 0..5, 7", value); nt_variant = value; }
   else if (k == "splitk_defer") { TAD_REQUIRE(value == 0 || value == 1, "linear_tuning: splitk_defer=%d not in {0, 1}", value); nt_sk_defer = value; }
+  else if (k == "w4_epilogues") { TAD_REQUIRE(value >= 0 && value < 16, "linear_tuning: w4_epilogues=%d not a mask of bits 1..3", value); nt_w4_epilogues = value; }
   else if (k == "w4_plain") { TAD_REQUIRE(value >= 0, "linear_tuning: w4_plain=%d must be >= 0", value); nt_w4_plain = value; }
   else if (k == "tn_w4") { TAD_REQUIRE(value == 0 || value == 1, "linear_tuning: tn_w4=%d not in {0, 1}", value); tn_w4 = value; }
   else if (k == "tn_pdeep") { TAD_REQUIRE(value == 0 || value == 1, "linear_tuning: tn_pdeep=%d not in {0, 1}", value); tn_pdeep = value; }
