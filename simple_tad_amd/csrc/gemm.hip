@@ -188,7 +188,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
   // EPI_DB (persistent 256 x 256 kernel): TWO chunk buffers of 32 rows, the accumulators of chunk q + 1 are dropped into one while the row
   // pass of chunk q reads the other -- one barrier per chunk instead of two, and the LDS writes run beside the row pass
   constexpr bool EPI_DB = TAD_EPI_DB && PERSIST && !DIRECT && !SPLITK && BM == 256 && BN == 256 && NW == 8;
-  constexpr int CROWS = EPI_DB ? 32 : BM < 128 ? BM : (((BN > 128 || (NW == 4 && BM == 256)) && IS_RES && !OUT_BF16) ? 32 : (((PERSIST && BN > 128) || NW == 4) ? 64 : 128));
+  constexpr int CROWS = EPI_DB ? 32 : BM < 128 ? BM : BM == 192 ? 64 : (((BN > 128 || (NW == 4 && BM == 256)) && IS_RES && !OUT_BF16) ? 32 : (((PERSIST && BN > 128) || NW == 4) ? 64 : 128));
   constexpr int EPI_OFF = PERSIST ? STAGE_BYTES : 0;
   constexpr int EPI_BYTES = DIRECT ? 0 : (EPI_DB ? 2 : 1) * CROWS * (BN * 4 + 16);
   constexpr int LDS_BYTES = STAGES * STAGE_BYTES > EPI_OFF + EPI_BYTES ? STAGES * STAGE_BYTES : EPI_OFF + EPI_BYTES;
@@ -1287,12 +1287,13 @@ int nt_w4_plain = getenv("TAD_GEMM_W4_PLAIN") ? env_int("TAD_GEMM_W4_PLAIN") : 1
 // "w4_epilogues=0;w4_epilogues=14", eight / four waves): proj + residual 96.0 / 96.9 us, fc2 + residual 250.4 / 241.1, fc1 GELU 278.1 / 282.1, dX(fc2) GELU backward
 // 291.2 / 338.8 -- the residual epilogue (bit 2) is on by default, the vector-heavy GELU ones stay on eight waves
 int nt_w4_epilogues = getenv("TAD_GEMM_W4_EPILOGUES") ? env_int("TAD_GEMM_W4_EPILOGUES") : 4;
+int nt_tail_192 = getenv("TAD_GEMM_TAIL_192") ? env_int("TAD_GEMM_TAIL_192") : 1;  // 1: tails of the split plan may run as 192 x 128 tiles (nt_tail_variant)
 int tn_w4 = getenv("TAD_GEMM_TN_W4") ? env_int("TAD_GEMM_TN_W4") : 1;  // 1: the 256 x 256 weight-gradient GEMM runs as four waves of 128 x 128 (gemm_w4.hip)
 int tn_pdeep = env_int("TAD_GEMM_TN_PDEEP");  // 1: gemm_tn 256 x 256 with the P operand two reduction tiles ahead (see PDEEP); measured null (round 4), off
 unsigned long long* nt_stamps = nullptr;
 long long nt_launches = 0;  // gemm_nt kernel launches so far (tad_linear_kernel_launches)
 #else
-extern int gemm_debug, nt_persist, nt_direct, nt_split, nt_splitk, nt_variant, nt_group_m_knob, tn_variant, tn_pdeep, nt_sk_defer, tn_w4, nt_w4_plain, nt_w4_epilogues;
+extern int gemm_debug, nt_persist, nt_direct, nt_split, nt_splitk, nt_variant, nt_group_m_knob, tn_variant, tn_pdeep, nt_sk_defer, tn_w4, nt_w4_plain, nt_w4_epilogues, nt_tail_192;
 extern unsigned long long* nt_stamps;
 extern long long nt_launches;
 #endif
@@ -1348,6 +1349,9 @@ static void launch_nt_variant(int v, GemmNT& p, hipStream_t st) {
       (void)launch_gemm_nt_w4(p, per7 ? grid_p : 0, st);
       break;
     }
+    case 8:  // 192 x 128 (4 x 2 waves, 3 stages): tails of the split plan whose 256 x 128 tiles would leave > a third of the CUs idle
+      if (direct) NT_LAUNCH(192, 128, 4, 2, 3, false, true, tiles(192, 128), 512); else NT_LAUNCH(192, 128, 4, 2, 3, false, false, tiles(192, 128), 512);
+      break;
     case 4:
       if (direct) NT_LAUNCH(128, 64, 2, 2, 2, false, true, tiles(128, 64), 256); else NT_LAUNCH(128, 64, 2, 2, 2, false, false, tiles(128, 64), 256);
       break;
@@ -1493,8 +1497,23 @@ static double nt_cost(int v, int epi, int c_bf16, int M, int N, int K) {
     const int64_t tiles = (int64_t)((M + 255) / 256) * ((N + 127) / 128);
     return (double)((tiles + cus - 1) / cus) * (nk * 1.06 + epi_us) + 3.0;
   }
+  if (v == 8) {  // 192 x 128: 7 / 8 of the 256 x 128 tile's time per K-tile for 3 / 4 of its rows (tools/exp_tail_tile.py)
+    const double epi_us = (epi == EPI_GELU || epi == EPI_DGELU) ? 4.5 : (epi == EPI_RESIDUAL ? 5.5 : 2.5);
+    const int64_t tiles = (int64_t)((M + 191) / 192) * ((N + 127) / 128);
+    return (double)((tiles + cus - 1) / cus) * (nk * 0.93 + epi_us) + 3.0;
+  }
   const int64_t tiles = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
   return (double)((tiles + 2 * cus - 1) / (2 * cus)) * (nk * 1.3 + 5.0) + 3.0;
+}
+// The tile of a tail launch of the split plan (a problem of at least 2048 rows that fills less than a round of 256 x 256 tiles): 256 x 256,
+// 256 x 128, or -- tad_linear_tuning("tail_192", 1), default -- 192 x 128 where that puts more CUs to work (ViT-B's N = 768 Linears:
+// 6656 rows = 156 tiles of 256 x 128 on 256 CUs, or 210 of 192 x 128: the five tails of a block 146.4 -> 132.9 us, bit-identical)
+static int nt_tail_variant(const GemmNT& t) {
+  const double c1 = nt_cost(1, t.epi, t.c_bf16, t.M, t.N, t.K), c3 = nt_cost(3, t.epi, t.c_bf16, t.M, t.N, t.K);
+  const double c8 = nt_tail_192 ? nt_cost(8, t.epi, t.c_bf16, t.M, t.N, t.K) : 1e300;
+  const bool v1_ok = !(t.epi == EPI_RESIDUAL && (t.c_bf16 || t.res_mod > 0));
+  if (c8 < c3 && (c8 < c1 || !v1_ok)) return 8;
+  return (c1 < c3 && v1_ok) ? 1 : 3;
 }
 
 // Which 256 x 256 kernel runs the whole rounds of a planned launch: the eight-wave one (1), or -- tad_linear_tuning("w4_plain", K_min): for
@@ -1566,7 +1585,7 @@ int launch_gemm_nt(const GemmNT& p_in, hipStream_t st, void* ws = nullptr, size_
       main_rows = panels * 256;
       const int tail = p.M - main_rows;
       double tail_cost = tail < 2048 ? nt_cost(2, p.epi, p.c_bf16, tail, p.N, p.K)
-                                     : fmin(nt_cost(3, p.epi, p.c_bf16, tail, p.N, p.K), nt_cost(1, p.epi, p.c_bf16, tail, p.N, p.K));
+                                     : nt_cost(nt_tail_variant(row_range(p, main_rows, tail)), p.epi, p.c_bf16, tail, p.N, p.K);
       // (d) the tail's tiles split along K over all CUs (SPLITK kernels): 78 tiles of the N = 768 Linears of ViT-B run as 3 shares
       // each on 234 CUs instead of one K loop on 156
       if (ws) {
@@ -1591,7 +1610,7 @@ int launch_gemm_nt(const GemmNT& p_in, hipStream_t st, void* ws = nullptr, size_
     if (rc) return rc;
     if (tail_splits) return launch_gemm_nt_splitk(t, tail_splits, ws, st);
     if (t.M < 2048) return launch_gemm_nt_one(t, 2, st);
-    return launch_gemm_nt_one(t, nt_cost(1, t.epi, t.c_bf16, t.M, t.N, t.K) < nt_cost(3, t.epi, t.c_bf16, t.M, t.N, t.K) ? 1 : 3, st);
+    return launch_gemm_nt_one(t, nt_tail_variant(t), st);
   }
   return launch_gemm_nt_one(p, cost_b < cost_a ? nt_main_variant(p) : 3, st);
 }
@@ -1746,8 +1765,9 @@ int tad_linear_tuning(const char* key, int value) {
   else if (k == "direct_epilogue") { TAD_REQUIRE(value >= 0 && value <= 2, "linear_tuning: direct_epilogue=%d not in 0..2", value); nt_direct = value; }
   else if (k == "debug") gemm_debug = value;  // ablation bits (timing experiments; ignored by production builds)
   else if (k == "group_m") { TAD_REQUIRE(value >= 0 && value <= 1024, "linear_tuning: group_m=%d out of range", value); nt_group_m_knob = value; }
-  else if (k == "variant") { TAD_REQUIRE(value >= 0 && value <= 7 && value != 6, "linear_tuning: variant=%d not one of 0..5, 7", value); nt_variant = value; }
+  else if (k == "variant") { TAD_REQUIRE(value >= 0 && value <= 8 && value != 6, "linear_tuning: variant=%d not one of 0..5, 7, 8", value); nt_variant = value; }
   else if (k == "splitk_defer") { TAD_REQUIRE(value == 0 || value == 1, "linear_tuning: splitk_defer=%d not in {0, 1}", value); nt_sk_defer = value; }
+  else if (k == "tail_192") { TAD_REQUIRE(value == 0 || value == 1, "linear_tuning: tail_192=%d not in {0, 1}", value); nt_tail_192 = value; }
   else if (k == "w4_epilogues") { TAD_REQUIRE(value >= 0 && value < 16, "linear_tuning: w4_epilogues=%d not a mask of bits 1..3", value); nt_w4_epilogues = value; }
   else if (k == "w4_plain") { TAD_REQUIRE(value >= 0, "linear_tuning: w4_plain=%d must be >= 0", value); nt_w4_plain = value; }
   else if (k == "tn_w4") { TAD_REQUIRE(value == 0 || value == 1, "linear_tuning: tn_w4=%d not in {0, 1}", value); tn_w4 = value; }

@@ -519,7 +519,9 @@ def test_linear_persistent_schedule_is_bit_identical(K, M, N, Kd, mode):
                           ("persist_direct", dict(persistent=1, direct_epilogue=2)), ("split", dict(persistent=1, split_tail=2)),
                           ("default", {**K.LINEAR_TUNING_DEFAULTS, "splitk_tail": 0}),
                           # the four-wave kernels (csrc/gemm_w4.hip: 128 x 128 outputs per wave, hand-ordered K loop), per tile and persistent
-                          ("w4_tile", dict(variant=7)), ("w4_persist", dict(variant=7, persistent=1))]:
+                          ("w4_tile", dict(variant=7)), ("w4_persist", dict(variant=7, persistent=1)),
+                          # 192 x 128 tiles (the tail launch of the split plan, tad_linear_tuning("tail_192")), with and without the register-layout stores
+                          ("t192", dict(variant=8)), ("t192_direct", dict(variant=8, direct_epilogue=2))]:
             K.linear_tuning(**{**base, **cfg})
             y, pre = run()
             torch.cuda.synchronize()
@@ -527,7 +529,7 @@ def test_linear_persistent_schedule_is_bit_identical(K, M, N, Kd, mode):
     finally:
         K.linear_tuning(**K.LINEAR_TUNING_DEFAULTS)
     y0, p0 = outs["tile"]
-    for name in ("tile_direct", "persist", "persist_direct", "split", "default", "w4_tile", "w4_persist"):
+    for name in ("tile_direct", "persist", "persist_direct", "split", "default", "w4_tile", "w4_persist", "t192", "t192_direct"):
         y1, p1 = outs[name]
         assert torch.equal(y0, y1), f"{name}: output differs from per-tile scheduling"
         if p0 is not None:
