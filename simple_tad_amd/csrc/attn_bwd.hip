@@ -322,6 +322,11 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_bwd_dq_kernel(cons
                           // round 5 (tools/ab_attn.py, same results): backward pair 832.6 us without, 836.1 with -- the wait in front of the tile
                           // barrier is wave skew, not DMA latency (the scheme that gave the four-wave weight-gradient GEMM 6 %); off
 #endif
+#ifndef TAD_DKV_ROWC_SGPR
+#define TAD_DKV_ROWC_SGPR 0  // (experiment) 1: the row constants (-lse, -delta: initial S / dP accumulators) of a half tile come from
+                             // SCALAR registers (s_load of the 2 x 32 values, requested one half tile ahead) + a move and a lane-half select per
+                             // accumulator register, instead of 8 of the 24 ds_read_b128 of a half tile.  Without dropout / head_dim 80.
+#endif
 #ifndef TAD_DKV_ABL
 #define TAD_DKV_ABL 0  // timing experiments (experiments/README.md, round 4): 1 = a quarter of the row-constant LDS reads
 #endif
@@ -454,6 +459,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
 
   const int nt = (N + 63) / 64;
   constexpr bool STREAM = TAD_DKV_STREAM && !X && DMA_MODE == 0;
+  constexpr bool RC_SGPR = TAD_DKV_ROWC_SGPR && !X && !DROP && DMA_MODE == 0;
+  float rc_s[32], rc_d[32];  // (RC_SGPR) -lse / -delta of the 32 rows of the coming half tile, wave-uniform
+  const float* const rc_base = rowc_g + ((int64_t)b * H + head) * N;
+  auto rc_load = [&](int row0) {  // row0 .. row0 + 31 (clamped by the caller: rows >= N are neutralised in the ragged branch)
+    if constexpr (RC_SGPR) {
+      const int r0 = __builtin_amdgcn_readfirstlane(row0);
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        rc_s[i] = __builtin_nontemporal_load(rc_base + bhn + r0 + i);
+        rc_d[i] = __builtin_nontemporal_load(rc_base + r0 + i);
+      }
+    }
+  };
+  rc_load(0);
   LOAD_QDO(0, 0);
   if (STREAM && 1 < nt) { LOAD_HALF0_(1, 64); LOAD_HALF1_(1, 64); }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -494,6 +513,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
       constexpr int NTR = X ? 12 : 8;    // transposed reads per batch
       f32x4 si[4], di[4];
       op16x8 qa[NKS], da[NKS];
+      if constexpr (!RC_SGPR)
       static_for<0, 4>([&](auto r4c) {
         constexpr int r4 = decltype(r4c)::value;
         if constexpr (!(TAD_DKV_ABL & 1) || r4 == 0) {
@@ -537,7 +557,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
   }
       if constexpr (DMA_MODE != 3 && !X) {
         TR_ISSUE(0);
-        lds_wait<16>(si[0], si[1], si[2], si[3], di[0], di[1], di[2], di[3]);  // (the counter saturates at 15: this also covers the row fragments)
+        if constexpr (!RC_SGPR) lds_wait<16>(si[0], si[1], si[2], si[3], di[0], di[1], di[2], di[3]);  // (the counter saturates at 15: this also covers the row fragments)
         lds_wait<NTR>(qa[0], qa[1], qa[2], qa[3], da[0], da[1], da[2], da[3]);
       } else {  // ablation (timing only): no transposed reads at all -- how much of the kernel is LDS read traffic?
         lds_wait<0>(si[0], si[1], si[2], si[3], di[0], di[1], di[2], di[3]);
@@ -545,8 +565,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
         if constexpr (X) lds_wait<0>(qa[NKS - 1], da[NKS - 1]);
       }
       f32x16 s, dp;
+      if constexpr (RC_SGPR) {
+        // accumulator register r of lane half h5 <-> row (r & 3) + 8 (r >> 2) + 4 h5 of the half tile: one scalar per lane half
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s[r] = h5 ? rc_s[(r & 3) + 8 * (r >> 2) + 4] : rc_s[(r & 3) + 8 * (r >> 2)];
+          dp[r] = h5 ? rc_d[(r & 3) + 8 * (r >> 2) + 4] : rc_d[(r & 3) + 8 * (r >> 2)];
+        }
+        // request the constants of the next half tile: they land behind this half tile's matrix work
+        const int nrow = min(t * 64 + 32 * qt + 32, N - 32);
+        rc_load(nrow);
+      } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[r] = si[r >> 2][r & 3]; dp[r] = DROP ? 0.f : di[r >> 2][r & 3]; }
+      }
       if (t * 64 + 32 * qt + 32 > N) {  // ragged half tile (N % 32 != 0): rows >= N get exp2(c*(s - 3e30)) = 0 and delta = 0
         // (one lane value against 16 literals: written as `row0 + literal + 4 h5 >= N` the compiler computed the 16 row indices in
         // front of this branch, i.e. in every half tile)

@@ -21,6 +21,14 @@ constexpr float RESCALE_THR = 8.0f;  // log2 units
 #ifndef TAD_FWD_ROWSUM_VALU
 #define TAD_FWD_ROWSUM_VALU 0  // 1: row sums of P as f32 adds of the unrounded exponentials + one half swap per tile, instead of 4 MFMAs
 #endif
+#ifndef TAD_FWD_PV_F16
+#define TAD_FWD_PV_F16 0  // (bf16 build only; experiment) 1: the P V product in IEEE half -- P in [0, 2^8] rounded to f16 (11 significant bits instead
+                          // of 8), the V fragments converted bf16 -> f16 in registers (exact while |v| < 65504; 3 vector instructions per pair)
+#endif
+#if defined(TAD_OPND_F16) && TAD_FWD_PV_F16
+#undef TAD_FWD_PV_F16
+#define TAD_FWD_PV_F16 0
+#endif
 #ifndef TAD_FWD_ABL
 #define TAD_FWD_ABL 0  // timing-only ablations of the forward tile body (experiments; WRONG results): bit 0 no exponentials, 1 no row
                        // maximum, 2 no P V products / V reads / row sums, 3 no K Q^T products / K reads, 4 no DMA and no barrier in
@@ -42,6 +50,32 @@ __device__ __forceinline__ float half_swap_sum(float x) {
 }
 
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+#if TAD_FWD_PV_F16
+typedef __attribute__((ext_vector_type(8))) _Float16 pv16x8;
+typedef _Float16 pv16_t;
+#define PV_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define PV_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+// eight bf16 -> eight f16: each 32-bit word holds two bf16; word << 16 / word & 0xffff0000 are their f32 images
+__device__ __forceinline__ pv16x8 v_to_pv(const op16x8& v) {
+  typedef __attribute__((ext_vector_type(4))) uint32_t w32x4;
+  const w32x4 w = __builtin_bit_cast(w32x4, v);
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+  pv16x8 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const h2 t = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(__uint_as_float(w[i] << 16), __uint_as_float(w[i] & 0xffff0000u)));  // (exact: 8 significant bits)
+    r[2 * i] = t[0];
+    r[2 * i + 1] = t[1];
+  }
+  return r;
+}
+#else
+typedef op16x8 pv16x8;
+typedef op16_t pv16_t;
+#define PV_MFMA_32x32x16(a, b, c) TAD_MFMA_32x32x16(a, b, c)
+#define PV_MFMA_16x16x32(a, b, c) TAD_MFMA_16x16x32(a, b, c)
+__device__ __forceinline__ pv16x8 v_to_pv(const op16x8& v) { return v; }
+#endif
 
 // DMA_MODE: see attn_bwd.hip (0: next tile's LDS-DMA pieces at the top of the tile; 2: timing-only ablation, ablation builds)
 // QS: the q third of qkv already carries the factor scale * log2(e) (tad_linear_fwd_qkv's q_prescale): the scores leave the matrix
@@ -169,12 +203,12 @@ __global__ __launch_bounds__(256, TAD_FWD_ROWSUM_VALU ? 4 : 1) void attn_fwd_ker
   // The selector A has ones in rows 0 and 8 over kg {0, 2} and in rows 4 and 12 over kg {1, 3}; output register 0 of lane l is
   // D[4 (l>>4)][l & 15]: lanes 0-15 and 32-47 get the sum of query l & 15, lanes 16-31 and 48-63 that of query 16 + (l & 15) -- each
   // lane its own query (lane & 31), no cross-lane step.
-  op16x8 sel;
+  pv16x8 sel;
   {
     const int m = lane & 15, kg = lane >> 4;
     const bool on = ((m & 7) == 0 && (kg & 1) == 0) || ((m & 7) == 4 && (kg & 1) == 1);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) sel[e] = (op16_t)(on ? 1.0f : 0.0f);
+    for (int e = 0; e < 8; ++e) sel[e] = (pv16_t)(on ? 1.0f : 0.0f);
   }
 
   // One K/V tile of 64 keys out of LDS ring slot BUF (a literal: every LDS address below is then lane-constant + immediate).
@@ -253,7 +287,7 @@ __global__ __launch_bounds__(256, TAD_FWD_ROWSUM_VALU ? 4 : 1) void attn_fwd_ker
           for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
       }
       const float mc = m_run * c;  // (plain q only)
-      op16x8 pf[2][2];
+      pv16x8 pf[2][2];
       float psum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
@@ -264,8 +298,8 @@ __global__ __launch_bounds__(256, TAD_FWD_ROWSUM_VALU ? 4 : 1) void attn_fwd_ker
             const float sh = QS ? s[kt][8 * s2 + j] - m_run : fmaf(s[kt][8 * s2 + j], c, -mc);
             const float pe = (TAD_FWD_ABL & 1) ? sh : fast_exp2(sh);
             if (VSUM) psum[(j + 8 * s2) & 3] += pe;
-            if (DROP) pf[kt][s2][j] = (op16_t)(drop_keep(drop, drop_row, (uint32_t)(kv0 + kt * 32 + acc_row(8 * s2 + j, h5))) ? pe * drop.inv_keep : 0.f);
-            else pf[kt][s2][j] = (op16_t)pe;
+            if (DROP) pf[kt][s2][j] = (pv16_t)(drop_keep(drop, drop_row, (uint32_t)(kv0 + kt * 32 + acc_row(8 * s2 + j, h5))) ? pe * drop.inv_keep : 0.f);
+            else pf[kt][s2][j] = (pv16_t)pe;
           }
       f32x4 rs = {0.f, 0.f, 0.f, 0.f};
       if constexpr (TAD_FWD_ABL & 4) {
@@ -276,9 +310,9 @@ __global__ __launch_bounds__(256, TAD_FWD_ROWSUM_VALU ? 4 : 1) void attn_fwd_ker
       } else if constexpr (TAD_FWD_ABL & 32) {
         static_for<0, 4>([&](auto gc) {
           constexpr int g_ = decltype(gc)::value;
-          rs = TAD_MFMA_16x16x32(sel, pf[g_ >> 1][g_ & 1], rs);
+          rs = PV_MFMA_16x16x32(sel, pf[g_ >> 1][g_ & 1], rs);
 #pragma unroll
-          for (int dt = 0; dt < 2; ++dt) o[dt] = TAD_MFMA_32x32x16(kf[dt][g_], pf[g_ >> 1][g_ & 1], o[dt]);
+          for (int dt = 0; dt < 2; ++dt) o[dt] = PV_MFMA_32x32x16(v_to_pv(kf[dt][g_]), pf[g_ >> 1][g_ & 1], o[dt]);
         });
       } else {
       // V^T fragments through the asm reads of common.h (the builtin made the compiler drain the DMA of the next tile here):
@@ -300,11 +334,11 @@ __global__ __launch_bounds__(256, TAD_FWD_ROWSUM_VALU ? 4 : 1) void attn_fwd_ker
       static_for<0, 4>([&](auto gc) {
         constexpr int g_ = decltype(gc)::value, par = g_ & 1;
         if constexpr (g_ < 3) v_issue(std::integral_constant<int, g_ + 1>{}, std::integral_constant<int, par ^ 1>{});
-        if (!VSUM) rs = TAD_MFMA_16x16x32(sel, pf[g_ >> 1][g_ & 1], rs);
+        if (!VSUM) rs = PV_MFMA_16x16x32(sel, pf[g_ >> 1][g_ & 1], rs);
         if constexpr (X) lds_wait<(g_ < 3 ? 6 : 0)>(vlo[par][0], vhi[par][0], vlo[par][1], vhi[par][1], vlo[par][NDT - 1], vhi[par][NDT - 1]);
         else lds_wait<(g_ < 3 ? 4 : 0)>(vlo[par][0], vhi[par][0], vlo[par][1], vhi[par][1]);
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) o[dt] = TAD_MFMA_32x32x16(join_tr(vlo[par][dt], vhi[par][dt]), pf[g_ >> 1][g_ & 1], o[dt]);
+        for (int dt = 0; dt < NDT; ++dt) o[dt] = PV_MFMA_32x32x16(v_to_pv(join_tr(vlo[par][dt], vhi[par][dt])), pf[g_ >> 1][g_ & 1], o[dt]);
       });
       }
       if (VSUM) l_run += half_swap_sum((psum[0] + psum[1]) + (psum[2] + psum[3]));

@@ -18,6 +18,8 @@ ap.add_argument("--B", type=int, default=32)
 ap.add_argument("--H", type=int, default=12)
 ap.add_argument("--N", type=int, default=1568)
 ap.add_argument("--fwd-only", action="store_true")
+ap.add_argument("--check-bwd", action="store_true", help="dqkv of every build against the first one's (same forward outputs)")
+ap.add_argument("--check", action="store_true", help="forward error of every build against an f64 softmax(q k^T) v of the same 16-bit operands (4 heads)")
 a = ap.parse_args()
 B, H, N = a.B, a.H, a.N
 D = H * 64
@@ -84,3 +86,35 @@ for n, _, _ in libs:
     fw, bw = res[(n, "fwd")], res[(n, "bwd")]
     print(f"{n:16s} {statistics.median(fw):10.1f} {min(fw):8.1f} {statistics.median(bw):11.1f} {min(bw):8.1f}")
 sys.stdout.flush()
+
+if a.check:
+    import math
+    q3 = qkv_p.view(B, N, 3, H, 64)
+    print(f"{'build':16s} {'fwd rel-L2':>11s} {'max |err| / max |ref|':>22s}   (f64 reference of the same operands, batch 0, heads 0-3)")
+    for n, fw, _ in libs:
+        fw()
+        torch.cuda.synchronize()
+        o = out.view(B, N, H, 64)
+        num = den = 0.0
+        mx = rmx = 0.0
+        for h in range(4):
+            q, k, v = (q3[0, :, j, h].double() for j in range(3))
+            ref = torch.softmax((q @ k.t()) * math.log(2.0), dim=-1) @ v
+            d = o[0, :, h].double() - ref
+            num += float((d * d).sum()); den += float((ref * ref).sum())
+            mx = max(mx, float(d.abs().max())); rmx = max(rmx, float(ref.abs().max()))
+        print(f"{n:16s} {math.sqrt(num / den):11.2e} {mx / rmx:22.2e}")
+
+if a.check_bwd:
+    ref = None
+    for n, fw, bw in libs:
+        libs[0][1]()  # (the first build's forward for all: same out / lse)
+        dqkv.zero_()
+        bw()
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = dqkv.clone()
+            print(f"{n:16s} dqkv reference, |dqkv| max {float(ref.float().abs().max()):.3e}")
+        else:
+            d = (dqkv.float() - ref.float()).abs()
+            print(f"{n:16s} dqkv bit-identical to {libs[0][0]}: {torch.equal(dqkv, ref)}, max |diff| {float(d.max()):.3e}")
