@@ -164,8 +164,9 @@ int tad_linear_bwd_weight_qkv(const uint16_t* dy, const uint16_t* x, float* dW, 
  *                     csrc/gemm_w4.hip); 8 = 192 x 128 -- all bit-identical
  *   "tail_192"        1 = the second launch of the split plan may use 192 x 128 tiles where they put more CUs to work than 256 x 128
  *                     (default: ViT-B's 6656-row tails run 210 workgroups instead of 156, 9 % faster); 0 = 256 x 128 / 256 x 256 only
- *   "w4_plain"        K_min > 0: bias-only Linears whose reduction is at least K_min long run their whole rounds of 256 x 256 tiles on the
- *                     four-wave kernel (default 128; bit-identical, 5-8 % faster on the N = 768 input-gradient Linears); 0 = eight waves
+ *   "w4_plain"        K_min > 0: Linears whose reduction is at least K_min long run their whole rounds of 256 x 256 tiles on the
+ *                     four-wave kernel (default 640: bit-identical, 5-8 % faster on the input-gradient Linears of ViT-B / L; at K = 384 / 512
+ *                     its slower epilogue costs what its K loop gains); 0 = eight waves.  Applies to bias-only epilogues and to those of
  *   "w4_epilogues"    bit mask of the other epilogues whose whole rounds take the four-wave kernel: bit 1 GELU, 2 residual with f32 output
  *                     (default: 4), 3 GELU backward
  *   "tn_w4"           1 = the 256 x 256 weight-gradient GEMM runs as four waves of 128 x 128 outputs (default; bit-identical, 8 % faster);

@@ -9,7 +9,11 @@ CSRC = os.path.join(HERE, "csrc")
 # TAD_BUILD_LIB / TAD_BUILD_DEFINES: experiment builds next to the production library (own object directory), e.g.
 #   TAD_BUILD_LIB=libtad_spread.so TAD_BUILD_DEFINES="-DTAD_DMA_SPREAD=1" python -m simple_tad_amd.build --force
 # and TAD_LIB=<path> selects the library a process loads (_lib.py).
-LIB = os.path.join(HERE, os.environ.get("TAD_BUILD_LIB", "libtad_mi355x.so"))
+# TAD_BUILD_ABLATION=1 (the diagnostic build: -DTAD_GEMM_ABLATION, in-kernel stamps / clock readings / debug knobs) never writes the production
+# library: without TAD_BUILD_LIB it builds libtad_ablation.so in its own object directory.
+_ABLATION = os.environ.get("TAD_BUILD_ABLATION") == "1"
+_LIB_NAME = os.environ.get("TAD_BUILD_LIB", "libtad_ablation.so" if _ABLATION else "libtad_mi355x.so")
+LIB = os.path.join(HERE, _LIB_NAME)
 SOURCES = ["capi.hip", "elementwise.hip", "layernorm.hip", "gemm.hip", "gemm_w4.hip", "attn_fwd.hip", "attn_bwd.hip", "attn_f32.hip", "precise.hip", "optim.hip", "mae.hip", "metrics.hip", "collective.hip"]
 # Sources that touch 16-bit GEMM / attention operands are compiled a second time with -DTAD_OPND_F16: the same kernels for IEEE half
 # operands, exported as tad_*_f16 (csrc/common.h, csrc/opnd_f16_names.h; include/tad_mi355x.h "IEEE half operand twins").
@@ -42,7 +46,7 @@ def _deps_mtime():
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _deps_mtime():
         return LIB
-    objdir = os.path.join(HERE, "build" if "TAD_BUILD_LIB" not in os.environ else "build_" + os.path.splitext(os.path.basename(LIB))[0])
+    objdir = os.path.join(HERE, "build" if _LIB_NAME == "libtad_mi355x.so" else "build_" + os.path.splitext(os.path.basename(LIB))[0])
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
 
@@ -56,7 +60,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(p) for p in deps):
             return obj
         flags = [f for f in FLAGS if f not in ("-mllvm", "-amdgpu-mfma-vgpr-form=1")] if src in NO_VGPR_FORM else FLAGS
-        cmd = [hipcc, *flags, *(["-DTAD_OPND_F16"] if half else []), *(["-DTAD_GEMM_ABLATION"] if os.environ.get("TAD_BUILD_ABLATION") == "1" else []),
+        cmd = [hipcc, *flags, *(["-DTAD_OPND_F16"] if half else []), *(["-DTAD_GEMM_ABLATION"] if _ABLATION else []),
                *os.environ.get("TAD_BUILD_DEFINES", "").split(), "-c", srcp, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)

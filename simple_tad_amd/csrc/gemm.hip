@@ -1282,7 +1282,7 @@ int nt_group_m_knob = getenv("TAD_GEMM_GROUP_M") ? env_int("TAD_GEMM_GROUP_M") :
 int tn_variant = env_int("TAD_GEMM_TN_VARIANT");
 // > 0: bias-only Linears with K >= this run their whole rounds on the four-wave kernel.  Measured (tools/exp_w4_plain.py, planned launches at M = 50176):
 // qkv forward 176.9 / 177.2 us (eight / four waves), dX(proj) 78.0 / 73.9, dX(qkv) 159.0 / 148.4, dX(fc1) 225.4 / 208.5 -- on by default
-int nt_w4_plain = getenv("TAD_GEMM_W4_PLAIN") ? env_int("TAD_GEMM_W4_PLAIN") : 128;
+int nt_w4_plain = getenv("TAD_GEMM_W4_PLAIN") ? env_int("TAD_GEMM_W4_PLAIN") : 640;  // K_min of the Linears whose whole rounds of 256 x 256 tiles run on the four-wave kernel (0 = none): below ~640 its epilogue costs more than its K loop gains (tools/exp_w4_plain.py --D 384 / 512)
 // bit mask: which other epilogues' whole rounds take the four-wave kernel (see nt_main_variant).  Measured (tools/exp_gemm_knobs.py --configs
 // "w4_epilogues=0;w4_epilogues=14", eight / four waves): proj + residual 96.0 / 96.9 us, fc2 + residual 250.4 / 241.1, fc1 GELU 278.1 / 282.1, dX(fc2) GELU backward
 // 291.2 / 338.8 -- the residual epilogue (bit 2) is on by default, the vector-heavy GELU ones stay on eight waves
@@ -1524,7 +1524,7 @@ static int nt_main_variant(const GemmNT& p) {
   if (p.epi == EPI_PLAIN) return (nt_w4_plain > 0 && p.K >= nt_w4_plain) ? 7 : 1;
   // the other epilogues: tad_linear_tuning("w4_epilogues", mask) -- bit 1 GELU, 2 residual (f32 output), 3 GELU backward
   const int bit = p.epi == EPI_GELU ? 1 : (p.epi == EPI_RESIDUAL && !p.c_bf16 && p.res_mod <= 0) ? 2 : p.epi == EPI_DGELU ? 3 : -1;
-  return (bit > 0 && ((nt_w4_epilogues >> bit) & 1)) ? 7 : 1;
+  return (bit > 0 && ((nt_w4_epilogues >> bit) & 1) && nt_w4_plain > 0 && p.K >= nt_w4_plain) ? 7 : 1;
 }
 
 int launch_gemm_nt(const GemmNT& p_in, hipStream_t st, void* ws = nullptr, size_t ws_bytes = 0) {

@@ -14,13 +14,16 @@ M, D, dev, bf = a.rows, 768, "cuda", torch.bfloat16
 VAR = [int(v) for v in a.variants.split(",")]
 rnd = lambda *s, scale=1.0: (torch.randn(*s, device=dev) * scale).to(bf)  # noqa: E731
 x_d, x_3d, x_4d = rnd(M, D), rnd(M, 3 * D), rnd(M, 4 * D)
-W = {n: rnd(*s, scale=0.02) for n, s in {"proj": (D, D), "fc2": (D, 4 * D), "qkvT": (D, 3 * D)}.items()}
-b_d, res = torch.randn(D, device=dev), torch.randn(M, D, device=dev)
+W = {n: rnd(*s, scale=0.02) for n, s in {"proj": (D, D), "fc2": (D, 4 * D), "qkvT": (D, 3 * D), "fc1": (4 * D, D), "qkv": (3 * D, D)}.items()}
+b_d, b_4d, res = torch.randn(D, device=dev), torch.randn(4 * D, device=dev), torch.randn(M, D, device=dev)
 cases = [("proj fwd +res f32 K768", lambda: K.linear_fwd(x_d, W["proj"], b_d, out_dtype=torch.float32, epilogue=2, residual=res)),
          ("fc2 fwd +res f32 K3072", lambda: K.linear_fwd(x_4d, W["fc2"], b_d, out_dtype=torch.float32, epilogue=2, residual=res)),
          ("dX proj 16-bit K768", lambda: K.linear_bwd_input(x_d, W["proj"])),
          ("dX qkv f32 K2304", lambda: K.linear_bwd_input(x_3d, W["qkvT"], out_dtype=torch.float32)),
-         ("dX fc1 f32 K3072", lambda: K.linear_bwd_input(x_4d, W["fc2"], out_dtype=torch.float32))]
+         ("dX fc1 f32 K3072", lambda: K.linear_bwd_input(x_4d, W["fc2"], out_dtype=torch.float32)),
+         ("fc1 fwd gelu +preact K768", lambda: K.linear_fwd(x_d, W["fc1"], b_4d, epilogue=1, want_preact=True)),
+         ("dX fc2 dgelu K768", lambda: K.linear_bwd_input(x_d, W["fc1"], gelu_preact=x_4d)),
+         ("qkv fwd K768", lambda: K.linear_fwd_qkv(x_d, W["qkv"], b_d, b_d, q_prescale=0.18))]
 
 
 def timeit(fn, it=20):
