@@ -52,6 +52,17 @@ for cfg in a.configs.split(";"):
         a1, a2 = s[:, :, 4 + 2 * q], s[:, :, 5 + 2 * q]
         print(f"   chunk {q}: transpose+barrier {np.mean((a1 - prev)[used]):5.2f} us, row pass {np.mean((a2 - a1)[used]):5.2f} us")
         prev = a2
+    # per workgroup: when its first K loop starts (launch skew), when its last tile's stores are out, tiles it ran
+    nt_wg = used.sum(axis=1)
+    live = nt_wg > 0
+    first = np.array([s[i, 0, 0] for i in np.where(live)[0]])
+    last = np.array([s[i, nt_wg[i] - 1, 3] for i in np.where(live)[0]])
+    print(f"   first K loop starts: min {first.min():.1f} p50 {np.percentile(first, 50):.1f} p90 {np.percentile(first, 90):.1f} max {first.max():.1f} us;  workgroup finishes: "
+          f"p10 {np.percentile(last, 10):.1f} p50 {np.percentile(last, 50):.1f} p90 {np.percentile(last, 90):.1f} max {last.max():.1f} us;  tiles per workgroup {nt_wg[live].min()}..{nt_wg[live].max()}")
+    for ntile in sorted(set(nt_wg[live].tolist())):
+        sel = np.where(live)[0][nt_wg[live] == ntile]
+        l2 = np.array([s[i, ntile - 1, 3] for i in sel])
+        print(f"      workgroups with {ntile} tiles: {len(sel)}, finish p50 {np.percentile(l2, 50):.1f} max {l2.max():.1f} us")
     if c.get('persistent', 1):
         # phase spread: epilogue start times of the 3rd tile of each workgroup, and how many workgroups are inside an epilogue over time
         st = s[:, 2, 1][used[:, 2]]
