@@ -1287,13 +1287,14 @@ int nt_w4_plain = getenv("TAD_GEMM_W4_PLAIN") ? env_int("TAD_GEMM_W4_PLAIN") : 6
 // "w4_epilogues=0;w4_epilogues=14", eight / four waves): proj + residual 96.0 / 96.9 us, fc2 + residual 250.4 / 241.1, fc1 GELU 278.1 / 282.1, dX(fc2) GELU backward
 // 291.2 / 338.8 -- the residual epilogue (bit 2) is on by default, the vector-heavy GELU ones stay on eight waves
 int nt_w4_epilogues = getenv("TAD_GEMM_W4_EPILOGUES") ? env_int("TAD_GEMM_W4_EPILOGUES") : 4;
+int nt_short_k = getenv("TAD_GEMM_SHORT_K") ? env_int("TAD_GEMM_SHORT_K") : 1;  // 1: Linears with K < 512 (GELU / GELU' ones: <= 512) run on 128 x 128 tiles, two workgroups per CU (launch_gemm_nt)
 int nt_tail_192 = getenv("TAD_GEMM_TAIL_192") ? env_int("TAD_GEMM_TAIL_192") : 1;  // 1: tails of the split plan may run as 192 x 128 tiles (nt_tail_variant)
 int tn_w4 = getenv("TAD_GEMM_TN_W4") ? env_int("TAD_GEMM_TN_W4") : 1;  // 1: the 256 x 256 weight-gradient GEMM runs as four waves of 128 x 128 (gemm_w4.hip)
 int tn_pdeep = env_int("TAD_GEMM_TN_PDEEP");  // 1: gemm_tn 256 x 256 with the P operand two reduction tiles ahead (see PDEEP); measured null (round 4), off
 unsigned long long* nt_stamps = nullptr;
 long long nt_launches = 0;  // gemm_nt kernel launches so far (tad_linear_kernel_launches)
 #else
-extern int gemm_debug, nt_persist, nt_direct, nt_split, nt_splitk, nt_variant, nt_group_m_knob, tn_variant, tn_pdeep, nt_sk_defer, tn_w4, nt_w4_plain, nt_w4_epilogues, nt_tail_192;
+extern int gemm_debug, nt_persist, nt_direct, nt_split, nt_splitk, nt_variant, nt_group_m_knob, tn_variant, tn_pdeep, nt_sk_defer, tn_w4, nt_w4_plain, nt_w4_epilogues, nt_tail_192, nt_short_k;
 extern unsigned long long* nt_stamps;
 extern long long nt_launches;
 #endif
@@ -1568,6 +1569,12 @@ int launch_gemm_nt(const GemmNT& p_in, hipStream_t st, void* ws = nullptr, size_
     if (t128 * 2 > cu_count() || p.N < 64) return launch_gemm_nt_one(p, 2, st);
     return launch_gemm_nt_one(p, (t64 * 4 <= 3 * cu_count() && p.M >= 64) ? 5 : 4, st);  // 64 x 64 while even 128 x 64 fills < 3/4 of the CUs
   }
+  // Short reductions (ViT-S: K = 384; the MAE decoder: K = 512): the epilogue is as long as the K loop, and 128 x 128 tiles put TWO workgroups on a
+  // CU, so one's epilogue runs beside the other's K loop -- measured (tools/exp_gemm_knobs.py --D 384 / 512 --configs "short_k=0;short_k=1"):
+  // K = 512: fc1 + GELU 171 -> 153.5 us, dX(fc2) GELU' 165 -> 152 (the eight Linears of a decoder block 785 -> 763); K = 384: proj + residual
+  // 41.0 -> 36.0 (N = 384 is 1.5 tiles of 256 columns), the GELU shapes equal (their 308 MB of output bound them), bias-only shapes equal or
+  // slower.  From K = 768 the 256 x 256 tile wins everywhere (fc1 274 against 290 us)
+  if (nt_short_k && ((p.K == 512 && (p.epi == EPI_GELU || p.epi == EPI_DGELU)) || (p.K < 512 && p.epi == EPI_RESIDUAL))) return launch_gemm_nt_one(p, 2, st);
   const bool v1_ok = !(p.epi == EPI_RESIDUAL && (p.c_bf16 || p.res_mod > 0));  // (those instantiations do not exist)
   // Plans: (a) 256 x 128 tiles, (b) 256 x 256 tiles, (c) 256 x 256 tiles for as many row panels as fill whole rounds of one
   // workgroup per CU, the remaining rows as a second launch with whatever suits that smaller problem.  (c) is what lets the
@@ -1767,6 +1774,7 @@ int tad_linear_tuning(const char* key, int value) {
   else if (k == "group_m") { TAD_REQUIRE(value >= 0 && value <= 1024, "linear_tuning: group_m=%d out of range", value); nt_group_m_knob = value; }
   else if (k == "variant") { TAD_REQUIRE(value >= 0 && value <= 8 && value != 6, "linear_tuning: variant=%d not one of 0..5, 7, 8", value); nt_variant = value; }
   else if (k == "splitk_defer") { TAD_REQUIRE(value == 0 || value == 1, "linear_tuning: splitk_defer=%d not in {0, 1}", value); nt_sk_defer = value; }
+  else if (k == "short_k") { TAD_REQUIRE(value == 0 || value == 1, "linear_tuning: short_k=%d not in {0, 1}", value); nt_short_k = value; }
   else if (k == "tail_192") { TAD_REQUIRE(value == 0 || value == 1, "linear_tuning: tail_192=%d not in {0, 1}", value); nt_tail_192 = value; }
   else if (k == "w4_epilogues") { TAD_REQUIRE(value >= 0 && value < 16, "linear_tuning: w4_epilogues=%d not a mask of bits 1..3", value); nt_w4_epilogues = value; }
   else if (k == "w4_plain") { TAD_REQUIRE(value >= 0, "linear_tuning: w4_plain=%d must be >= 0", value); nt_w4_plain = value; }

@@ -452,7 +452,7 @@ def _pad_reduction(a, b, mult: int = 64):
     return torch.nn.functional.pad(a, (0, pad)).contiguous(), torch.nn.functional.pad(b, (0, pad)).contiguous()
 
 
-LINEAR_TUNING_DEFAULTS = dict(persistent=1, direct_epilogue=1, split_tail=1, splitk_tail=1, group_m=0, variant=0, tn_pdeep=0, splitk_defer=1, tn_w4=1, w4_plain=640, w4_epilogues=4, tail_192=1)
+LINEAR_TUNING_DEFAULTS = dict(persistent=1, direct_epilogue=1, split_tail=1, splitk_tail=1, group_m=0, variant=0, tn_pdeep=0, splitk_defer=1, tn_w4=1, w4_plain=640, w4_epilogues=4, tail_192=1, short_k=1)
 
 
 def linear_workspace(nbytes: int, device) -> torch.Tensor:

@@ -514,14 +514,17 @@ def test_linear_persistent_schedule_is_bit_identical(K, M, N, Kd, mode):
 
     outs = {}
     try:
-        base = dict(persistent=0, direct_epilogue=0, split_tail=0, splitk_tail=0)  # (the split-K tail changes the summation order: its own test)
+        # (the split-K tail changes the summation order: its own test; short_k would send the K < 512 cases to 128 x 128 tiles under every configuration)
+        base = dict(persistent=0, direct_epilogue=0, split_tail=0, splitk_tail=0, short_k=0)
         for name, cfg in [("tile", {}), ("tile_direct", dict(direct_epilogue=2)), ("persist", dict(persistent=1)),
                           ("persist_direct", dict(persistent=1, direct_epilogue=2)), ("split", dict(persistent=1, split_tail=2)),
                           ("default", {**K.LINEAR_TUNING_DEFAULTS, "splitk_tail": 0}),
                           # the four-wave kernels (csrc/gemm_w4.hip: 128 x 128 outputs per wave, hand-ordered K loop), per tile and persistent
                           ("w4_tile", dict(variant=7)), ("w4_persist", dict(variant=7, persistent=1)),
                           # 192 x 128 tiles (the tail launch of the split plan, tad_linear_tuning("tail_192")), with and without the register-layout stores
-                          ("t192", dict(variant=8)), ("t192_direct", dict(variant=8, direct_epilogue=2))]:
+                          ("t192", dict(variant=8)), ("t192_direct", dict(variant=8, direct_epilogue=2)),
+                          # the short-K plan (K < 512: 128 x 128 tiles, two workgroups per CU) and those tiles for any K
+                          ("short_k", dict(short_k=1)), ("t128", dict(variant=2))]:
             K.linear_tuning(**{**base, **cfg})
             y, pre = run()
             torch.cuda.synchronize()
@@ -529,7 +532,7 @@ def test_linear_persistent_schedule_is_bit_identical(K, M, N, Kd, mode):
     finally:
         K.linear_tuning(**K.LINEAR_TUNING_DEFAULTS)
     y0, p0 = outs["tile"]
-    for name in ("tile_direct", "persist", "persist_direct", "split", "default", "w4_tile", "w4_persist", "t192", "t192_direct"):
+    for name in ("tile_direct", "persist", "persist_direct", "split", "default", "w4_tile", "w4_persist", "t192", "t192_direct", "short_k", "t128"):
         y1, p1 = outs[name]
         assert torch.equal(y0, y1), f"{name}: output differs from per-tile scheduling"
         if p0 is not None:

@@ -26,15 +26,16 @@ ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--shapes", default="")
 ap.add_argument("--trace", action="store_true")
+ap.add_argument("--D", type=int, default=768, help="model width (384: ViT-S, 512: MAE decoder, 1024: ViT-L)")
 ap.add_argument("--check", action="store_true", help="every configuration's outputs must be bit-identical to the first one's")
 a = ap.parse_args()
 cfgs = ([dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in c.split(",")) for c in a.configs.split(";")] if a.configs
         else [{a.knob: int(v)} for v in a.values.split(",")])
-dev, bf, D, M = "cuda", torch.bfloat16, 768, 50176
-SHAPES = [("qkv fwd   N2304 K768  plain", 3 * D, D, "plain"), ("proj fwd  N768  K768  res", D, D, "res"),
-          ("fc1 fwd   N3072 K768  gelu", 4 * D, D, "gelu"), ("fc2 fwd   N768  K3072 res", D, 4 * D, "res"),
-          ("dX qkv    N768  K2304 plain", D, 3 * D, "plain"), ("dX fc2    N3072 K768  dgelu", 4 * D, D, "dgelu"),
-          ("dX fc1    N768  K3072 plain", D, 4 * D, "plain"), ("dX proj   N768  K768  plain", D, D, "plain")]
+dev, bf, D, M = "cuda", torch.bfloat16, a.D, 50176
+SHAPES = [(f"qkv fwd   N{3 * D} K{D} plain", 3 * D, D, "plain"), (f"proj fwd  N{D} K{D} res", D, D, "res"),
+          (f"fc1 fwd   N{4 * D} K{D} gelu", 4 * D, D, "gelu"), (f"fc2 fwd   N{D} K{4 * D} res", D, 4 * D, "res"),
+          (f"dX qkv    N{D} K{3 * D} plain", D, 3 * D, "plain"), (f"dX fc2    N{4 * D} K{D} dgelu", 4 * D, D, "dgelu"),
+          (f"dX fc1    N{D} K{4 * D} plain", D, 4 * D, "plain"), (f"dX proj   N{D} K{D} plain", D, D, "plain")]
 if a.shapes:
     SHAPES = [s for s in SHAPES if any(s[0].startswith(p) for p in a.shapes.split(","))]
 
