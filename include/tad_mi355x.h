@@ -161,10 +161,11 @@ int tad_linear_bwd_weight_qkv(const uint16_t* dy, const uint16_t* x, float* dW, 
  *                     that the partial tiles travel through memory beside the whole rounds (default); 0 = one launch that combines inside
  *   "variant"         0 = tile configuration planned per shape (default); 1 / 3 / 2 / 4 / 5 = 256 x 256, 256 x 128, 128 x 128, 128 x 64,
  *                     64 x 64 tiles for every launch; 7 = the four-wave 256 x 256 kernels (128 x 128 outputs per wave, one wave per SIMD;
- *                     csrc/gemm_w4.hip); 8 = 192 x 128 -- all bit-identical
- *   "short_k"         1 = short reductions whose epilogue is as long as their K loop run on 128 x 128 tiles, two workgroups per CU, so that
- *                     one's epilogue runs beside the other's K loop: GELU / GELU' Linears at K = 512 (the MAE decoder: -9 %), residual Linears
- *                     at K < 512 (ViT-S proj: -12 %) (default); 0 = planned as the rest
+ *                     csrc/gemm_w4.hip); 8 / 9 = 192 x 128 as eight / four waves -- all bit-identical
+ *   "short_k"         1 = Linears with K <= 512, whose epilogue is as long as their K loop, run on tiles that put two workgroups on a CU so
+ *                     that one's epilogue runs beside the other's K loop: 192 x 128 as four waves (variant 9) for the GELU / GELU' Linears and,
+ *                     at K < 512, the bias-only ones; 128 x 128 for the residual ones at K < 512 (default: the MAE decoder's fc1 / dX(fc2) -11 %,
+ *                     ViT-S 2-12 % per shape); 0 = planned as the rest
  *   "tail_192"        1 = the second launch of the split plan may use 192 x 128 tiles where they put more CUs to work than 256 x 128
  *                     (default: ViT-B's 6656-row tails run 210 workgroups instead of 156, 9 % faster); 0 = 256 x 128 / 256 x 256 only
  *   "w4_plain"        K_min > 0: Linears whose reduction is at least K_min long run their whole rounds of 256 x 256 tiles on the

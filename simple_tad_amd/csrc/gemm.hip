@@ -1287,7 +1287,7 @@ int nt_w4_plain = getenv("TAD_GEMM_W4_PLAIN") ? env_int("TAD_GEMM_W4_PLAIN") : 6
 // "w4_epilogues=0;w4_epilogues=14", eight / four waves): proj + residual 96.0 / 96.9 us, fc2 + residual 250.4 / 241.1, fc1 GELU 278.1 / 282.1, dX(fc2) GELU backward
 // 291.2 / 338.8 -- the residual epilogue (bit 2) is on by default, the vector-heavy GELU ones stay on eight waves
 int nt_w4_epilogues = getenv("TAD_GEMM_W4_EPILOGUES") ? env_int("TAD_GEMM_W4_EPILOGUES") : 4;
-int nt_short_k = getenv("TAD_GEMM_SHORT_K") ? env_int("TAD_GEMM_SHORT_K") : 1;  // 1: Linears with K < 512 (GELU / GELU' ones: <= 512) run on 128 x 128 tiles, two workgroups per CU (launch_gemm_nt)
+int nt_short_k = getenv("TAD_GEMM_SHORT_K") ? env_int("TAD_GEMM_SHORT_K") : 1;  // 1: the short-K plan of launch_gemm_nt (K <= 512: tiles that put two workgroups on a CU)
 int nt_tail_192 = getenv("TAD_GEMM_TAIL_192") ? env_int("TAD_GEMM_TAIL_192") : 1;  // 1: tails of the split plan may run as 192 x 128 tiles (nt_tail_variant)
 int tn_w4 = getenv("TAD_GEMM_TN_W4") ? env_int("TAD_GEMM_TN_W4") : 1;  // 1: the 256 x 256 weight-gradient GEMM runs as four waves of 128 x 128 (gemm_w4.hip)
 int tn_pdeep = env_int("TAD_GEMM_TN_PDEEP");  // 1: gemm_tn 256 x 256 with the P operand two reduction tiles ahead (see PDEEP); measured null (round 4), off
@@ -1352,6 +1352,9 @@ static void launch_nt_variant(int v, GemmNT& p, hipStream_t st) {
     }
     case 8:  // 192 x 128 (4 x 2 waves, 3 stages): tails of the split plan whose 256 x 128 tiles would leave > a third of the CUs idle
       if (direct) NT_LAUNCH(192, 128, 4, 2, 3, false, true, tiles(192, 128), 512); else NT_LAUNCH(192, 128, 4, 2, 3, false, false, tiles(192, 128), 512);
+      break;
+    case 9:  // 192 x 128 as FOUR waves (2 x 2 of 96 x 64), 2 stages of 40 KiB: two workgroups per CU (the short-K plan of launch_gemm_nt)
+      if (direct) NT_LAUNCH(192, 128, 2, 2, 2, false, true, tiles(192, 128), 256); else NT_LAUNCH(192, 128, 2, 2, 2, false, false, tiles(192, 128), 256);
       break;
     case 4:
       if (direct) NT_LAUNCH(128, 64, 2, 2, 2, false, true, tiles(128, 64), 256); else NT_LAUNCH(128, 64, 2, 2, 2, false, false, tiles(128, 64), 256);
@@ -1569,12 +1572,17 @@ int launch_gemm_nt(const GemmNT& p_in, hipStream_t st, void* ws = nullptr, size_
     if (t128 * 2 > cu_count() || p.N < 64) return launch_gemm_nt_one(p, 2, st);
     return launch_gemm_nt_one(p, (t64 * 4 <= 3 * cu_count() && p.M >= 64) ? 5 : 4, st);  // 64 x 64 while even 128 x 64 fills < 3/4 of the CUs
   }
-  // Short reductions (ViT-S: K = 384; the MAE decoder: K = 512): the epilogue is as long as the K loop, and 128 x 128 tiles put TWO workgroups on a
-  // CU, so one's epilogue runs beside the other's K loop -- measured (tools/exp_gemm_knobs.py --D 384 / 512 --configs "short_k=0;short_k=1"):
-  // K = 512: fc1 + GELU 171 -> 153.5 us, dX(fc2) GELU' 165 -> 152 (the eight Linears of a decoder block 785 -> 763); K = 384: proj + residual
-  // 41.0 -> 36.0 (N = 384 is 1.5 tiles of 256 columns), the GELU shapes equal (their 308 MB of output bound them), bias-only shapes equal or
-  // slower.  From K = 768 the 256 x 256 tile wins everywhere (fc1 274 against 290 us)
-  if (nt_short_k && ((p.K == 512 && (p.epi == EPI_GELU || p.epi == EPI_DGELU)) || (p.K < 512 && p.epi == EPI_RESIDUAL))) return launch_gemm_nt_one(p, 2, st);
+  // Short reductions (ViT-S: K = 384; the MAE decoder: K = 512): the epilogue is as long as the K loop, and tiles that put TWO workgroups on a CU
+  // let one's epilogue run beside the other's K loop: 192 x 128 as four waves of 96 x 64 (variant 9: 80 KiB of LDS, <= 210 registers) or
+  // 128 x 128 (variant 2).  Measured (tools/exp_gemm_knobs.py --D 384 / 512 --configs "variant=0;variant=9;variant=2"), us, planned 256 x 256 /
+  // variant 9 / variant 2 -- K = 512: fc1 + GELU 171 / 152 / 161, dX(fc2) GELU' 165 / 151 / 159, the bias-only and residual shapes 1-7 % slower on
+  // either; K = 384: qkv 60.0 / 58.5 / 62, fc1 + GELU 102 / 98.6 / 100, dX(fc2) 99 / 97 / 100.5, dX(proj) 28.5 / 25.0 / 24.8, proj + residual
+  // 41.0 / 38 / 36 (N = 384 is 1.5 tiles of 256 columns).  From K = 768 the 256 x 256 tile wins everywhere (fc1 274 / 277 / 290)
+  if (nt_short_k && p.K <= 512 && !(p.rowscale && p.rows_per_scale < 256)) {
+    const bool act = p.epi == EPI_GELU || p.epi == EPI_DGELU;
+    if (p.epi == EPI_RESIDUAL && p.K < 512) return launch_gemm_nt_one(p, 2, st);
+    if (act || (p.epi == EPI_PLAIN && p.K < 512)) return launch_gemm_nt_one(p, 9, st);
+  }
   const bool v1_ok = !(p.epi == EPI_RESIDUAL && (p.c_bf16 || p.res_mod > 0));  // (those instantiations do not exist)
   // Plans: (a) 256 x 128 tiles, (b) 256 x 256 tiles, (c) 256 x 256 tiles for as many row panels as fill whole rounds of one
   // workgroup per CU, the remaining rows as a second launch with whatever suits that smaller problem.  (c) is what lets the
@@ -1772,7 +1780,7 @@ int tad_linear_tuning(const char* key, int value) {
   else if (k == "direct_epilogue") { TAD_REQUIRE(value >= 0 && value <= 2, "linear_tuning: direct_epilogue=%d not in 0..2", value); nt_direct = value; }
   else if (k == "debug") gemm_debug = value;  // ablation bits (timing experiments; ignored by production builds)
   else if (k == "group_m") { TAD_REQUIRE(value >= 0 && value <= 1024, "linear_tuning: group_m=%d out of range", value); nt_group_m_knob = value; }
-  else if (k == "variant") { TAD_REQUIRE(value >= 0 && value <= 8 && value != 6, "linear_tuning: variant=%d not one of 0..5, 7, 8", value); nt_variant = value; }
+  else if (k == "variant") { TAD_REQUIRE(value >= 0 && value <= 9 && value != 6, "linear_tuning: variant=%d not one of 0..5, 7, 8, 9", value); nt_variant = value; }
   else if (k == "splitk_defer") { TAD_REQUIRE(value == 0 || value == 1, "linear_tuning: splitk_defer=%d not in {0, 1}", value); nt_sk_defer = value; }
   else if (k == "short_k") { TAD_REQUIRE(value == 0 || value == 1, "linear_tuning: short_k=%d not in {0, 1}", value); nt_short_k = value; }
   else if (k == "tail_192") { TAD_REQUIRE(value == 0 || value == 1, "linear_tuning: tail_192=%d not in {0, 1}", value); nt_tail_192 = value; }

@@ -524,7 +524,7 @@ def test_linear_persistent_schedule_is_bit_identical(K, M, N, Kd, mode):
                           # 192 x 128 tiles (the tail launch of the split plan, tad_linear_tuning("tail_192")), with and without the register-layout stores
                           ("t192", dict(variant=8)), ("t192_direct", dict(variant=8, direct_epilogue=2)),
                           # the short-K plan (K < 512: 128 x 128 tiles, two workgroups per CU) and those tiles for any K
-                          ("short_k", dict(short_k=1)), ("t128", dict(variant=2))]:
+                          ("short_k", dict(short_k=1)), ("t128", dict(variant=2)), ("t192_4w", dict(variant=9)), ("t192_4w_direct", dict(variant=9, direct_epilogue=2))]:
             K.linear_tuning(**{**base, **cfg})
             y, pre = run()
             torch.cuda.synchronize()
@@ -532,7 +532,7 @@ def test_linear_persistent_schedule_is_bit_identical(K, M, N, Kd, mode):
     finally:
         K.linear_tuning(**K.LINEAR_TUNING_DEFAULTS)
     y0, p0 = outs["tile"]
-    for name in ("tile_direct", "persist", "persist_direct", "split", "default", "w4_tile", "w4_persist", "t192", "t192_direct", "short_k", "t128"):
+    for name in ("tile_direct", "persist", "persist_direct", "split", "default", "w4_tile", "w4_persist", "t192", "t192_direct", "short_k", "t128", "t192_4w", "t192_4w_direct"):
         y1, p1 = outs[name]
         assert torch.equal(y0, y1), f"{name}: output differs from per-tile scheduling"
         if p0 is not None:
