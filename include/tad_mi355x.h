@@ -126,7 +126,8 @@ int tad_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float*
  * in-launch combine ("splitk_defer", 0; experiments) waits for the other shares of a tile inside ONE launch and needs its whole grid
  * resident at once: if a share never arrives the kernel gives up, flags it in host-visible memory, and the NEXT tad_linear_* call on
  * the process returns TAD_ELAUNCH (the output of the affected Linear is invalid).  Results differ from the ws == NULL plan only in the
- * summation order over K. */
+ * summation order over K.  tad_linear_workspace_bytes returns 0 for shapes whose plan never splits along K under the current
+ * tad_linear_tuning knobs (every Linear of ViT-B by default; ViT-L's fc2 / dX(fc1) tails: 16 tiles x 8 shares = 33.5 MB). */
 size_t tad_linear_workspace_bytes(int64_t M, int N, int K);
 int tad_linear_fwd(const uint16_t* x, const uint16_t* w, const float* bias, void* y, int y_dtype,
                    int epilogue, uint16_t* preact, const float* residual, const float* gamma,

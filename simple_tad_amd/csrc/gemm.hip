@@ -1739,9 +1739,24 @@ int tad_linear_fwd(const uint16_t* x, const uint16_t* w, const float* bias, void
 
 #ifndef TAD_OPND_F16
 size_t tad_linear_workspace_bytes(int64_t M, int N, int K) {
-  (void)N; (void)K;
-  if (M < 4096) return 0;  // (small problems never take the split plan)
-  return SK_HEADER_BYTES + (size_t)cu_count() * SK_TILE_BYTES;  // tiles x splits <= CUs partial tiles of 256 x 256 f32
+  // What launch_gemm_nt's split plan would hand to nt_splitk_plan for this shape (the epilogue kind is not known here: assumed eligible),
+  // or 0 when the tail of this shape never splits along K -- every Linear of ViT-B under the default knobs (64 MB used to stay
+  // resident per stream for nothing, and every Linear call paid for the lookup of a buffer)
+  if (M < 4096 || N < 128 || K <= 0 || K % BK || !nt_split || !nt_splitk) return 0;
+  const int cus = cu_count(), grid = cus & ~7;
+  const int64_t tiles_n = (N + 255) / 256, tiles_m = (M + 255) / 256;
+  const int64_t rounds = grid > 0 ? tiles_m * tiles_n / grid : 0;
+  const int64_t panels = rounds > 0 ? rounds * grid / tiles_n : 0;
+  if (!(panels > 0 && panels < tiles_m)) return 0;
+  const int64_t tiles = (tiles_m - panels) * tiles_n;  // (tail rows = M - 256 panels)
+  const int nk = K / BK;
+  if (tiles <= 0 || tiles > cus / 2 || tiles > 1008) return 0;
+  if (nt_splitk == 1 && (tiles > cus / 4 || nk < 64)) return 0;
+  int64_t s = cus / tiles;
+  if (s > nk / 2) s = nk / 2;
+  if (s > 8) s = 8;
+  if (s < 2) return 0;
+  return SK_HEADER_BYTES + (size_t)(tiles * s) * SK_TILE_BYTES;
 }
 #endif
 
