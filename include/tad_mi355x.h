@@ -150,6 +150,16 @@ int tad_linear_fwd_qkv(const uint16_t* x, const uint16_t* w, const float* q_bias
 int tad_linear_bwd_weight_qkv(const uint16_t* dy, const uint16_t* x, float* dW, float* dq_bias, float* dv_bias,
                               int accumulate, void* ws, size_t ws_bytes, int64_t M, int N, int K,
                               tad_stream_t stream);
+/* TWO weight gradients over the same M rows with the same K in one call -- the qkv and proj Linears of a Block (modeling_finetune.py:89-92,
+ * 104): dW1 [N1, K] (+)= dy1^T x1 with its bias column sums (db1 [N1], or -- db1b != NULL -- the first / last third of them to db1 / db1b
+ * [N1/3] as in tad_linear_bwd_weight_qkv; db1 NULL: none), dW2 [N2, K] (+)= dy2^T x2 (no bias sums).  When N1 is a multiple of 256 and K
+ * runs on the 256-wide tiles both run as ONE kernel launch (a small problem alone pays for filling the chip with many reduction shares:
+ * ViT-B's proj gradient is 9 tiles x 28 shares; the pair is 36 tiles x 7), otherwise as two; tad_linear_tuning("tn_pair", 0) forces two.
+ * ws: at least the largest of tad_linear_bwd_weight_workspace_bytes(M, N1, K), (M, N2, K) and (M, N1 + N2, K).  The sums over the M rows
+ * are taken in another order than the single calls take them (a different share count), deterministic for a given shape. */
+int tad_linear_bwd_weight_pair(const uint16_t* dy1, const uint16_t* x1, float* dW1, float* db1, float* db1b, int N1,
+                               const uint16_t* dy2, const uint16_t* x2, float* dW2, int N2, int accumulate, void* ws,
+                               size_t ws_bytes, int64_t M, int K, tad_stream_t stream);
 /* Scheduling knobs of the Linear GEMMs (process-wide; results never depend on them, only timing): tad_linear_tuning(key, value).
  *   "persistent"      1 = one workgroup per CU walks the tile list (default), 0 = one workgroup per tile
  *   "direct_epilogue" 2 = epilogue on the accumulator registers, stores straight from the MFMA layout; 0 = accumulators
@@ -174,6 +184,7 @@ int tad_linear_bwd_weight_qkv(const uint16_t* dy, const uint16_t* x, float* dW, 
  *                     its slower epilogue costs what its K loop gains); 0 = eight waves.  Applies to bias-only epilogues and to those of
  *   "w4_epilogues"    bit mask of the other epilogues whose whole rounds take the four-wave kernel: bit 1 GELU, 2 residual with f32 output
  *                     (default: 4), 3 GELU backward
+ *   "tn_pair"         1 = tad_linear_bwd_weight_pair runs its two problems as one launch when they fit (default); 0 = always two launches
  *   "tn_w4"           1 = the 256 x 256 weight-gradient GEMM runs as four waves of 128 x 128 outputs (default; bit-identical, 8 % faster);
  *                     0 = eight waves of 128 x 64
  *   "tn_pdeep"        1 = the weight-gradient GEMM requests its dy operand two reduction tiles ahead (three-slot ring, the whole
@@ -404,6 +415,9 @@ int tad_linear_bwd_weight_f16(const uint16_t* dy, const uint16_t* x, float* dW, 
                               int64_t M, int N, int K, tad_stream_t stream);
 int tad_linear_bwd_weight_qkv_f16(const uint16_t* dy, const uint16_t* x, float* dW, float* dq_bias, float* dv_bias, int accumulate,
                                   void* ws, size_t ws_bytes, int64_t M, int N, int K, tad_stream_t stream);
+int tad_linear_bwd_weight_pair_f16(const uint16_t* dy1, const uint16_t* x1, float* dW1, float* db1, float* db1b, int N1,
+                                   const uint16_t* dy2, const uint16_t* x2, float* dW2, int N2, int accumulate, void* ws,
+                                   size_t ws_bytes, int64_t M, int K, tad_stream_t stream);
 int tad_attn_fwd_f16(const uint16_t* qkv, void* out, int out_dtype, uint16_t* out_lo, float* lse, int B, int N, int H, int d,
                      float scale, int q_prescaled, float dropout_p, uint32_t seed, tad_stream_t stream);
 int tad_attn_bwd_f16(const uint16_t* qkv, const uint16_t* out, const uint16_t* out_lo, const uint16_t* dout, const float* lse,

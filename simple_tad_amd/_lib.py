@@ -34,6 +34,7 @@ SIGNATURES = {
     "tad_linear_tuning": (_i, [C.c_char_p, _i]),
     "tad_linear_fwd_qkv": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _i64, _i, _i, _vp]),
     "tad_linear_bwd_weight_qkv": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _i64, _i, _i, _vp]),
+    "tad_linear_bwd_weight_pair": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _sz, _i64, _i, _vp]),
     "tad_linear_debug_stamps": (_i, [_vp]),
     "tad_linear_kernel_launches": (C.c_longlong, []),
     "tad_linear_bwd_input": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _sz, _i64, _i, _i, _vp]),
@@ -90,7 +91,8 @@ F16_TWINS = {
     "tad_patch_embed_bwd": "tad_patch_embed_bwd_f16", "tad_layernorm_fwd": "tad_layernorm_fwd_f16",
     "tad_layernorm_bwd": "tad_layernorm_bwd_f16", "tad_linear_fwd": "tad_linear_fwd_f16", "tad_linear_fwd_qkv": "tad_linear_fwd_qkv_f16",
     "tad_linear_bwd_input": "tad_linear_bwd_input_f16", "tad_linear_bwd_weight": "tad_linear_bwd_weight_f16",
-    "tad_linear_bwd_weight_qkv": "tad_linear_bwd_weight_qkv_f16", "tad_attn_fwd": "tad_attn_fwd_f16", "tad_attn_bwd": "tad_attn_bwd_f16",
+    "tad_linear_bwd_weight_qkv": "tad_linear_bwd_weight_qkv_f16", "tad_linear_bwd_weight_pair": "tad_linear_bwd_weight_pair_f16",
+    "tad_attn_fwd": "tad_attn_fwd_f16", "tad_attn_bwd": "tad_attn_bwd_f16",
     "tad_meanpool_bwd": "tad_meanpool_bwd_f16", "tad_adamw_step": "tad_adamw_step_f16",
 }
 for _bf, _h in F16_TWINS.items():

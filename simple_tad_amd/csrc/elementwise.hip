@@ -549,9 +549,10 @@ int launch_reduce_col_ranges(const float* partial, int N, int splits, int c0, fl
 // The two reductions that follow a dW GEMM in ONE launch: the split-K slabs (as reduce_partials_kernel) and, in extra blocks at the
 // start of the grid, the bias column sums partial2[rows2][n2] -> out2a (columns [0, n2a)) and, if out2b, columns [c2b, c2b + n2a) ->
 // out2b (the qkv Linear: q_bias / v_bias ranges), else all n2 columns -> out2a.
+// outB != null (the pair launch of two weight gradients, launch_gemm_tn_pair): elements [0, nA) of a slab go to out, [nA, n) to outB.
 __global__ void reduce_dw_kernel(const float* __restrict__ partial, float* __restrict__ out, int splits, int64_t n, int accumulate,
                                  int slab_blocks, const float* __restrict__ partial2, int rows2, int n2, float* out2a, float* out2b, int n2a,
-                                 int c2b) {
+                                 int c2b, float* __restrict__ outB, int64_t nA) {
   // the (few, latency-bound) bias blocks come FIRST in the grid so that they run beside the slab blocks, not after them
   const int bias_blocks = (int)gridDim.x - slab_blocks;
   if ((int)blockIdx.x >= bias_blocks) {
@@ -563,14 +564,16 @@ __global__ void reduce_dw_kernel(const float* __restrict__ partial, float* __res
         const float4 v = reinterpret_cast<const float4*>(partial + (int64_t)k * n)[i];
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
       }
+      float4* const dst4 = (outB && 4 * i >= nA) ? reinterpret_cast<float4*>(outB) + (i - (nA >> 2)) : reinterpret_cast<float4*>(out) + i;
       if (accumulate) {
-        const float4 o = reinterpret_cast<float4*>(out)[i];
+        const float4 o = *dst4;
         s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
       }
-      reinterpret_cast<float4*>(out)[i] = s;
+      *dst4 = s;
     }
     return;
   }
+  if (!partial2) return;  // (pair launch without bias sums: no bias blocks are launched)
   // bias job: one float4 column group per thread
   const int c4 = (int)blockIdx.x * blockDim.x + threadIdx.x;
   const int groups = n2a >> 2;
@@ -606,8 +609,19 @@ int launch_reduce_dw(const float* partial, float* out, int splits, int64_t n, in
   const int groups = (out2b ? 2 : 1) * (n2a / 4);
   const int bias_blocks = (groups + 255) / 256;
   hipLaunchKernelGGL(reduce_dw_kernel, dim3(slab_blocks + bias_blocks), dim3(256), 0, st, partial, out, splits, n, accumulate, slab_blocks,
-                     partial2, rows2, n2, out2a, out2b, n2a, c2b);
+                     partial2, rows2, n2, out2a, out2b, n2a, c2b, (float*)nullptr, n);
   return check_launch("reduce_dw");
+}
+
+// the same over slabs that hold TWO outputs: elements [0, nA) -> outA, [nA, n) -> outB (nA % 4 == 0); partial2 == null: no bias sums
+int launch_reduce_dw_pair(const float* partial, float* outA, float* outB, int64_t nA, int splits, int64_t n, int accumulate, const float* partial2,
+                          int rows2, int n2, float* out2a, float* out2b, int n2a, int c2b, hipStream_t st) {
+  const int slab_blocks = capped_grid((n + 3) / 4, 256);
+  const int groups = partial2 ? (out2b ? 2 : 1) * (n2a / 4) : 0;
+  const int bias_blocks = (groups + 255) / 256;
+  hipLaunchKernelGGL(reduce_dw_kernel, dim3(slab_blocks + bias_blocks), dim3(256), 0, st, partial, outA, splits, n, accumulate, slab_blocks,
+                     partial2, rows2, n2, out2a, out2b, n2a, c2b, outB, nA);
+  return check_launch("reduce_dw_pair");
 }
 
 int launch_reduce_partials(const float* partial, float* out, int splits, int64_t n, int accumulate, hipStream_t st) {

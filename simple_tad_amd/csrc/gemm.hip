@@ -29,6 +29,8 @@ int launch_reduce_col_ranges(const float* partial, int N, int splits, int c0, fl
                              hipStream_t st);
 int launch_reduce_dw(const float* partial, float* out, int splits, int64_t n, int accumulate, const float* partial2, int rows2, int n2,
                      float* out2a, float* out2b, int n2a, int c2b, hipStream_t st);
+int launch_reduce_dw_pair(const float* partial, float* outA, float* outB, int64_t nA, int splits, int64_t n, int accumulate, const float* partial2,
+                          int rows2, int n2, float* out2a, float* out2b, int n2a, int c2b, hipStream_t st);
 
 // EPI_RESMOD = EPI_RESIDUAL with the residual row taken modulo res_mod ("+ pos_embed" of the patch embedding): a variant of its
 // own so that the integer division stays out of the Linear kernels
@@ -1026,6 +1028,12 @@ struct GemmTN {
   int Mr, N, K;
   int rows_per_split;  // multiple of 64
   int debug;           // ablation bits as in GemmNT
+  // PAIR (gemm_tn_w4_kernel only; launch_gemm_tn_pair): TWO weight gradients with the same Mr and K in one launch.  Output rows [0, N1) are
+  // P^T Q of the first problem (P [Mr, N1]), rows [N1, N) those of the second (P2 [Mr, N - N1], Q2 [Mr, K]); N1 is a multiple of 256 so that no
+  // tile straddles the two, and only the first problem has bias column sums.  N1 = 0: one problem
+  const uint16_t* P2;
+  const uint16_t* Q2;
+  int N1;
 };
 
 // swizzle of the 16-byte chunk index within a tile row (rows are >= 256 bytes); changes bits 1..3 only
@@ -1287,6 +1295,7 @@ int nt_w4_plain = getenv("TAD_GEMM_W4_PLAIN") ? env_int("TAD_GEMM_W4_PLAIN") : 6
 // "w4_epilogues=0;w4_epilogues=14", eight / four waves): proj + residual 96.0 / 96.9 us, fc2 + residual 250.4 / 241.1, fc1 GELU 278.1 / 282.1, dX(fc2) GELU backward
 // 291.2 / 338.8 -- the residual epilogue (bit 2) is on by default, the vector-heavy GELU ones stay on eight waves
 int nt_w4_epilogues = getenv("TAD_GEMM_W4_EPILOGUES") ? env_int("TAD_GEMM_W4_EPILOGUES") : 4;
+int tn_pair = getenv("TAD_GEMM_TN_PAIR") ? env_int("TAD_GEMM_TN_PAIR") : 1;  // 1: tad_linear_bwd_weight_pair runs its two problems as one launch when they fit (launch_gemm_tn_pair); 0: always two launches
 int nt_short_k = getenv("TAD_GEMM_SHORT_K") ? env_int("TAD_GEMM_SHORT_K") : 1;  // 1: the short-K plan of launch_gemm_nt (K <= 512: tiles that put two workgroups on a CU)
 int nt_tail_192 = getenv("TAD_GEMM_TAIL_192") ? env_int("TAD_GEMM_TAIL_192") : 1;  // 1: tails of the split plan may run as 192 x 128 tiles (nt_tail_variant)
 int tn_w4 = getenv("TAD_GEMM_TN_W4") ? env_int("TAD_GEMM_TN_W4") : 1;  // 1: the 256 x 256 weight-gradient GEMM runs as four waves of 128 x 128 (gemm_w4.hip)
@@ -1294,7 +1303,7 @@ int tn_pdeep = env_int("TAD_GEMM_TN_PDEEP");  // 1: gemm_tn 256 x 256 with the P
 unsigned long long* nt_stamps = nullptr;
 long long nt_launches = 0;  // gemm_nt kernel launches so far (tad_linear_kernel_launches)
 #else
-extern int gemm_debug, nt_persist, nt_direct, nt_split, nt_splitk, nt_variant, nt_group_m_knob, tn_variant, tn_pdeep, nt_sk_defer, tn_w4, nt_w4_plain, nt_w4_epilogues, nt_tail_192, nt_short_k;
+extern int gemm_debug, nt_persist, nt_direct, nt_split, nt_splitk, nt_variant, nt_group_m_knob, tn_variant, tn_pdeep, nt_sk_defer, tn_w4, nt_w4_plain, nt_w4_epilogues, nt_tail_192, nt_short_k, tn_pair;
 extern unsigned long long* nt_stamps;
 extern long long nt_launches;
 #endif
@@ -1686,7 +1695,7 @@ int launch_gemm_tn(const uint16_t* P, const uint16_t* Q, float* out, float* bias
   if (!(Mr > 0 && N > 0 && K > 0)) { set_error("gemm_tn: empty problem"); return TAD_EINVAL; }
   if (N % 8 || K % 8) { set_error("gemm_tn: N=%d and K=%d must be multiples of 8", N, K); return TAD_EINVAL; }
   if (Mr * (int64_t)N * 2 >= (1ll << 32) || Mr * (int64_t)K * 2 >= (1ll << 32)) { set_error("gemm_tn: operand exceeds 4 GiB"); return TAD_EINVAL; }
-  GemmTN p;
+  GemmTN p{};
   p.P = P; p.Q = Q; p.slab = (float*)ws; p.Mr = (int)Mr; p.N = N; p.K = K;
   p.debug = gemm_debug;
   int splits;
@@ -1711,6 +1720,41 @@ int launch_gemm_tn(const uint16_t* P, const uint16_t* Q, float* out, float* bias
   // slab reduction and bias column sums in one launch (N * K % 4 == 0 and N % 4 == 0 hold: N, K are multiples of 8)
   if (bias_out2) return launch_reduce_dw(p.slab, out, splits, (int64_t)N * K, accumulate, p.bias_slab, splits * tiles_k, N, bias_out, bias_out2, N / 3, 2 * (N / 3), st);
   return launch_reduce_dw(p.slab, out, splits, (int64_t)N * K, accumulate, p.bias_slab, splits * tiles_k, N, bias_out, nullptr, N, 0, st);
+}
+
+// Two weight gradients over the same rows with the same K as ONE launch of the four-wave kernel (GemmTN::N1): out1 [N1, K] = P1^T Q1 with its
+// bias column sums (bias_out1, or split into bias_out1 / bias_out1b as for the qkv Linear), out2 [N2, K] = P2^T Q2.  A small problem pays for
+// filling the chip with many splits -- the 768 x 768 proj gradient of ViT-B runs 9 tiles x 28 splits: 28 slabs to write and sum, an epilogue per
+// 28 reduction tiles -- where the pair (36 tiles x 7 splits: the shape of the fc1 gradient) pays once: qkv + proj 160.8 + 71.7 us apart, ~197 as a
+// pair.  Falls back to two launches when the pair does not fit the kernel (K not on 256-wide tiles, N1 not a multiple of 256, four-wave kernel off).
+// The summation order over the rows differs from the single launches' (another split count), as between any two batch sizes.
+int launch_gemm_tn_pair(const uint16_t* P1, const uint16_t* Q1, float* out1, float* bias_out1, float* bias_out1b, int N1, const uint16_t* P2,
+                        const uint16_t* Q2, float* out2, int N2, int accumulate, void* ws, size_t ws_bytes, int64_t Mr, int K, hipStream_t st) {
+  if (!(Mr > 0 && N1 > 0 && N2 > 0 && K > 0)) { set_error("gemm_tn_pair: empty problem"); return TAD_EINVAL; }
+  if (N1 % 8 || N2 % 8 || K % 8) { set_error("gemm_tn_pair: N1=%d, N2=%d and K=%d must be multiples of 8", N1, N2, K); return TAD_EINVAL; }
+  const int N = N1 + N2;
+  int splits = 0, rows_per_split = 0;
+  const int tiles = tn_plan(Mr, N, K, &splits, &rows_per_split);
+  const int tiles_k = (K + 255) / 256;
+  const bool fits = tn_pair && tn_variant(K) == 1 && knobs::tn_w4 && !knobs::tn_pdeep && !gemm_debug && N1 % 256 == 0 && rows_per_split >= 2 * BK &&
+                    Mr * (int64_t)N * 2 < (1ll << 32) && Mr * (int64_t)K * 2 < (1ll << 32) &&
+                    ws_bytes >= (size_t)splits * ((size_t)N * K + (size_t)tiles_k * N) * sizeof(float);
+  if (!fits) {
+    const int rc = launch_gemm_tn(P1, Q1, out1, bias_out1, bias_out1b, accumulate, ws, ws_bytes, Mr, N1, K, st);
+    if (rc) return rc;
+    return launch_gemm_tn(P2, Q2, out2, nullptr, nullptr, accumulate, ws, ws_bytes, Mr, N2, K, st);
+  }
+  GemmTN p{};
+  p.P = P1; p.Q = Q1; p.P2 = P2; p.Q2 = Q2; p.N1 = N1;
+  p.slab = (float*)ws; p.Mr = (int)Mr; p.N = N; p.K = K; p.rows_per_split = rows_per_split;
+  p.bias_slab = bias_out1 ? p.slab + (size_t)splits * N * K : nullptr;
+  int rc = launch_gemm_tn_w4(p, tiles * splits, st);
+  if (rc) return rc;
+  // slabs [splits][N][K]: rows [0, N1) -> out1, rows [N1, N) -> out2, both in one launch (with the bias column sums of the first problem)
+  const int64_t n1 = (int64_t)N1 * K, n = (int64_t)N * K;
+  if (!bias_out1) return launch_reduce_dw_pair(p.slab, out1, out2, n1, splits, n, accumulate, nullptr, 0, 0, nullptr, nullptr, 0, 0, st);
+  if (bias_out1b) return launch_reduce_dw_pair(p.slab, out1, out2, n1, splits, n, accumulate, p.bias_slab, splits * tiles_k, N, bias_out1, bias_out1b, N1 / 3, 2 * (N1 / 3), st);
+  return launch_reduce_dw_pair(p.slab, out1, out2, n1, splits, n, accumulate, p.bias_slab, splits * tiles_k, N, bias_out1, nullptr, N1, 0, st);
 }
 
 TAD_NAMESPACE_END
@@ -1786,6 +1830,14 @@ int tad_linear_bwd_weight_qkv(const uint16_t* dy, const uint16_t* x, float* dW, 
   return launch_gemm_tn(dy, x, dW, dq_bias, dv_bias, accumulate, ws, ws_bytes, M, N, K, (hipStream_t)stream);
 }
 
+int tad_linear_bwd_weight_pair(const uint16_t* dy1, const uint16_t* x1, float* dW1, float* db1, float* db1b, int N1, const uint16_t* dy2,
+                               const uint16_t* x2, float* dW2, int N2, int accumulate, void* ws, size_t ws_bytes, int64_t M, int K, tad_stream_t stream) {
+  TAD_REQUIRE(dy1 && x1 && dW1 && dy2 && x2 && dW2 && ws, "linear_bwd_weight_pair: null pointer");
+  TAD_REQUIRE(!db1b || db1, "linear_bwd_weight_pair: db1b (the v_bias third) comes with db1 (the q_bias third)");
+  TAD_REQUIRE(!db1b || (N1 > 0 && N1 % 12 == 0), "linear_bwd_weight_pair: N1=%d must be 3 x a multiple of 4 for the split bias sums", N1);
+  return launch_gemm_tn_pair(dy1, x1, dW1, db1, db1b, N1, dy2, x2, dW2, N2, accumulate, ws, ws_bytes, M, K, (hipStream_t)stream);
+}
+
 #ifndef TAD_OPND_F16  // process-wide knobs / counters: one copy for the library (bf16 pass)
 int tad_linear_tuning(const char* key, int value) {
   TAD_REQUIRE(key, "linear_tuning: null key");
@@ -1797,6 +1849,7 @@ int tad_linear_tuning(const char* key, int value) {
   else if (k == "group_m") { TAD_REQUIRE(value >= 0 && value <= 1024, "linear_tuning: group_m=%d out of range", value); nt_group_m_knob = value; }
   else if (k == "variant") { TAD_REQUIRE(value >= 0 && value <= 9 && value != 6, "linear_tuning: variant=%d not one of 0..5, 7, 8, 9", value); nt_variant = value; }
   else if (k == "splitk_defer") { TAD_REQUIRE(value == 0 || value == 1, "linear_tuning: splitk_defer=%d not in {0, 1}", value); nt_sk_defer = value; }
+  else if (k == "tn_pair") { TAD_REQUIRE(value == 0 || value == 1, "linear_tuning: tn_pair=%d not in {0, 1}", value); tn_pair = value; }
   else if (k == "short_k") { TAD_REQUIRE(value == 0 || value == 1, "linear_tuning: short_k=%d not in {0, 1}", value); nt_short_k = value; }
   else if (k == "tail_192") { TAD_REQUIRE(value == 0 || value == 1, "linear_tuning: tail_192=%d not in {0, 1}", value); nt_tail_192 = value; }
   else if (k == "w4_epilogues") { TAD_REQUIRE(value >= 0 && value < 16, "linear_tuning: w4_epilogues=%d not a mask of bits 1..3", value); nt_w4_epilogues = value; }

@@ -65,23 +65,29 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(const GemmTN p) {
   const int n0 = tn_ * BM, k0 = tk_ * BN;
   const int mr0 = split * p.rows_per_split;
   const int nt = p.rows_per_split / BK;  // >= 2 (launcher)
-  const int p_bytes = (int)((int64_t)p.Mr * p.N * 2), q_bytes = (int)((int64_t)p.Mr * p.K * 2);
+  // PAIR (GemmTN::N1): tiles of output rows >= N1 belong to the second problem -- its own operands, P with its own leading dimension
+  const bool seg2 = p.N1 > 0 && n0 >= p.N1;  // (uniform)
+  const uint16_t* const Pg = seg2 ? p.P2 : p.P;
+  const uint16_t* const Qg = seg2 ? p.Q2 : p.Q;
+  const int ldp = p.N1 > 0 ? (seg2 ? p.N - p.N1 : p.N1) : p.N;  // columns of this tile's P operand
+  const int np0 = seg2 ? n0 - p.N1 : n0;                        // the tile's first column in it
+  const int p_bytes = (int)((int64_t)p.Mr * ldp * 2), q_bytes = (int)((int64_t)p.Mr * p.K * 2);
   // DMA: piece = 1 KiB = 2 rows of 512 B; piece i of wave w = rows 2 (4 i + w), + 1; lane -> row lane / 32, 16-byte chunk lane % 32
   uint32_t p_off[8], q_off[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int row = (i * NW + wave) * 2 + (lane >> 5);
     const int chunk = (lane & 31) ^ sw_tn(row);
-    int col = n0 + chunk * 8;
-    if (col > p.N - 8) col = p.N - 8;  // (columns beyond N only feed outputs that are never stored; the clamp keeps the address in the row)
-    p_off[i] = (uint32_t)(mr0 + row) * (uint32_t)(p.N * 2) + (uint32_t)(col * 2);
+    int col = np0 + chunk * 8;
+    if (col > ldp - 8) col = ldp - 8;  // (columns beyond N only feed outputs that are never stored; the clamp keeps the address in the row)
+    p_off[i] = (uint32_t)(mr0 + row) * (uint32_t)(ldp * 2) + (uint32_t)(col * 2);
     col = k0 + chunk * 8;
     if (col > p.K - 8) col = p.K - 8;
     q_off[i] = (uint32_t)(mr0 + row) * (uint32_t)(p.K * 2) + (uint32_t)(col * 2);
   }
 #define TNW4_PIECE(SLOT, idx, t_)                                                                                                            \
-  if ((idx) < 8) w4_dma_piece(p.P, p_bytes, lds + (SLOT) + (((idx) & 7) * NW + wave) * 1024, p_off[(idx) & 7], (uint32_t)(t_) * BK * (uint32_t)(p.N * 2)); \
-  else w4_dma_piece(p.Q, q_bytes, lds + (SLOT) + P_BYTES + (((idx) & 7) * NW + wave) * 1024, q_off[(idx) & 7], (uint32_t)(t_) * BK * (uint32_t)(p.K * 2))
+  if ((idx) < 8) w4_dma_piece(Pg, p_bytes, lds + (SLOT) + (((idx) & 7) * NW + wave) * 1024, p_off[(idx) & 7], (uint32_t)(t_) * BK * (uint32_t)(ldp * 2)); \
+  else w4_dma_piece(Qg, q_bytes, lds + (SLOT) + P_BYTES + (((idx) & 7) * NW + wave) * 1024, q_off[(idx) & 7], (uint32_t)(t_) * BK * (uint32_t)(p.K * 2))
   // transposed fragment reads (gemm_tn_kernel): 16-lane group g covers reduction rows 8 g .. + 7 of a k-step, lane li of the group
   // supplies row li >> 2 (+ 4 for the second read), columns c0 + 4 (li & 3) .. + 3
   const int g = lane >> 4, li = lane & 15;
@@ -100,7 +106,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(const GemmTN p) {
   }
   // bias gradient = column sums of P (one extra MFMA per row fragment against an all-ones operand), shared out as in gemm_tn_kernel:
   // the tiles_k workgroups of a row panel take turns over the reduction tiles, the two waves of a row split the fragments
-  const bool bias_on = p.bias_slab != nullptr;
+  const bool bias_on = p.bias_slab != nullptr && !seg2;  // (PAIR: only the first problem has bias column sums)
   op16x8 ones;
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (op16_t)1.0f;

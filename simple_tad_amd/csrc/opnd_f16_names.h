@@ -20,6 +20,7 @@
 #define tad_linear_bwd_input tad_linear_bwd_input_f16
 #define tad_linear_bwd_weight tad_linear_bwd_weight_f16
 #define tad_linear_bwd_weight_qkv tad_linear_bwd_weight_qkv_f16
+#define tad_linear_bwd_weight_pair tad_linear_bwd_weight_pair_f16
 #define tad_attn_fwd tad_attn_fwd_f16
 #define tad_attn_bwd tad_attn_bwd_f16
 #define tad_meanpool_bwd tad_meanpool_bwd_f16

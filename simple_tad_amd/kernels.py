@@ -452,7 +452,7 @@ def _pad_reduction(a, b, mult: int = 64):
     return torch.nn.functional.pad(a, (0, pad)).contiguous(), torch.nn.functional.pad(b, (0, pad)).contiguous()
 
 
-LINEAR_TUNING_DEFAULTS = dict(persistent=1, direct_epilogue=1, split_tail=1, splitk_tail=1, group_m=0, variant=0, tn_pdeep=0, splitk_defer=1, tn_w4=1, w4_plain=640, w4_epilogues=4, tail_192=1, short_k=1)
+LINEAR_TUNING_DEFAULTS = dict(persistent=1, direct_epilogue=1, split_tail=1, splitk_tail=1, group_m=0, variant=0, tn_pdeep=0, splitk_defer=1, tn_w4=1, w4_plain=640, w4_epilogues=4, tail_192=1, short_k=1, tn_pair=1)
 
 
 def linear_workspace(nbytes: int, device) -> torch.Tensor:
@@ -567,6 +567,25 @@ def linear_bwd_weight_qkv(dy, x, dW, dq_bias, dv_bias, accumulate):
         check(_fn("tad_linear_bwd_weight_qkv", op)(dy.data_ptr(), x.data_ptr(), dW.data_ptr(), dq_bias.data_ptr(), dv_bias.data_ptr(), int(accumulate),
                                             ws.data_ptr(), ws.numel(), M, N, K, _stream()), "tad_linear_bwd_weight_qkv")
     return dW
+
+
+def linear_bwd_weight_pair(dy1, x1, dW1, db1, db1b, dy2, x2, dW2, accumulate):
+    """two weight gradients over the same rows with the same K in one call (tad_linear_bwd_weight_pair): dW1 [N1,K] (+)= dy1^T x1 with its
+    bias column sums (db1 [N1] | None; db1b given: the first / last third to db1 / db1b), dW2 [N2,K] (+)= dy2^T x2.  In place."""
+    op = _req16(dy1, "linear_bwd_weight_pair.dy1")
+    for t, n in ((x1, "x1"), (dy2, "dy2"), (x2, "x2")):
+        _req16(t, "linear_bwd_weight_pair." + n, like=op)
+    M, N1 = dy1.shape
+    N2 = dy2.shape[1]
+    K = x1.shape[1]
+    assert x1.shape[0] == M and dy2.shape[0] == M and x2.shape == (M, K), "linear_bwd_weight_pair: the two problems share M and K"
+    assert dW1.shape == (N1, K) and dW2.shape == (N2, K) and dW1.dtype == dW2.dtype == torch.float32
+    lib = _lib.load()
+    ws = workspace(max(lib.tad_linear_bwd_weight_workspace_bytes(M, n, K) for n in (N1, N2, N1 + N2)), dy1.device)
+    with _timed("gemm_tn", 2.0 * M * (N1 + N2) * K, 2.0 * (M * (N1 + N2) + 2 * M * K) + 4.0 * (N1 + N2) * K):
+        check(_fn("tad_linear_bwd_weight_pair", op)(dy1.data_ptr(), x1.data_ptr(), dW1.data_ptr(), _p(db1), _p(db1b), N1, dy2.data_ptr(), x2.data_ptr(),
+                                                    dW2.data_ptr(), N2, int(accumulate), ws.data_ptr(), ws.numel(), M, K, _stream()),
+              "tad_linear_bwd_weight_pair")
 
 
 def colsum_bf16(a, out=None):

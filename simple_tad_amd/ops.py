@@ -428,12 +428,14 @@ def _attn_fwd_core(xn, qkv_w, q_bias, v_bias, B, N, H, scale, train, drop=(0.0, 
 
 
 def _attn_bwd_core(d_ao, xn, qkv, ao, lse, qkv_w, has_qkv_bias, B, N, H, scale, dx_dtype, qv_params=None, ao_lo=None, drop=(0.0, 0),
-                   q_prescaled=None):
+                   q_prescaled=None, pair=None):
     """returns dxn, dWqkv, dq_bias, dv_bias (None for what went into gradient sinks).  q_prescaled: the q contract of the forward
-    that produced `qkv` (ctx.qpre)"""
+    that produced `qkv` (ctx.qpre).  pair = (dy, x, w) of ANOTHER bias-less weight gradient over the same rows with the same K that is due
+    (the Block's proj: dy = the 16-bit gradient of its output, x = the attention output): a fifth value is returned then, that Linear's dW
+    (None if it went into its gradient sink).  With sinks on all parameters the two weight gradients run as ONE launch
+    (K.linear_bwd_weight_pair: a 768 x 768 gradient alone fills the chip with 9 tiles x 28 reduction shares, the pair with 36 x 7)."""
     if q_prescaled is None:
         q_prescaled = _attn_q_prescale
-    D = xn.shape[1]
     if qkv.dtype == torch.float32:  # generic head dim (see _attn_fwd_core)
         dqkv = K.cast_bf16(K.attn_bwd_f32(qkv, ao.float(), d_ao.float(), lse, B, N, H, scale, d=head_dim_of(qkv_w, H), drop_p=drop[0],
                                           seed=drop[1]))
@@ -441,21 +443,35 @@ def _attn_bwd_core(d_ao, xn, qkv, ao, lse, qkv_w, has_qkv_bias, B, N, H, scale, 
         dqkv = K.attn_bwd(qkv, ao, d_ao, lse, B, N, H, scale, out_lo=ao_lo, q_prescaled=q_prescaled, drop_p=drop[0], seed=drop[1],
                           d=head_dim_of(qkv_w, H))
     dxn = K.linear_bwd_input(dqkv, wT_bf16(qkv_w, True), out_dtype=dx_dtype)
+
+    def done(*r):  # (+ the pair's weight gradient by itself when it did not ride along)
+        return r if pair is None else r + (linear_dw(pair[0], pair[1], pair[2])[0],)
+
     if has_qkv_bias and qv_params is not None:
         ents = [_sink(qkv_w), _sink(qv_params[0]), _sink(qv_params[1])]
         if all(e is not None for e in ents):
             # dW, dq_bias and dv_bias accumulate straight into the flat gradient buffer: no [3D] temporary, no slicing copies, no
             # autograd accumulation kernels
-            K.linear_bwd_weight_qkv(dqkv, xn, ents[0][1].view(qkv_w.shape[0], -1), ents[1][1], ents[2][1], accumulate=True)
-            for ent, prm in zip(ents, (qkv_w,) + tuple(qv_params)):
+            prms = (qkv_w,) + tuple(qv_params)
+            sp = _sink(pair[2]) if pair is not None else None
+            paired = sp is not None and pair[0].dtype == dqkv.dtype and pair[1].shape == xn.shape and pair[0].shape[0] == dqkv.shape[0]
+            if paired:
+                K.linear_bwd_weight_pair(dqkv, xn, ents[0][1].view(qkv_w.shape[0], -1), ents[1][1], ents[2][1], pair[0], pair[1],
+                                         sp[1].view(pair[2].shape[0], -1), accumulate=True)
+                ents, prms = ents + [sp], prms + (pair[2],)
+            else:
+                K.linear_bwd_weight_qkv(dqkv, xn, ents[0][1].view(qkv_w.shape[0], -1), ents[1][1], ents[2][1], accumulate=True)
+            for ent, prm in zip(ents, prms):
                 if ent[2] is not None:
                     ent[2](prm)
-            return dxn, None, None, None
+            if paired:
+                return dxn, None, None, None, None
+            return done(dxn, None, None, None)
     dWqkv, dbqkv = linear_dw(dqkv, xn, qkv_w, None, loose_bias=has_qkv_bias)
     if has_qkv_bias:
         AH = dbqkv.numel() // 3
-        return dxn, dWqkv, dbqkv[:AH].clone(), dbqkv[2 * AH:].clone()
-    return dxn, dWqkv, None, None
+        return done(dxn, dWqkv, dbqkv[:AH].clone(), dbqkv[2 * AH:].clone())
+    return done(dxn, dWqkv, None, None)
 
 
 class AttentionFn(_Fn):
@@ -636,8 +652,9 @@ class BlockFn(_Fn):
                                                         rowscale=dp1, rows_per_scale=N)
         # ---- attention branch
         d_ao = K.linear_bwd_input(gpb, wT_bf16(proj_w, True))
-        dWp, _ = linear_dw(gpb, ao, proj_w)
-        dxn1, dWqkv, dqb, dvb = _attn_bwd_core(d_ao, xn1, qkv, ao, lse, qkv_w, has_qb, B, N, H, scale, None, ctx.qv, ao_lo=ao_lo, q_prescaled=ctx.qpre)
+        # (the proj weight gradient rides with the qkv one: one launch for both, _attn_bwd_core)
+        dxn1, dWqkv, dqb, dvb, dWp = _attn_bwd_core(d_ao, xn1, qkv, ao, lse, qkv_w, has_qb, B, N, H, scale, None, ctx.qv, ao_lo=ao_lo, q_prescaled=ctx.qpre,
+                                                     pair=(gpb, ao, proj_w))
         prev = ctx.prev_link
         if prev is not None:
             gin, ginb, dg1, dbeta1, _ = layernorm_bwd_sunk(dxn1, x0, g1, mean1, rstd1, n1w, n1b, dres=gmid, want_bf16=True, rowscale=prev.dp2,

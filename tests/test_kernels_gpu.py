@@ -589,6 +589,73 @@ def test_weight_gradient_four_wave_kernel_is_bit_identical(K, M, N, Kd):
     check(outs[1][1], dy.double().sum(0), what="db (four-wave kernel)")
 
 
+@pytest.mark.parametrize("M,N1,N2,Kd,qkv", [(50176, 2304, 768, 768, True), (25088 + 70, 768, 768 + 8, 768, False), (12544, 3072, 1024, 1024, True),
+                                            (20000, 1152, 384, 384, True), (30000, 2304 + 24, 768, 768, True), (1024, 512, 256, 256, False)])
+def test_weight_gradient_pair_launch(K, M, N1, N2, Kd, qkv):
+    """tad_linear_bwd_weight_pair: the qkv and proj weight gradients of a Block as ONE launch of the four-wave kernel (output rows >= N1 take the
+    second problem's operands) against the two single calls -- the same products summed over the rows in another order (a different share
+    count), so equal to f32 summation accuracy, not bit for bit; bit for bit where the pair falls back to two launches (K on 128-wide tiles,
+    N1 not a multiple of 256, tn_pair = 0), deterministic, accumulate mode, split (qkv) and plain bias sums, right against f64."""
+    g = torch.Generator().manual_seed(M + N1 + N2)
+    dy1 = dev(torch.randn(M, N1, generator=g)).to(torch.bfloat16)
+    x1 = dev(torch.randn(M, Kd, generator=g)).to(torch.bfloat16)
+    dy2 = dev(torch.randn(M, N2, generator=g)).to(torch.bfloat16)
+    x2 = dev(torch.randn(M, Kd, generator=g)).to(torch.bfloat16)
+
+    def single(acc):
+        dW1 = torch.full((N1, Kd), 0.5 if acc else 0.0, device="cuda")
+        dW2 = torch.full((N2, Kd), 0.25 if acc else 0.0, device="cuda")
+        if qkv:
+            dq, dv = torch.full((N1 // 3,), 1.0 if acc else 0.0, device="cuda"), torch.full((N1 // 3,), 2.0 if acc else 0.0, device="cuda")
+            K.linear_bwd_weight_qkv(dy1, x1, dW1, dq, dv, accumulate=acc)
+            b = (dq, dv)
+        else:
+            db = torch.full((N1,), 1.0 if acc else 0.0, device="cuda")
+            K.linear_bwd_weight(dy1, x1, want_bias=True, dW=dW1, db=db, accumulate=acc)
+            b = (db,)
+        K.linear_bwd_weight(dy2, x2, want_bias=False, dW=dW2, accumulate=acc)
+        return (dW1, dW2) + b
+
+    def pair(acc):
+        dW1 = torch.full((N1, Kd), 0.5 if acc else 0.0, device="cuda")
+        dW2 = torch.full((N2, Kd), 0.25 if acc else 0.0, device="cuda")
+        if qkv:
+            dq, dv = torch.full((N1 // 3,), 1.0 if acc else 0.0, device="cuda"), torch.full((N1 // 3,), 2.0 if acc else 0.0, device="cuda")
+            K.linear_bwd_weight_pair(dy1, x1, dW1, dq, dv, dy2, x2, dW2, accumulate=acc)
+            b = (dq, dv)
+        else:
+            db = torch.full((N1,), 1.0 if acc else 0.0, device="cuda")
+            K.linear_bwd_weight_pair(dy1, x1, dW1, db, None, dy2, x2, dW2, accumulate=acc)
+            b = (db,)
+        return (dW1, dW2) + b
+
+    # one launch when N1 is a multiple of 256 and K runs on the 256-wide tiles (tn_variant: unless those would pad K by a third or more)
+    one_launch = N1 % 256 == 0 and -(-Kd // 256) * 256 * 3 < -(-Kd // 128) * 128 * 4
+    for acc in (False, True):
+        s_, p_ = single(acc), pair(acc)
+        p2 = pair(acc)
+        torch.cuda.synchronize()
+        for a_, b_, c_ in zip(s_, p_, p2):
+            assert torch.equal(b_, c_), "pair launch is not deterministic"
+            if one_launch:
+                scale = float(a_.abs().max())
+                assert float((a_ - b_).abs().max()) <= 2e-5 * scale + 1e-4, f"pair vs single calls: {float((a_ - b_).abs().max()):.3e} of {scale:.3e}"
+            else:
+                assert torch.equal(a_, b_), "fallback of the pair differs from the single calls"
+    try:
+        K.linear_tuning(tn_pair=0)
+        for a_, b_ in zip(single(True), pair(True)):
+            assert torch.equal(a_, b_), "tn_pair = 0 differs from the single calls"
+    finally:
+        K.linear_tuning(**K.LINEAR_TUNING_DEFAULTS)
+    dW1, dW2 = pair(False)[:2]
+    rows = torch.randint(0, min(N1, N2), (12,), generator=g).tolist() + [0, min(N1, N2) - 1]
+    check(dW1[rows], dy1[:, rows].double().t() @ x1.double(), what="dW1 (pair)")
+    check(dW2[rows], dy2[:, rows].double().t() @ x2.double(), what="dW2 (pair)")
+    check(dW1[[N1 - 1]], dy1[:, [N1 - 1]].double().t() @ x1.double(), what="dW1 last row (pair)")
+    check(dW2[[N2 - 1]], dy2[:, [N2 - 1]].double().t() @ x2.double(), what="dW2 last row (pair)")
+
+
 @pytest.mark.parametrize("M,D,Kd", [(25088 + 5, 768, 768), (20000 + 3, 384, 384), (300, 128, 128), (40000, 1024, 256)])
 def test_qkv_linear_q_prescale_every_schedule(K, M, D, Kd):
     """tad_linear_fwd_qkv(q_prescale): `q = q * self.scale` (modeling_finetune.py:96) folded into the qkv Linear -- the q third of the
