@@ -118,6 +118,14 @@ __device__ __forceinline__ void stage_tile(const void* gbase, int gbytes, char* 
                       // round 4 (tools/ab_gemm.py, eight in-model shapes: sum 1537.0 vs 1534.8 us; fc1 -3, dX(fc2) +3.5): the epilogue is bound by its
                       // vector work (GELU polynomials, conversions), not by the chunk barriers -- off
 #endif
+#ifndef TAD_W4_PREFETCH
+#define TAD_W4_PREFETCH 0  // (experiment, round 5; 4 or 8 to build it) four-wave gemm_nt kernels: each wave touches one cache line per row of the x panel's K-tile
+                           // kt + 2 + TAD_W4_PREFETCH (a 4-byte LDS-DMA into a sink) right behind the LDS-DMA pieces of K-tile kt + 2, so that the lines are in the
+                           // L2 when their own pieces ask for them -- for the bias-only Linears with K >= 2560 (an x panel of 1.2 MB and more per tile row, streamed
+                           // from beyond the last-level cache).  Bit-identical.  Measured (tools/ab_gemm.py, 15 rounds): dX(fc1) 214.7 -> 204.4 us, every other
+                           // shape 0-1.5 % slower (the wait that leaves the touch in flight), block sum 1465.9 -> 1460.5; the step 722.7 -> 723.0 clips/s over
+                           // three alternations: nothing.  With the touch on every shape the K = 768 / 2304 ones lose 2 %; distance 8 is no better.  Off
+#endif
 #ifndef TAD_NT_PEEL
 #define TAD_NT_PEEL 1  // last K-tile of the persistent bias-only 16-bit kernel peeled (see PEEL in gemm_nt_kernel); 0 = the round-1 schedule
 #endif
@@ -193,7 +201,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
   constexpr int CROWS = EPI_DB ? 32 : BM < 128 ? BM : BM == 192 ? 64 : (((BN > 128 || (NW == 4 && BM == 256)) && IS_RES && !OUT_BF16) ? 32 : (((PERSIST && BN > 128) || NW == 4) ? 64 : 128));
   constexpr int EPI_OFF = PERSIST ? STAGE_BYTES : 0;
   constexpr int EPI_BYTES = DIRECT ? 0 : (EPI_DB ? 2 : 1) * CROWS * (BN * 4 + 16);
-  constexpr int LDS_BYTES = STAGES * STAGE_BYTES > EPI_OFF + EPI_BYTES ? STAGES * STAGE_BYTES : EPI_OFF + EPI_BYTES;
+  constexpr int LDS_MAIN = STAGES * STAGE_BYTES > EPI_OFF + EPI_BYTES ? STAGES * STAGE_BYTES : EPI_OFF + EPI_BYTES;
+  constexpr bool W4PF = W4 && TAD_W4_PREFETCH > 0;                       // L2 prefetch of the x panel (see TAD_W4_PREFETCH)
+  constexpr int PF_SINK = (LDS_MAIN + 1023) / 1024 * 1024;               // 4 x 256 bytes nobody reads
+  constexpr int LDS_BYTES = W4PF ? PF_SINK + 1024 : LDS_MAIN;
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
   __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
 
@@ -252,8 +263,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
   // ---- DMA addressing: one wave-instruction fills RPP LDS rows (1 KiB); lane -> (row lane/CPR, physical chunk lane%CPR)
   const int drow = lane / CPR, dchunk = lane % CPR;
   uint32_t a_off[BM / (RPP * NW)], b_off[BN / (RPP * NW)];
+  uint32_t pf_off = 0;  // (W4PF) byte offset of the x row this lane touches: the wave's 64 rows, one per lane
 #define TILE_OFFSETS()                                                                                                 \
   {                                                                                                                    \
+    if constexpr (W4PF) pf_off = (EPI == EPI_PLAIN && p.K >= 2560) ? (uint32_t)(m0 + ((lane & 7) * NW + wave) * RPP + (lane >> 3)) * lda_b : 0x80000000u; /* (out of range: dropped) */ \
     _Pragma("unroll") for (int i = 0; i < BM / (RPP * NW); ++i) {                                                      \
       const int row = (i * NW + wave) * RPP + drow;                                                                    \
       a_off[i] = (uint32_t)(((DBG_BITS(p) & 64) ? 0 : m0) + row) * lda_b + (uint32_t)((dchunk ^ sw_nt(row)) * 16);  /* (debug 64, timing only: every tile reads the A rows of tile 0 -- A always L2-resident) */ \
@@ -481,7 +494,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
     // K-tile 1 (K-tile 0 is on its way: issued before the loop, or under the previous tile's epilogue); nk >= 2 (the launcher's rule)
     static_for<0, 16>([&](auto ic) { W4_PIECE(STAGE_BYTES, decltype(ic)::value, 1); });
     first_tile = false;
-    wait_stage<LOADS>(1);
+    // (W4PF) the touch is always the YOUNGEST vector-memory operation behind a K-tile's pieces, so every wait for those pieces leaves exactly
+    // one operation in flight (vmcnt(1) / + 1), and a touch has two K-tiles to land before it would hold up the pieces requested behind it
+#define W4_TOUCH(kt_)                                                                                                                     \
+    if constexpr (W4PF) {                                                                                                                 \
+      const int ktp = min((int)(kt_), nk - 1);                                                                                            \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.A), 0, a_bytes, 0x00020000),    \
+                                               LDS_PTR(lds + PF_SINK + wave * 256), 4, pf_off, (uint32_t)(ktp + kt0) * ROWB, 0, 0);       \
+    }
+    W4_TOUCH(1 + TAD_W4_PREFETCH);
+    wait_stage<LOADS, W4PF ? 1 : 0>(1);
     block_barrier();
     static_for<0, 8>([&](auto gc) {
       constexpr int g = decltype(gc)::value;
@@ -508,7 +530,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
       lds_wait<0>(fb[1][0], fb[1][1], fb[1][2], fb[1][3], fb[1][4], fb[1][5], fb[1][6], fb[1][7]);
       lds_wait<0>(fa[1][0], fa[1][1], fa[1][2], fa[1][3], fa[1][4], fa[1][5], fa[1][6], fa[1][7]);
       if constexpr (NEXT) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (W4PF) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         block_barrier();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -525,6 +548,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
           fb[0][g] = lds_read_b128<op16x8, (g >> 2) * 8192>(b_ad[0][g & 3]);
           fa[0][g] = lds_read_b128<op16x8, (g >> 2) * 8192>(a_ad[0][g & 3]);
         }
+        if constexpr (NEXT2 && g == 7) { W4_TOUCH(kt + 2 + TAD_W4_PREFETCH); }
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[g][j] = TAD_MFMA_16x16x32(fb[1][j], fa[1][g], acc[g][j]);
         __builtin_amdgcn_sched_barrier(0);
@@ -546,6 +570,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_nt_kernel(const
         for (int q = 0; q < 4; ++q) { a_ad[ks][q] ^= (uint32_t)STAGE_BYTES; b_ad[ks][q] ^= (uint32_t)STAGE_BYTES; }
     }
 #undef W4_PIECE
+#undef W4_TOUCH
   } else {
     // K-tile 0 is already on its way (issued before the loop, or under the previous tile's epilogue); with the DIRECT epilogue
     // (which leaves the LDS alone) so are the other prologue stages of every tile but the first
