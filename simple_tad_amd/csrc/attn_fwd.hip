@@ -29,6 +29,9 @@ constexpr float RESCALE_THR = 8.0f;  // log2 units
 #undef TAD_FWD_PV_F16
 #define TAD_FWD_PV_F16 0
 #endif
+#ifndef TAD_FWD_STAGGER
+#define TAD_FWD_STAGGER 0  // (experiment) N: a wave sleeps (hardware wave slot & 3) x N x 256 cycles before the first tile (see the loop head)
+#endif
 #ifndef TAD_FWD_ABL
 #define TAD_FWD_ABL 0  // timing-only ablations of the forward tile body (experiments; WRONG results): bit 0 no exponentials, 1 no row
                        // maximum, 2 no P V products / V reads / row sums, 3 no K Q^T products / K reads, 4 no DMA and no barrier in
@@ -351,6 +354,14 @@ __global__ __launch_bounds__(256, TAD_FWD_ROWSUM_VALU ? 4 : 1) void attn_fwd_ker
   };
 
   DMA_TILE(0, 0);
+#if TAD_FWD_STAGGER
+  {
+    // (experiment) the workgroups that share a CU start together and run identical tile bodies: are the waves of a SIMD phase-locked (all in their
+    // MFMA block, then all in their softmax)?  Delay a wave by (its hardware wave slot & 3) quarters of a tile body before the first barrier.
+    const uint32_t slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) & 3u;  // hwreg(HW_REG_HW_ID, 0, 4): wave slot in its SIMD
+    for (uint32_t i = 0; i < slot * (uint32_t)TAD_FWD_STAGGER; ++i) __builtin_amdgcn_s_sleep(4);  // 4 x 64 cycles
+  }
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int t = 0; t < nt; t += 2) {
