@@ -124,6 +124,46 @@ def test_linear_bwd(K):
     check(dv, dy.double().sum(0)[2 * N // 3:], what="dv_bias")
 
 
+
+def test_half_twins_of_the_round5_linear_plans(K):
+    """The IEEE-half instantiations of what round 5 added to the Linear plans: the short-K plan (192 x 128 as four waves / 128 x 128 tiles,
+    tad_linear_tuning("short_k")) bit-identical to the planned 256 x 256 launches, and the pair launch of two weight gradients
+    (tad_linear_bwd_weight_pair_f16) right against f64 products of the same operands."""
+    M = 20000 + 7
+    try:
+        for N, Kd, mode in ((1536, 384, "gelu"), (384, 384, "res"), (1152, 384, "plain"), (2048, 512, "dgelu")):
+            g = torch.Generator().manual_seed(N + Kd)
+            x = torch.randn(M, Kd, generator=g).cuda().half()
+            w = (torch.randn(N, Kd, generator=g) * 0.05).cuda().half()
+            b, res = torch.randn(N, generator=g).cuda(), torch.randn(M, N, generator=g).cuda()
+            h = torch.randn(M, N, generator=g).cuda().half()
+            outs = []
+            for sk in (0, 1):
+                K.linear_tuning(**{**K.LINEAR_TUNING_DEFAULTS, "short_k": sk})
+                if mode == "gelu":
+                    o = K.linear_fwd(x, w, b, epilogue=K.EPI_BIAS_GELU, want_preact=True)
+                elif mode == "res":
+                    o = (K.linear_fwd(x, w, b, out_dtype=torch.float32, epilogue=K.EPI_BIAS_RESIDUAL, residual=res)[0],)
+                elif mode == "dgelu":
+                    o = (K.linear_bwd_input(x, w, gelu_preact=h),)
+                else:
+                    o = (K.linear_fwd(x, w, b)[0],)
+                outs.append([t.clone() for t in o])
+            assert all(torch.equal(a, c) for a, c in zip(*outs)), f"short-K plan differs ({N}, {Kd}, {mode})"
+    finally:
+        K.linear_tuning(**K.LINEAR_TUNING_DEFAULTS)
+    M, N1, N2, Kd = 25088, 2304, 768, 768
+    g = torch.Generator().manual_seed(1)
+    dy1, x1 = torch.randn(M, N1, generator=g).cuda().half(), torch.randn(M, Kd, generator=g).cuda().half()
+    dy2, x2 = torch.randn(M, N2, generator=g).cuda().half(), torch.randn(M, Kd, generator=g).cuda().half()
+    dW1, dW2 = torch.zeros(N1, Kd, device="cuda"), torch.zeros(N2, Kd, device="cuda")
+    dq, dv = torch.zeros(N1 // 3, device="cuda"), torch.zeros(N1 // 3, device="cuda")
+    K.linear_bwd_weight_pair(dy1, x1, dW1, dq, dv, dy2, x2, dW2, accumulate=False)
+    for got, ref in ((dW1[:8], dy1[:, :8].double().t() @ x1.double()), (dW2[-8:], dy2[:, -8:].double().t() @ x2.double()),
+                     (dq, dy1[:, :N1 // 3].double().sum(0)), (dv, dy1[:, 2 * (N1 // 3):].double().sum(0))):
+        assert float((got.double() - ref).abs().max() / ref.abs().max()) < 1e-5
+
+
 @pytest.mark.parametrize("rows,D", [(150, 128), (1030, 768), (9, 1280)])
 def test_layernorm(K, rows, D):
     x = R.tensor_for(f"hln.x{D}", (rows, D), scale=2.0, shift=0.5)
