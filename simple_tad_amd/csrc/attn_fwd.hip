@@ -29,6 +29,15 @@ constexpr float RESCALE_THR = 8.0f;  // log2 units
 #undef TAD_FWD_PV_F16
 #define TAD_FWD_PV_F16 0
 #endif
+#ifndef TAD_FWD_CNEG
+#define TAD_FWD_CNEG 0  // (experiment) 1 (pre-scaled q, no dropout, head_dim 64): the running row maximum is subtracted by the matrix pipe -- sixteen registers hold
+                        // -m_run and are the C operand of the first score product of every tile -- instead of one v_sub per score (32 of ~110 vector
+                        // instructions per tile); costs 16 registers
+#endif
+#ifndef TAD_FWD_PIPE
+#define TAD_FWD_PIPE 0  // (experiment) 1: the exponentials / 16-bit packing of key group g + 1 are placed between the P V matrix instructions of group g
+                        // (program order pinned by scheduling barriers), instead of all exponentials in front of all P V products
+#endif
 #ifndef TAD_FWD_STAGGER
 #define TAD_FWD_STAGGER 0  // (experiment) N: a wave sleeps (hardware wave slot & 3) x N x 256 cycles before the first tile (see the loop head)
 #endif
@@ -226,7 +235,11 @@ __global__ __launch_bounds__(256, TAD_FWD_ROWSUM_VALU ? 4 : 1) void attn_fwd_ker
   // output registers cost 24-56 VGPRs (a wave per SIMD).  One body, one v_sub per score.
   const int nt = (N + KV_TILE - 1) / KV_TILE;
   const uint32_t drop_row = (uint32_t)((b * H + head) * N + min(q0 + ql, N - 1));  // (DROP) the lane's row of the keep mask
-  float m_run = -1e30f, l_run = 0.f;  // running row maximum (units of the scores as the matrix pipe delivers them), row sum of P
+  constexpr bool CNEG = TAD_FWD_CNEG && QS && !DROP && !X && !TAD_FWD_ABL;
+  float m_run = CNEG ? 0.f : -1e30f, l_run = 0.f;  // running row maximum (units of the scores as the matrix pipe delivers them), row sum of P
+  f32x16 negm;                        // (CNEG) -m_run in all sixteen registers: the C operand of a tile's first score products
+#pragma unroll
+  for (int r = 0; r < 16; ++r) negm[r] = 0.f;
   auto fwd_tile = [&](auto BUFC, const int T) {
     constexpr int BUF = decltype(BUFC)::value;
     const int kv0 = T * KV_TILE;
@@ -239,14 +252,17 @@ __global__ __launch_bounds__(256, TAD_FWD_ROWSUM_VALU ? 4 : 1) void attn_fwd_ker
         constexpr int i_ = decltype(ic)::value, kt = i_ / NKS, ks = i_ % NKS;
         kf[kt][ks] = lds_read_b128<op16x8, BUF * BUF_BYTES + kt * 32 * (ks < 4 ? 128 : 32)>(k_rd[ks]);
       });
+      if constexpr (!CNEG) {
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+      }
       static_for<0, 2 * NKS>([&](auto ic) {
         constexpr int i_ = decltype(ic)::value, kt = i_ / NKS, ks = i_ % NKS;
         lds_wait<2 * NKS - 1 - i_>(kf[kt][ks]);
-        s[kt] = TAD_MFMA_32x32x16(kf[kt][ks], qf[ks], s[kt]);
+        if constexpr (CNEG && ks == 0) s[kt] = TAD_MFMA_32x32x16(kf[kt][ks], qf[ks], negm);  // scores - m_run
+        else s[kt] = TAD_MFMA_32x32x16(kf[kt][ks], qf[ks], s[kt]);
       });
       } else {
 #pragma unroll
@@ -279,6 +295,26 @@ __global__ __launch_bounds__(256, TAD_FWD_ROWSUM_VALU ? 4 : 1) void attn_fwd_ker
       // precedes the exponentiation of this tile (textbook order).
       const float m_tile = half_swap_max(mloc);
       const float cq = QS ? 1.f : c;  // log2 units per score unit
+      if constexpr (CNEG) {
+        // m_tile is relative to m_run here.  The first tile always moves the reference to its own maximum (m_run starts at 0, not at -inf: -inf
+        // as a C operand would swallow the scores); later tiles only when they exceed it by the threshold
+        if (T == 0 || __any(m_tile > RESCALE_THR)) {
+          const float d = T == 0 ? m_tile : fmaxf(m_tile, 0.f);  // shift of the reference
+          const float alpha = fast_exp2(-d);
+          m_run += d;
+          l_run *= alpha;
+#pragma unroll
+          for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) negm[r] = -m_run;
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kt][r] -= d;
+        }
+      } else
       if (__any((m_tile - m_run) * cq > RESCALE_THR)) {
         const float m_new = fmaxf(m_run, m_tile);
         const float alpha = fast_exp2((m_run - m_new) * cq);
@@ -292,18 +328,25 @@ __global__ __launch_bounds__(256, TAD_FWD_ROWSUM_VALU ? 4 : 1) void attn_fwd_ker
       const float mc = m_run * c;  // (plain q only)
       pv16x8 pf[2][2];
       float psum[4] = {0.f, 0.f, 0.f, 0.f};
+      constexpr bool PIPE = TAD_FWD_PIPE && !X && !DROP && !TAD_FWD_ABL;
+      // elements [j0, j1) of key group g_ = 2 kt + s2 (keys 16 g_ .. 16 g_ + 15): exponential, row-sum contribution, 16-bit P
+      auto p_part = [&](auto gc, int j0, int j1) {
+        constexpr int g_ = decltype(gc)::value, kt = g_ >> 1, s2 = g_ & 1;
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float sh = QS ? s[kt][8 * s2 + j] - m_run : fmaf(s[kt][8 * s2 + j], c, -mc);
-            const float pe = (TAD_FWD_ABL & 1) ? sh : fast_exp2(sh);
-            if (VSUM) psum[(j + 8 * s2) & 3] += pe;
-            if (DROP) pf[kt][s2][j] = (pv16_t)(drop_keep(drop, drop_row, (uint32_t)(kv0 + kt * 32 + acc_row(8 * s2 + j, h5))) ? pe * drop.inv_keep : 0.f);
-            else pf[kt][s2][j] = (pv16_t)pe;
-          }
+        for (int j = 0; j < 8; ++j) {
+          if (j < j0 || j >= j1) continue;
+          const float sh = CNEG ? s[kt][8 * s2 + j] : QS ? s[kt][8 * s2 + j] - m_run : fmaf(s[kt][8 * s2 + j], c, -mc);
+          const float pe = (TAD_FWD_ABL & 1) ? sh : fast_exp2(sh);
+          if (VSUM) psum[(j + 8 * s2) & 3] += pe;
+          if (DROP) pf[kt][s2][j] = (pv16_t)(drop_keep(drop, drop_row, (uint32_t)(kv0 + kt * 32 + acc_row(8 * s2 + j, h5))) ? pe * drop.inv_keep : 0.f);
+          else pf[kt][s2][j] = (pv16_t)pe;
+        }
+      };
+      if constexpr (PIPE) {
+        p_part(std::integral_constant<int, 0>{}, 0, 8);
+      } else {
+        static_for<0, 4>([&](auto gc) { p_part(gc, 0, 8); });
+      }
       f32x4 rs = {0.f, 0.f, 0.f, 0.f};
       if constexpr (TAD_FWD_ABL & 4) {
 #pragma unroll
@@ -337,11 +380,29 @@ __global__ __launch_bounds__(256, TAD_FWD_ROWSUM_VALU ? 4 : 1) void attn_fwd_ker
       static_for<0, 4>([&](auto gc) {
         constexpr int g_ = decltype(gc)::value, par = g_ & 1;
         if constexpr (g_ < 3) v_issue(std::integral_constant<int, g_ + 1>{}, std::integral_constant<int, par ^ 1>{});
+        if constexpr (PIPE) {
+          // group g's three matrix instructions with group g + 1's exponentials between them, in this order
+          __builtin_amdgcn_sched_barrier(0);
+          rs = PV_MFMA_16x16x32(sel, pf[g_ >> 1][g_ & 1], rs);
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (g_ < 3) p_part(std::integral_constant<int, g_ + 1>{}, 0, 2);
+          lds_wait<(g_ < 3 ? 4 : 0)>(vlo[par][0], vhi[par][0], vlo[par][1], vhi[par][1]);
+          __builtin_amdgcn_sched_barrier(0);
+          o[0] = PV_MFMA_32x32x16(v_to_pv(join_tr(vlo[par][0], vhi[par][0])), pf[g_ >> 1][g_ & 1], o[0]);
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (g_ < 3) p_part(std::integral_constant<int, g_ + 1>{}, 2, 5);
+          __builtin_amdgcn_sched_barrier(0);
+          o[1] = PV_MFMA_32x32x16(v_to_pv(join_tr(vlo[par][1], vhi[par][1])), pf[g_ >> 1][g_ & 1], o[1]);
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (g_ < 3) p_part(std::integral_constant<int, g_ + 1>{}, 5, 8);
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
         if (!VSUM) rs = PV_MFMA_16x16x32(sel, pf[g_ >> 1][g_ & 1], rs);
         if constexpr (X) lds_wait<(g_ < 3 ? 6 : 0)>(vlo[par][0], vhi[par][0], vlo[par][1], vhi[par][1], vlo[par][NDT - 1], vhi[par][NDT - 1]);
         else lds_wait<(g_ < 3 ? 4 : 0)>(vlo[par][0], vhi[par][0], vlo[par][1], vhi[par][1]);
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) o[dt] = PV_MFMA_32x32x16(v_to_pv(join_tr(vlo[par][dt], vhi[par][dt])), pf[g_ >> 1][g_ & 1], o[dt]);
+        }
       });
       }
       if (VSUM) l_run += half_swap_sum((psum[0] + psum[1]) + (psum[2] + psum[3]));
