@@ -69,6 +69,10 @@ def parse_args():
     ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the all-host-cores leg of the CPU baseline (it is bounded to ~60 s and on by default)")
     ap.add_argument("--linear-schedule", default="auto", choices=["auto", "per-tile", "persistent"], help="world > 1 only: the Linear GEMMs' grid while an "
                     "RCCL kernel may hold CUs (auto = per-tile; parallel.DataParallel)")
+    ap.add_argument("--bucket-dtype", default="f32", choices=["f32", "bf16"], help="world > 1 only: format of the gradient buckets on the wire "
+                    "(DataParallel(bucket_dtype=...): bf16 halves the bytes of the exchange; default f32)")
+    ap.add_argument("--no-rccl-info", action="store_true", help="world > 1: do not collect RCCL's own description of the communicator (NCCL_DEBUG=INFO "
+                    "INIT / GRAPH lines of rank 0 in a temporary file: version, channels, transport per peer) into the `collective` object")
     ap.add_argument("--no-live-profile", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip everything after the timed region except cpu_baseline")
     ap.add_argument("--only-extras", default="", help="comma list out of roofline_all,engine_loop,fwd_only,half,precise,mae_pretrain,torch_route,vit_small,vit_large "
@@ -95,6 +99,37 @@ def self_launch(args):
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     print(f"[bench] starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
     sys.exit(subprocess.call(cmd, env=env))
+
+
+def rccl_summary(log_path):
+    """what RCCL says about the communicator of this run: library version, channel count, and how rank 0 reaches its peers (the NCCL_DEBUG=INFO
+    lines "Channel 03/0 : 0[0] -> 1[1] via P2P/IPC" etc.: P2P = peer-to-peer over xGMI, SHM / NET = through host memory / the network)"""
+    import re
+    out = {}
+    try:
+        import torch
+        v = torch.cuda.nccl.version()
+        out["version"] = ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception as e:  # noqa: BLE001
+        out["version_error"] = repr(e)
+    if not log_path:
+        out["debug_lines"] = "not collected (--no-rccl-info, a dry run, or NCCL_DEBUG already set by the caller)"
+        return out
+    try:
+        import glob
+        txt = "".join(open(f, errors="replace").read() for f in sorted(glob.glob(log_path + "*")))
+        via = re.findall(r"Channel (\d+)/\d+ : (\d+)\[[^\]]*\] -> (\d+)\[[^\]]*\] .*?via (\S+)", txt)
+        out["channels"] = len({c for c, *_ in via}) or None
+        out["transports"] = sorted({t for *_, t in via})
+        out["peers_of_rank0"] = sorted({int(dst) for _, src, dst, _ in via if src == "0"})
+        keep = [ln.split("NCCL INFO", 1)[-1].strip() for ln in txt.splitlines()
+                if re.search(r"version|nChannels|Channel 00|Trees|Ring 00|XGMI|xGMI|PCI|threadThresholds|comm .* rank 0", ln)]
+        out["lines"] = keep[:12]
+        out["transport_of_rank0"] = ("xGMI peer-to-peer" if any(t.startswith("P2P") for t in out["transports"]) else
+                                     "host memory / network (no P2P line)" if out["transports"] else "unknown (no Channel lines in the log)")
+    except Exception as e:  # noqa: BLE001
+        out["debug_error"] = repr(e)
+    return out
 
 
 def flops_per_clip(N, D, L, n_cls=2, k_patch=1536):
@@ -131,10 +166,47 @@ def read_profiles():
     return out
 
 
+def host_cpu_share():
+    """what the process may actually use of the host: os.cpu_count() counts every core of the machine, the scheduler affinity and the
+    cgroup CPU quota say how many of them this job gets (a 1-GPU box of an 8-GPU host is given a share)"""
+    n = os.cpu_count() or 1
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except Exception:  # noqa: BLE001
+        aff = n
+    quota = None
+    for path, v2 in (("/sys/fs/cgroup/cpu.max", True), ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", False)):
+        try:
+            if v2:
+                q, per = open(path).read().split()[:2]
+                quota = None if q == "max" else float(q) / float(per)
+            else:
+                q = float(open(path).read())
+                quota = None if q <= 0 else q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except Exception:  # noqa: BLE001
+            continue
+    mem = None
+    try:
+        import psutil
+        mem = psutil.virtual_memory().available
+        for path in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+            try:
+                lim = open(path).read().strip()
+                if lim != "max":
+                    mem = min(mem, int(lim))
+                break
+            except Exception:  # noqa: BLE001
+                continue
+    except Exception:  # noqa: BLE001
+        pass
+    return {"os_cpu_count": n, "affinity": aff, "cgroup_quota_cpus": quota, "usable": int(min(aff, quota) if quota else aff), "mem_available_bytes": mem}
+
+
 def cpu_baseline(state_dict, frames, reps=3, all_cores=True):
     """Oracle (pure-torch CPU restatement of the reference path) fwd+bwd, B=2, fp32: 1 warm-up + `reps` timed passes on at most 32
-    host cores (a larger pool on this small batch oversubscribes) and the same on ALL host cores, each leg
-    bounded: a warm-up pass over 15 s is reported as it is, so the two legs together stay within about a minute."""
+    host cores (a larger pool on this small batch oversubscribes) and -- BASELINE.md section 3 -- a second leg on os.cpu_count() threads
+    at a batch that pool can use (8 clips), each leg bounded so that the two together stay within about two minutes."""
     import torch
     from oracle import vit_oracle as O
     P = {k: v.detach().float().cpu().requires_grad_() for k, v in state_dict.items()}
@@ -160,35 +232,56 @@ def cpu_baseline(state_dict, frames, reps=3, all_cores=True):
             one()
         return reps, (time.perf_counter() - t0) / reps
 
-    ncpu = os.cpu_count() or 1
+    share = host_cpu_share()
+    ncpu = share["os_cpu_count"]
     n32 = min(ncpu, 32)
     r, dt = timed(n32)
-    out = {"value": round(2 / dt, 4), "unit": "clips/sec", "cores": n32, "kind": "port", "host_cores": ncpu, "reps": r,
+    out = {"value": round(2 / dt, 4), "unit": "clips/sec", "cores": n32, "kind": "port", "host_cores": ncpu, "reps": r, "host_cpu_share": share,
            "sample": f"ViT-B/16 16x224x224 fwd+bwd (CE loss), batch 2, fp32, {r} reps after 1 warm-up, oracle/vit_oracle.py "
                      f"on {n32} of {ncpu} host cores; {dt:.2f} s per batch"}
     if ncpu > n32 and all_cores:
-        # BASELINE.md section 3 asks for os.cpu_count() threads.  On this batch of two clips a 256-thread pool oversubscribes so badly that
-        # ONE pass can take minutes (196 s measured), so the leg runs in a child process (CPU only: it never touches the GPU) that is
-        # killed after 60 s; what it managed within the limit is what the line carries.
+        # BASELINE.md section 3 asks for os.cpu_count() threads.  At batch 2 a 256-thread pool oversubscribes so badly that ONE pass takes
+        # minutes (196 s measured in round 4), so this leg runs 8 clips (4 / 2 when the host's free memory is short: ~3.6 GB per clip) in a
+        # child process (CPU only: it never touches the GPU) with a passive OpenMP wait policy (spinning workers burn the job's CPU quota),
+        # prints every pass as it finishes and is stopped after 100 s: the line carries the last pass that finished.
         import subprocess
         torch.set_num_threads(n32)
+        mem = share.get("mem_available_bytes")
+        cb = 8 if (mem is None or mem > 64e9) else 4 if mem > 36e9 else 2
+        env = {**os.environ, "HIP_VISIBLE_DEVICES": "", "TAD_CPU_CHILD": "1", "OMP_WAIT_POLICY": "PASSIVE", "GOMP_SPINCOUNT": "0", "KMP_BLOCKTIME": "0"}
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", str(ncpu), "--frames", str(frames), "--batch", str(cb)]
+        txt, timed_out = "", False
         try:
-            pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", str(ncpu), "--frames", str(frames)],
-                                capture_output=True, text=True, timeout=60, env={**os.environ, "HIP_VISIBLE_DEVICES": "", "TAD_CPU_CHILD": "1"})
-            d = json.loads(pr.stdout.strip().splitlines()[-1])
-            out["all_cores"] = {"value": round(2 / d["s_per_batch"], 4), "unit": "clips/sec", "cores": ncpu, "reps": d["reps"], "s_per_batch": round(d["s_per_batch"], 2),
-                                "note": "same sample on every host core (os.cpu_count() threads), in a child process; `value` above is the faster-per-core 32-thread pool"}
-        except subprocess.TimeoutExpired:
-            out["all_cores"] = {"value": None, "cores": ncpu, "note": f"one warm-up + one timed pass of the same sample did not finish within 60 s on a {ncpu}-thread pool "
-                                                                       "(oversubscription at batch 2; 196 s per pass measured once): `value` above is the 32-thread pool"}
+            txt = subprocess.run(cmd, capture_output=True, text=True, timeout=100, env=env).stdout
+        except subprocess.TimeoutExpired as e:
+            timed_out = True
+            txt = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
         except Exception as e:  # noqa: BLE001
             out["all_cores"] = {"value": None, "cores": ncpu, "error": repr(e)}
+        if "all_cores" not in out:
+            passes = []
+            for ln in txt.strip().splitlines():
+                try:
+                    passes.append(json.loads(ln))
+                except Exception:  # noqa: BLE001
+                    pass
+            if passes:
+                d = passes[-1]
+                out["all_cores"] = {"value": round(cb / d["s_per_batch"], 4), "unit": "clips/sec", "cores": ncpu, "batch": cb, "s_per_batch": round(d["s_per_batch"], 2),
+                                    "pass": d["pass"], "passes_finished": len(passes), "stopped_at_100s": timed_out,
+                                    "note": f"the same model, {cb} clips per pass on os.cpu_count() = {ncpu} threads (passive OpenMP waits), in a child process; "
+                                            f"`value` above is the {n32}-thread pool at batch 2.  This job's CPU share of the host: {share['usable']} "
+                                            "(host_cpu_share)"}
+            else:
+                out["all_cores"] = {"value": None, "cores": ncpu, "batch": cb, "stopped_at_100s": timed_out,
+                                    "note": f"not one pass of {cb} clips finished within 100 s on a {ncpu}-thread pool; this job's CPU share of the host is "
+                                            f"{share['usable']} cores (host_cpu_share): `value` above is the {n32}-thread pool"}
     return out
 
 
-def cpu_baseline_child(threads, frames):
-    """the all-host-cores leg of cpu_baseline, run as `python bench.py --cpu-baseline-child N` by the parent (which kills it after 60 s):
-    the same seeded ViT-B/16 (the module surface constructs on the CPU; the oracle does the arithmetic), 1 warm-up + 1 timed pass"""
+def cpu_baseline_child(threads, frames, batch=2):
+    """the all-host-cores leg of cpu_baseline, run as `python bench.py --cpu-baseline-child N --batch B` by the parent (which stops it after
+    100 s): the same seeded ViT-B/16 (the module surface constructs on the CPU; the oracle does the arithmetic); every pass prints its time"""
     import torch
     import simple_tad_amd as T
     from oracle import vit_oracle as O
@@ -197,8 +290,8 @@ def cpu_baseline_child(threads, frames):
                        drop_path_rate=0.0, init_scale=0.001, use_flash_attn=True)
     P = {k: v.detach().float().requires_grad_() for k, v in m.state_dict().items()}
     torch.manual_seed(0)
-    x = torch.randn(2, 3, frames, 224, 224)
-    y = torch.randint(0, 2, (2,))
+    x = torch.randn(batch, 3, frames, 224, 224)
+    y = torch.randint(0, 2, (batch,))
     torch.set_num_threads(threads)
 
     def one():
@@ -206,10 +299,10 @@ def cpu_baseline_child(threads, frames):
             p_.grad = None
         torch.nn.functional.cross_entropy(O.forward(x, P, depth=12, num_heads=12, tubelet=2, patch=16), y).backward()
 
-    one()
-    t0 = time.perf_counter()
-    one()
-    print(json.dumps({"s_per_batch": time.perf_counter() - t0, "reps": 1, "threads": threads}), flush=True)
+    for i in range(3):  # pass 0 is the warm-up; the parent reports the LAST pass that finished inside its limit
+        t0 = time.perf_counter()
+        one()
+        print(json.dumps({"s_per_batch": time.perf_counter() - t0, "pass": "warm-up" if i == 0 else f"timed {i}", "reps": 1, "threads": threads, "batch": batch}), flush=True)
 
 
 # --------------------------------------------------------------------------------------------------------------- parity vs golden G11
@@ -272,7 +365,7 @@ def parity_vs_golden(T, dev, modes, loss_scale=4096.0):
 def main():
     args = parse_args()
     if args.cpu_baseline_child:
-        cpu_baseline_child(args.cpu_baseline_child, args.frames)
+        cpu_baseline_child(args.cpu_baseline_child, args.frames, batch=args.batch if args.batch != 32 else 2)
         return
     self_launch(args)
 
@@ -283,6 +376,13 @@ def main():
     from simple_tad_amd import _lib
     from simple_tad_amd.parallel import DataParallel, init_distributed_mode
 
+    rccl_log = None
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not args.no_rccl_info and not args.dry_run and "NCCL_DEBUG" not in os.environ:
+        # RCCL describes the communicator it builds (version, channels, the transport to every peer: P2P over xGMI, or through host memory /
+        # PCIe) when NCCL_DEBUG=INFO is set BEFORE the process group exists: rank 0's lines go to a file that the `collective` object quotes
+        import tempfile
+        rccl_log = os.path.join(tempfile.gettempdir(), f"tad_rccl_{os.getpid()}.log")
+        os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,GRAPH,ENV", NCCL_DEBUG_FILE=rccl_log)
     distributed, rank, world, local = init_distributed_mode()
     if args.gpus != world:
         if rank == 0:
@@ -296,6 +396,9 @@ def main():
         if rank == 0:
             print(json.dumps({"dry_run": True, "n_gpus": world, "allreduce_of_ones": t.item(),
                               "backend": torch.distributed.get_backend() if distributed else None,
+                              "flags": {"linear_schedule": args.linear_schedule, "bucket_dtype": args.bucket_dtype, "global_batch": args.global_batch,
+                                        "per_gpu_batch": (args.global_batch // world) if args.global_batch else args.batch,
+                                        "scaling": "strong" if args.global_batch else "weak"},
                               "launched_by": "self" if os.environ.get("TORCHELASTIC_RUN_ID") else "direct"}), flush=True)
         if distributed:
             torch.distributed.barrier()
@@ -333,7 +436,8 @@ def main():
     dp = opt = scaler = None
     if args.mode == "train":
         model.train()
-        dp = DataParallel(model, bucket_mb=64.0, linear_schedule=None if args.linear_schedule == "auto" else args.linear_schedule)
+        dp = DataParallel(model, bucket_mb=64.0, linear_schedule=None if args.linear_schedule == "auto" else args.linear_schedule,
+                          bucket_dtype=args.bucket_dtype)
         if distributed:
             dp.enable_timing()
         opt = E.create_optimizer(dp, lr=1e-3, weight_decay=0.05, layer_decay=0.75)
@@ -427,7 +531,8 @@ def main():
         torch.distributed.all_gather(own, torch.tensor([dt_own], dtype=torch.float64, device=dev))
         per_rank = [1e3 * float(o.item()) / args.steps for o in own]
         collective = {"backend": torch.distributed.get_backend(), "world_size": torch.distributed.get_world_size(),
-                      "allreduce_bytes_per_step": 4 * int(dp.flat_grad.numel()) if dp is not None else 0,
+                      "allreduce_bytes_per_step": dp.exchange_bytes_per_step() if dp is not None else 0,
+                      "bucket_dtype": dp.bucket_dtype if dp is not None else None,
                       "buckets": len(dp.buckets) if dp is not None else 0,
                       "rank_ms_per_step": {"min": round(min(per_rank), 3), "max": round(max(per_rank), 3), "all": [round(v, 3) for v in per_rank]},
                       "linear_schedule": (dp.linear_schedule if dp is not None else None),
@@ -436,6 +541,7 @@ def main():
         ts = dp.timing_summary() if dp is not None else None
         if ts is not None:
             collective.update(ts)
+        collective["rccl"] = rccl_summary(rccl_log)
     loss_val = float(last.float().mean().item()) if args.mode == "train" else float("nan")
 
     if rank != 0:
@@ -487,7 +593,12 @@ def main():
                                "calls": prof.seen.get("gemm_nt", g["calls"]), "sampled_calls": g["calls"], "sampled_launches": g["launches"],
                                "launches": round(prof.seen.get("gemm_nt", g["calls"]) * g["launches"] / max(g["calls"], 1)),
                                "avg_launch_us": round(1e3 * g["ms"] / g["launches"], 2),
-                               "gflop_per_launch": round(g["flops"] / g["launches"] / 1e9, 2)}
+                               "gflop_per_launch": round(g["flops"] / g["launches"] / 1e9, 2),
+                               # both operands + the output once, + the f32 residual / 16-bit pre-activation the epilogue reads or writes
+                               # (kernels.linear_fwd / linear_bwd_input), averaged over the sampled launches like `achieved`
+                               "algorithmic_bytes": round(g["bytes"] / g["launches"])}
+            if out["roofline"]["traffic"]:
+                out["roofline"]["traffic_over_algorithmic"] = round(out["roofline"]["traffic"] / max(out["roofline"]["algorithmic_bytes"], 1), 3)
 
     want = set(filter(None, args.only_extras.split(","))) or {"roofline_all", "engine_loop", "fwd_only", "half", "precise", "mae_pretrain", "torch_route",
                                                                 "vit_small", "vit_large", "inference_b1"}
@@ -677,6 +788,22 @@ def main():
                                                                          "source": "BASELINE.md section 4"}})
     if isinstance(par, dict) and "error" in par:
         out["parity_error"] = par["error"]
+    # ---- north_star's bar (1) is "within 1e-3 of the reference": `value` is the bf16 mode north_star names for the MFMA tiles, and its
+    # measured deviation is stated in `config`; the mode that IS inside 1e-3 (IEEE-half operands + loss scaling, the reference's own
+    # autocast + GradScaler recipe) carries its throughput here, at the top level of the line
+    if isinstance(par, dict) and isinstance(par.get("fast"), dict):
+        pf = par["fast"]
+        out["config"]["headline_mode_deviation"] = {"mode": "fast (bf16 operands)", "logits_rel_l2": pf["logits_rel_l2"], "features_rel_l2": pf["features_rel_l2"],
+                                                    "grad_rms_worst": pf["grad_rms"]["worst"], "tolerance": 1e-3, "within_tolerance": False,
+                                                    "see": "value_within_tolerance"}
+    hv = out.get("half")
+    if isinstance(hv, dict) and "value" in hv and isinstance(hv.get("deviation"), dict):
+        dv = hv["deviation"]
+        out["value_within_tolerance"] = {"mode": "half", "value": hv["value"], "unit": "clips/sec", "ms_per_step": hv["ms_per_step"], "vs_value": hv["vs_value"],
+                                         "logits_rel_l2": dv["logits_rel_l2"], "features_rel_l2": dv["features_rel_l2"],
+                                         "grad_rms_worst": dv["grad_rms"]["worst"], "tolerance": 1e-3,
+                                         "within_tolerance": bool(dv["logits_rel_l2"] <= 1e-3 and dv["features_rel_l2"] <= 1e-3 and dv["grad_rms"]["worst"] <= 1e-3),
+                                         "frac_of_bf16_mfma_roofline": hv["frac_of_f16_mfma_roofline"], "against": against}
 
     if extras and "mae_pretrain" in want:
         # ---- BASELINE configs[4] on one GPU: pretrain_videomae_large_patch16_224 (ViT-L/16 encoder on the 392 visible tokens, 12-block

@@ -190,6 +190,8 @@ int tad_linear_bwd_weight_pair(const uint16_t* dy1, const uint16_t* x1, float* d
  *   "tn_pdeep"        1 = the weight-gradient GEMM requests its dy operand two reduction tiles ahead (three-slot ring, the whole
  *                     160 KiB of LDS); 0 = two-stage ring (default: measured equal) */
 int tad_linear_tuning(const char* key, int value);
+/* Current value of a tad_linear_tuning knob (what a scoped change has to put back: simple_tad_amd.kernels.TuningScope). */
+int tad_linear_tuning_get(const char* key, int* value);
 /* Number of gemm_nt kernel launches issued so far by tad_linear_fwd* / tad_linear_bwd_input / tad_patch_embed_* (a call is one
  * launch, or two when the split-tail plan is taken): lets a profiler attribute event time to kernel launches. */
 long long tad_linear_kernel_launches(void);

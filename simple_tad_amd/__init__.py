@@ -5,8 +5,9 @@ from . import registry
 from .registry import create_model, register_model, list_models
 from . import modeling_finetune
 from .ops import set_precision, get_precision
+from .tuning import TuningScope
 from .modeling_finetune import (VisionTransformer, PatchEmbed, Block, Attention, Mlp, DropPath,
                                 get_sinusoid_encoding_table)
 
-__all__ = ["set_precision", "get_precision", "create_model", "register_model", "list_models", "modeling_finetune", "VisionTransformer", "PatchEmbed", "Block",
+__all__ = ["set_precision", "get_precision", "TuningScope", "create_model", "register_model", "list_models", "modeling_finetune", "VisionTransformer", "PatchEmbed", "Block",
            "Attention", "Mlp", "DropPath", "get_sinusoid_encoding_table"]

@@ -32,6 +32,7 @@ SIGNATURES = {
     "tad_linear_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _sz, _i64, _i, _i, _vp]),
     "tad_linear_workspace_bytes": (_sz, [_i64, _i, _i]),
     "tad_linear_tuning": (_i, [C.c_char_p, _i]),
+    "tad_linear_tuning_get": (_i, [C.c_char_p, C.POINTER(_i)]),
     "tad_linear_fwd_qkv": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _i64, _i, _i, _vp]),
     "tad_linear_bwd_weight_qkv": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _i64, _i, _i, _vp]),
     "tad_linear_bwd_weight_pair": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _sz, _i64, _i, _vp]),

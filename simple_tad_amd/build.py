@@ -7,13 +7,17 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 # TAD_BUILD_LIB / TAD_BUILD_DEFINES: experiment builds next to the production library (own object directory), e.g.
-#   TAD_BUILD_LIB=libtad_spread.so TAD_BUILD_DEFINES="-DTAD_DMA_SPREAD=1" python -m simple_tad_amd.build --force
+#   TAD_BUILD_LIB=libtad_spread.so TAD_BUILD_DEFINES="-DTAD_DMA_SPREAD=1" python -m simple_tad_amd.build --force   -> build_exp/libtad_spread.so
 # and TAD_LIB=<path> selects the library a process loads (_lib.py).
 # TAD_BUILD_ABLATION=1 (the diagnostic build: -DTAD_GEMM_ABLATION, in-kernel stamps / clock readings / debug knobs) never writes the production
-# library: without TAD_BUILD_LIB it builds libtad_ablation.so in its own object directory.
+# library: without TAD_BUILD_LIB it builds build_exp/libtad_ablation.so in its own object directory.
 _ABLATION = os.environ.get("TAD_BUILD_ABLATION") == "1"
 _LIB_NAME = os.environ.get("TAD_BUILD_LIB", "libtad_ablation.so" if _ABLATION else "libtad_mi355x.so")
-LIB = os.path.join(HERE, _LIB_NAME)
+# The production library is the ONLY built file in the package directory; every experiment / ablation build (and its objects) goes to
+# <repo>/build_exp/ -- git-ignored like every built artefact, but not gpurun-ignored, so it travels to the GPU box with the snapshot.
+EXP_DIR = os.path.join(os.path.dirname(HERE), "build_exp")
+_PRODUCTION = _LIB_NAME == "libtad_mi355x.so"
+LIB = os.path.join(HERE if _PRODUCTION else EXP_DIR, os.path.basename(_LIB_NAME))
 SOURCES = ["capi.hip", "elementwise.hip", "layernorm.hip", "gemm.hip", "gemm_w4.hip", "attn_fwd.hip", "attn_bwd.hip", "attn_f32.hip", "precise.hip", "optim.hip", "mae.hip", "metrics.hip", "collective.hip"]
 # Sources that touch 16-bit GEMM / attention operands are compiled a second time with -DTAD_OPND_F16: the same kernels for IEEE half
 # operands, exported as tad_*_f16 (csrc/common.h, csrc/opnd_f16_names.h; include/tad_mi355x.h "IEEE half operand twins").
@@ -46,7 +50,7 @@ def _deps_mtime():
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _deps_mtime():
         return LIB
-    objdir = os.path.join(HERE, "build" if _LIB_NAME == "libtad_mi355x.so" else "build_" + os.path.splitext(os.path.basename(LIB))[0])
+    objdir = os.path.join(HERE, "build") if _PRODUCTION else os.path.join(EXP_DIR, "obj_" + os.path.splitext(os.path.basename(LIB))[0])
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
 

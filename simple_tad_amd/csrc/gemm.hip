@@ -1460,28 +1460,63 @@ static int launch_gemm_nt_splitk(GemmNT p, int splits, void* ws, hipStream_t st,
   else { set_error("gemm_nt: no split-K kernel for epilogue %d", p.epi); return TAD_EINVAL; }
   return check_launch("gemm_nt_splitk");
 }
-// splits for a tail of `tiles` 256 x 256 tiles with nk K-tiles each, or 0: every share needs at least two K-tiles, all shares must be
-// resident at once, and the combine pass costs ~14 us (partial tiles written and read back, arrival wait), so short reductions gain nothing
-static int nt_splitk_plan(const GemmNT& t, size_t ws_bytes, double* cost_us) {
-  const int tiles = ((t.M + 255) / 256) * ((t.N + 255) / 256), nk = t.K / BK, cus = cu_count();
+// ---- geometry of the split plan, ONE copy for launch_gemm_nt, nt_splitk_plan and tad_linear_workspace_bytes (the workspace query
+// used to restate it, and any drift made the split-K tail drop out without a diagnostic)
+// Largest row count one launch may cover (32-bit operand offsets, see launch_gemm_nt); esz = bytes of the widest element the epilogue touches
+static int64_t nt_max_rows(int N, int K, int64_t esz) {
+  int64_t max_rows = ((1ll << 31) - 1) / ((int64_t)N * esz) - 256;
+  const int64_t a_rows = ((1ll << 32) - 1) / ((int64_t)K * 2);
+  if (a_rows < max_rows) max_rows = a_rows;
+  return max_rows / 256 * 256;
+}
+// Rows that fill whole rounds of one 256 x 256 tile per CU (0: the split plan does not apply); *tail_tiles = the 256 x 256 tiles left behind them
+static int nt_main_rows(int64_t M, int N, int64_t* tail_tiles) {
+  const int grid = cu_count() & ~7;
+  const int64_t tiles_n = (N + 255) / 256, tiles_m = (M + 255) / 256;
+  const int64_t rounds = grid > 0 ? tiles_m * tiles_n / grid : 0;
+  const int64_t panels = rounds > 0 ? rounds * grid / tiles_n : 0;
+  if (!(panels > 0 && panels < tiles_m)) return 0;
+  if (tail_tiles) *tail_tiles = (tiles_m - panels) * tiles_n;
+  return (int)(panels * 256);
+}
+// Shares per tile of a split-K tail of `tiles` tiles with nk K-tiles each (0: it does not split): every share needs at least two K-tiles and all
+// shares must be resident at once
+static int nt_splitk_shares(int64_t tiles, int nk) {
+  const int cus = cu_count();
   if (!nt_splitk || tiles <= 0 || tiles > cus / 2 || tiles > 1008) return 0;
   // measured (tools/exp_splitk.py, round 4): the 78-tile tails of ViT-B's N = 768 Linears (30 % of the CUs busy for one K loop) do NOT
   // gain -- three shares of 16 K-tiles + the combine take as long as one 256 x 128 K loop of 48 -- while the 16-tile tails of ViT-L's
   // N = 1024 Linears (6 % of the CUs) do: auto mode takes tails of at most a quarter of the CUs whose K loop is long enough
+  if (nt_splitk == 1 && (tiles > cus / 4 || nk < 64)) return 0;  // (K = 3072 at 16 tiles: 289 -> 297 us; K = 4096: 424 -> 392, 387 -> 376)
+  int64_t s = cus / tiles;
+  if (s > nk / 2) s = nk / 2;
+  if (s > 8) s = 8;
+  return s < 2 ? 0 : (int)s;
+}
+static size_t nt_splitk_ws_bytes(int64_t tiles, int shares) { return SK_HEADER_BYTES + (size_t)(tiles * shares) * SK_TILE_BYTES; }
+
+// splits for a tail of `tiles` 256 x 256 tiles with nk K-tiles each, or 0: the combine pass costs ~14 us (partial tiles written and read back,
+// arrival wait), so short reductions gain nothing
+static int nt_splitk_plan(const GemmNT& t, size_t ws_bytes, double* cost_us) {
+  const int tiles = ((t.M + 255) / 256) * ((t.N + 255) / 256), nk = t.K / BK;
   // Deferred plan (nt_sk_defer, launch_gemm_nt): the partial tiles are left by a launch IN FRONT of the whole-round launch and combined by a
   // launch BEHIND it, so their way through memory (58 MB each way for 76 tiles x 3 shares) runs beside two rounds of matrix work instead of
   // at the end of a 26 us kernel.  Measured (kernel trace, ViT-B dX(fc1), 76 tiles x 3 shares): partial-tile launch 54 us with write-through
   // stores, whole rounds 190, combine 15 -- against 190 + 47 for the 256 x 128 tail: the 58 MB of partial tiles cost what the balanced
   // K loop saves, so the rule for WHICH tails split stays what it was; the deferred form is the better way to run those that do
   // (ViT-L fc2 421 -> 388 us against 392 combined in the launch, dX(fc1) 387 -> 364 against 376).
-  if (nt_splitk == 1 && (tiles > cus / 4 || nk < 64)) return 0;  // (K = 3072 at 16 tiles: 289 -> 297 us; K = 4096: 424 -> 392, 387 -> 376)
   if (!((t.epi == EPI_PLAIN) || (t.epi == EPI_RESIDUAL && !t.c_bf16 && t.res_mod <= 0))) return 0;
   if (t.rowscale && t.rows_per_scale < 256) return 0;
   if (t.colscale_cols > 0) return 0;
-  int s = cus / tiles;
-  if (s > nk / 2) s = nk / 2;
-  if (s > 8) s = 8;
-  if (s < 2 || ws_bytes < SK_HEADER_BYTES + (size_t)tiles * s * SK_TILE_BYTES) return 0;
+  const int s = nt_splitk_shares(tiles, nk);
+  if (!s) return 0;
+  if (ws_bytes < nt_splitk_ws_bytes(tiles, s)) {
+    // (a workspace was handed in but is smaller than tad_linear_workspace_bytes says for this shape under the current knobs: say so once instead
+    //  of silently running the unsplit tail)
+    static bool warned = false;
+    if (!warned) { warned = true; fprintf(stderr, "[tad] gemm_nt: split-K workspace of %zu bytes < the %zu the tail of M=%d N=%d K=%d needs; running it unsplit\n", ws_bytes, nt_splitk_ws_bytes(tiles, s), t.M, t.N, t.K); }
+    return 0;
+  }
   *cost_us = nt_sk_defer ? (double)((nk + s - 1) / s) * 1.45 + 10.0 + 16.0 : (double)((nk + s - 1) / s) * 1.65 + 14.0 + 3.0;
   return s;
 }
@@ -1579,11 +1614,7 @@ int launch_gemm_nt(const GemmNT& p_in, hipStream_t st, void* ws = nullptr, size_
   // taller problem runs as row ranges that fit (ViT-B fc1, N = 3072 bf16: 222 clips of 1568 tokens per range; the f32 cap used to
   // apply to bf16 outputs too and refused B > 111).
   {
-    const int64_t esz = (p.c_bf16 && !p.residual) ? 2 : 4;
-    int64_t max_rows = ((1ll << 31) - 1) / ((int64_t)p.N * esz) - 256;
-    const int64_t a_rows = ((1ll << 32) - 1) / ((int64_t)p.K * 2);
-    if (a_rows < max_rows) max_rows = a_rows;
-    max_rows = max_rows / 256 * 256;
+    const int64_t max_rows = nt_max_rows(p.N, p.K, (p.c_bf16 && !p.residual) ? 2 : 4);
     if (max_rows <= 0) { set_error("gemm_nt: N=%d / K=%d too wide for the 32-bit operand offsets", p.N, p.K); return TAD_EINVAL; }
     if (p.M > max_rows) {
       for (int64_t r0 = 0; r0 < p.M; r0 += max_rows) {
@@ -1626,12 +1657,8 @@ int launch_gemm_nt(const GemmNT& p_in, hipStream_t st, void* ws = nullptr, size_
   double cost_c = 1e300;
   int main_rows = 0, tail_splits = 0;
   if (v1_ok && nt_split) {
-    const int tiles_n = (p.N + 255) / 256, tiles_m = (p.M + 255) / 256;
-    const int grid = cu_count() & ~7;
-    const int rounds = (int)((int64_t)tiles_m * tiles_n / grid);
-    const int panels = rounds > 0 ? (int)((int64_t)rounds * grid / tiles_n) : 0;
-    if (panels > 0 && panels < tiles_m) {
-      main_rows = panels * 256;
+    main_rows = nt_main_rows(p.M, p.N, nullptr);
+    if (main_rows > 0) {
       const int tail = p.M - main_rows;
       double tail_cost = tail < 2048 ? nt_cost(2, p.epi, p.c_bf16, tail, p.N, p.K)
                                      : nt_cost(nt_tail_variant(row_range(p, main_rows, tail)), p.epi, p.c_bf16, tail, p.N, p.K);
@@ -1717,6 +1744,7 @@ size_t gemm_tn_workspace_bytes(int64_t Mr, int N, int K) {
 // middle third is dropped (the qkv Linear: q_bias / no k bias / v_bias, modeling_finetune.py:69-76, 89-92)
 int launch_gemm_tn(const uint16_t* P, const uint16_t* Q, float* out, float* bias_out, float* bias_out2, int accumulate, void* ws,
                    size_t ws_bytes, int64_t Mr, int N, int K, hipStream_t st) {
+  if (const int rc = sk_check_pending_error()) return rc;  // (a failed in-launch split-K combine is reported by the NEXT tad_linear_* call, whichever it is)
   if (!(Mr > 0 && N > 0 && K > 0)) { set_error("gemm_tn: empty problem"); return TAD_EINVAL; }
   if (N % 8 || K % 8) { set_error("gemm_tn: N=%d and K=%d must be multiples of 8", N, K); return TAD_EINVAL; }
   if (Mr * (int64_t)N * 2 >= (1ll << 32) || Mr * (int64_t)K * 2 >= (1ll << 32)) { set_error("gemm_tn: operand exceeds 4 GiB"); return TAD_EINVAL; }
@@ -1755,6 +1783,7 @@ int launch_gemm_tn(const uint16_t* P, const uint16_t* Q, float* out, float* bias
 // The summation order over the rows differs from the single launches' (another split count), as between any two batch sizes.
 int launch_gemm_tn_pair(const uint16_t* P1, const uint16_t* Q1, float* out1, float* bias_out1, float* bias_out1b, int N1, const uint16_t* P2,
                         const uint16_t* Q2, float* out2, int N2, int accumulate, void* ws, size_t ws_bytes, int64_t Mr, int K, hipStream_t st) {
+  if (const int rc = sk_check_pending_error()) return rc;
   if (!(Mr > 0 && N1 > 0 && N2 > 0 && K > 0)) { set_error("gemm_tn_pair: empty problem"); return TAD_EINVAL; }
   if (N1 % 8 || N2 % 8 || K % 8) { set_error("gemm_tn_pair: N1=%d, N2=%d and K=%d must be multiples of 8", N1, N2, K); return TAD_EINVAL; }
   const int N = N1 + N2;
@@ -1808,24 +1837,24 @@ int tad_linear_fwd(const uint16_t* x, const uint16_t* w, const float* bias, void
 
 #ifndef TAD_OPND_F16
 size_t tad_linear_workspace_bytes(int64_t M, int N, int K) {
-  // What launch_gemm_nt's split plan would hand to nt_splitk_plan for this shape (the epilogue kind is not known here: assumed eligible),
-  // or 0 when the tail of this shape never splits along K -- every Linear of ViT-B under the default knobs (64 MB used to stay
-  // resident per stream for nothing, and every Linear call paid for the lookup of a buffer)
+  // What launch_gemm_nt's split plan hands to nt_splitk_plan for this shape (same helpers: nt_max_rows, nt_main_rows, nt_splitk_shares; the
+  // epilogue kind is not known here: assumed eligible, and both element sizes of the row-range rule are covered), or 0 when no tail of this
+  // shape splits along K -- every Linear of ViT-B under the default knobs (64 MB used to stay resident per stream for nothing)
   if (M < 4096 || N < 128 || K <= 0 || K % BK || !nt_split || !nt_splitk) return 0;
-  const int cus = cu_count(), grid = cus & ~7;
-  const int64_t tiles_n = (N + 255) / 256, tiles_m = (M + 255) / 256;
-  const int64_t rounds = grid > 0 ? tiles_m * tiles_n / grid : 0;
-  const int64_t panels = rounds > 0 ? rounds * grid / tiles_n : 0;
-  if (!(panels > 0 && panels < tiles_m)) return 0;
-  const int64_t tiles = (tiles_m - panels) * tiles_n;  // (tail rows = M - 256 panels)
-  const int nk = K / BK;
-  if (tiles <= 0 || tiles > cus / 2 || tiles > 1008) return 0;
-  if (nt_splitk == 1 && (tiles > cus / 4 || nk < 64)) return 0;
-  int64_t s = cus / tiles;
-  if (s > nk / 2) s = nk / 2;
-  if (s > 8) s = 8;
-  if (s < 2) return 0;
-  return SK_HEADER_BYTES + (size_t)(tiles * s) * SK_TILE_BYTES;
+  size_t need = 0;
+  for (int64_t esz = 2; esz <= 4; esz += 2) {
+    const int64_t max_rows = nt_max_rows(N, K, esz);
+    if (max_rows <= 0) continue;
+    for (int64_t r0 = 0; r0 < M; r0 += max_rows) {  // the row ranges launch_gemm_nt cuts a taller problem into (two distinct sizes at most)
+      const int64_t rows = (M - r0) < max_rows ? (M - r0) : max_rows;
+      if (r0 > 0 && rows == max_rows) continue;
+      int64_t tiles = 0;
+      if (rows < 2048 || !nt_main_rows(rows, N, &tiles)) continue;
+      const int s = nt_splitk_shares(tiles, K / BK);
+      if (s && nt_splitk_ws_bytes(tiles, s) > need) need = nt_splitk_ws_bytes(tiles, s);
+    }
+  }
+  return need;
 }
 #endif
 
@@ -1860,6 +1889,8 @@ int tad_linear_bwd_weight_pair(const uint16_t* dy1, const uint16_t* x1, float* d
   TAD_REQUIRE(dy1 && x1 && dW1 && dy2 && x2 && dW2 && ws, "linear_bwd_weight_pair: null pointer");
   TAD_REQUIRE(!db1b || db1, "linear_bwd_weight_pair: db1b (the v_bias third) comes with db1 (the q_bias third)");
   TAD_REQUIRE(!db1b || (N1 > 0 && N1 % 12 == 0), "linear_bwd_weight_pair: N1=%d must be 3 x a multiple of 4 for the split bias sums", N1);
+  // the slab reduction reads and writes float4s through every output (dW2 is usually a view into the flat gradient buffer)
+  TAD_REQUIRE(((uintptr_t)dW1 | (uintptr_t)dW2 | (uintptr_t)db1 | (uintptr_t)db1b) % 16 == 0, "linear_bwd_weight_pair: dW1, dW2, db1 and db1b must be 16-byte aligned");
   return launch_gemm_tn_pair(dy1, x1, dW1, db1, db1b, N1, dy2, x2, dW2, N2, accumulate, ws, ws_bytes, M, K, (hipStream_t)stream);
 }
 
@@ -1884,6 +1915,19 @@ int tad_linear_tuning(const char* key, int value) {
   else if (k == "split_tail") { TAD_REQUIRE(value >= 0 && value <= 2, "linear_tuning: split_tail=%d not in 0..2", value); nt_split = value; }
   else { set_error("linear_tuning: unknown key '%s'", key); return TAD_EINVAL; }
   return TAD_OK;
+}
+
+int tad_linear_tuning_get(const char* key, int* value) {
+  TAD_REQUIRE(key && value, "linear_tuning_get: null pointer");
+  const std::string k(key);
+  const struct { const char* name; const int* v; } table[] = {
+      {"splitk_tail", &nt_splitk}, {"persistent", &nt_persist}, {"direct_epilogue", &nt_direct}, {"debug", &gemm_debug}, {"group_m", &nt_group_m_knob},
+      {"variant", &nt_variant}, {"splitk_defer", &nt_sk_defer}, {"tn_pair", &tn_pair}, {"short_k", &nt_short_k}, {"tail_192", &nt_tail_192},
+      {"w4_epilogues", &nt_w4_epilogues}, {"w4_plain", &nt_w4_plain}, {"tn_w4", &tn_w4}, {"tn_pdeep", &tn_pdeep}, {"split_tail", &nt_split}};
+  for (const auto& e : table)
+    if (k == e.name) { *value = *e.v; return TAD_OK; }
+  set_error("linear_tuning_get: unknown key '%s'", key);
+  return TAD_EINVAL;
 }
 
 long long tad_linear_kernel_launches(void) { return nt_launches; }

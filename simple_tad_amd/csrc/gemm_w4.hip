@@ -215,6 +215,11 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(const GemmTN p) {
 #undef TNW4_PIECE
 #undef TNW4_READ
 
+  // Hazard fence for the asm bias MFMAs: the compiler does not know that bacc is written by a matrix instruction, so nothing
+  // orders the vector reads of bacc below behind the last of them but the code in between.  A 16 x 16 x 32 MFMA needs 8 passes (32 cycles) before
+  // its result may be read by a VALU / store instruction; the trailing s_nop 3 of the statement covers 4.  Budget assumed: 16 + 16 wait states
+  // here >= the remaining 28, whatever the compiler schedules between the loop and the stores.
+  asm volatile("s_nop 15\n\ts_nop 15" : "+v"(bacc[0]), "+v"(bacc[1]), "+v"(bacc[2]), "+v"(bacc[3])::"memory");
   if (bias_on && li == 0) {
     float* bo = p.bias_slab + ((int64_t)split * tiles_k + tk_) * p.N;
 #pragma unroll

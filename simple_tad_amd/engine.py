@@ -159,12 +159,15 @@ class NativeScalerWithGradNormCount:
         profiles/r05_kernel_stats_half.txt.)"""
         if self._pending is None:
             return
-        flag, event, optimizer = self._pending
+        flag, event, optimizer, scaled = self._pending
         self._pending = None
         if event is not None:
             event.synchronize()
         found_inf = bool(flag[0].item() != 0)  # (pinned host memory behind its event, or a CPU tensor: no device round trip)
-        self._update_scale(found_inf)
+        if scaled:
+            self._update_scale(found_inf)
+        elif found_inf:
+            self.skipped_steps += 1  # (clipping without loss scaling: the step was skipped on the device, the scale is not in play)
         if found_inf:
             optimizer.rollback_step()
 
@@ -202,15 +205,20 @@ class NativeScalerWithGradNormCount:
             if clip or scaling:
                 # ONE pass over the flat gradients + a one-thread finish: norm, coefficient (0 = overflow: the kernel skips the step)
                 # and the found-inf flag, all on the device (tad_grad_norm_coef)
+                # A NON-FINITE norm makes the coefficient 0 in EVERY mode (tad_grad_norm_coef), i.e. the update is skipped on the device.
+                # Under loss scaling that is GradScaler's rule.  Under clipping WITHOUT scaling (bf16 / precise) it is a deliberate
+                # difference from the reference, whose clip_grad_norm_ would multiply the gradients by NaN and write NaN into every weight
+                # (utils.py:401-404): here the weights survive, and the skip is accounted for like a scaled one -- counted in
+                # `skipped_steps`, the optimizer's step counts rolled back -- when the flag is read at the next call.
                 nc = K.grad_norm_coef(optimizer.flat_grad, inv, clip_grad if clip else 0.0)
                 norm = nc[0]
-                if scaling:  # the flag is read at the next call, from pinned host memory behind an event (see _settle)
-                    if self._flag_host is None:
-                        self._flag_host = torch.zeros(1, dtype=torch.float32).pin_memory()
-                    self._flag_host.copy_(nc[2:3], non_blocking=True)
-                    ev = torch.cuda.Event()
-                    ev.record()
-                    self._pending = (self._flag_host, ev, optimizer)
+                # the flag is read at the next call, from pinned host memory behind an event (see _settle)
+                if self._flag_host is None:
+                    self._flag_host = torch.zeros(1, dtype=torch.float32).pin_memory()
+                self._flag_host.copy_(nc[2:3], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                self._pending = (self._flag_host, ev, optimizer, scaling)
                 optimizer.step(grad_scale=nc[1:2])
             else:
                 norm = optimizer.step(want_sumsq=True).sqrt()

@@ -5,6 +5,7 @@ Every function requires CUDA(=HIP) tensors and raises otherwise -- there is no C
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import Optional
 
 import torch
@@ -420,15 +421,18 @@ def linear_fwd(x, w, bias=None, out_dtype=None, epilogue=EPI_BIAS, want_preact=F
     y = torch.empty((M, N), dtype=out_dtype, device=x.device)
     pre = torch.empty((M, N), dtype=op, device=x.device) if want_preact else None
     ws, wsb = _linear_ws(M, N, K, x.device)
-    with _timed("gemm_nt", 2.0 * M * N * K, 2.0 * (M * K + N * K) + y.element_size() * M * N):
+    # algorithmic bytes of the launch: both operands once, the output once, plus what the epilogue reads (f32 residual) / writes (16-bit pre-activation)
+    with _timed("gemm_nt", 2.0 * M * N * K, 2.0 * (M * K + N * K) + y.element_size() * M * N + (4.0 * M * N if residual is not None else 0.0)
+                + (2.0 * M * N if want_preact else 0.0)):
         check(_fn("tad_linear_fwd", op)(x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), _dt(y), epilogue, _p(pre), _p(residual),
                                          _p(gamma), _p(rowscale), int(rows_per_scale), ws, wsb, M, N, K, _stream()), "tad_linear_fwd")
     return y, pre
 
 
 # Split-K tails of the Linear GEMMs (include/tad_mi355x.h: tad_linear_fwd's `ws`): a per-(device, stream) scratch buffer is handed to the
-# Linear calls unless switched off -- parallel.DataParallel does that for world sizes > 1, where an overlapped RCCL kernel may hold CUs
-# and the split-K launch (all workgroups resident at once) must not be used.
+# Linear calls unless switched off here (experiments).  parallel.DataParallel leaves it ON at world sizes > 1: it pins the deferred
+# three-launch form (tad_linear_tuning("splitk_defer", 1)), which is ordered by kernel boundaries and needs no co-residency beside an
+# overlapped RCCL kernel; only the in-launch combine ("splitk_defer", 0) does.
 _linear_splitk = True
 
 
@@ -483,6 +487,13 @@ def linear_tuning(**knobs):
         check(_lib.load().tad_linear_tuning(k.encode(), int(v)), f"tad_linear_tuning({k}={v})")
 
 
+def linear_tuning_get(key: str) -> int:
+    """current value of a tad_linear_tuning knob"""
+    v = C.c_int(0)
+    check(_lib.load().tad_linear_tuning_get(key.encode(), C.byref(v)), f"tad_linear_tuning_get({key})")
+    return int(v.value)
+
+
 def linear_bwd_input(dy, wT, out_dtype=None, gelu_preact=None):
     """dy [M,N], wT [K,N] (both bf16 or both f16) -> dx [M,K]"""
     op = _req16(dy, "linear_bwd_input.dy")
@@ -498,7 +509,7 @@ def linear_bwd_input(dy, wT, out_dtype=None, gelu_preact=None):
         assert tuple(gelu_preact.shape) == (M, K)
     dx = torch.empty((M, K), dtype=out_dtype, device=dy.device)
     ws, wsb = _linear_ws(M, K, N, dy.device)
-    with _timed("gemm_nt", 2.0 * M * N * K, 2.0 * (M * N + N * K) + dx.element_size() * M * K):
+    with _timed("gemm_nt", 2.0 * M * N * K, 2.0 * (M * N + N * K) + dx.element_size() * M * K + (2.0 * M * K if gelu_preact is not None else 0.0)):
         check(_fn("tad_linear_bwd_input", op)(dy.data_ptr(), wT.data_ptr(), dx.data_ptr(), _dt(dx), _p(gelu_preact), ws, wsb, M, N, K,
                                                _stream()), "tad_linear_bwd_input")
     return dx

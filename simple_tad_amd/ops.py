@@ -390,6 +390,10 @@ def set_attn_q_prescale(on: bool):
     _attn_q_prescale = bool(on)
 
 
+def get_attn_q_prescale() -> bool:
+    return _attn_q_prescale
+
+
 def set_attn_exact_delta(on: bool):
     global _attn_exact_delta
     _attn_exact_delta = bool(on)

@@ -104,15 +104,25 @@ class DataParallel(nn.Module):
     """Replicated-model data parallelism with bucketed, overlapped gradient all-reduce."""
 
     def __init__(self, module: nn.Module, bucket_mb: float = 64.0, process_group=None, broadcast: bool = True, overlap: bool = True,
-                 reduce_avg: Optional[bool] = None, tail_mb: Optional[float] = 16.0, linear_schedule: Optional[str] = None):
+                 reduce_avg: Optional[bool] = None, tail_mb: Optional[float] = 16.0, linear_schedule: Optional[str] = None,
+                 bucket_dtype: str = "f32"):
         """``tail_mb``: the buckets that complete LAST (block 0 and the patch embedding: backward produces gradients head first) are cut
         to this size.  Every earlier bucket's all-reduce runs beside the rest of backward; the last one has nothing left to hide behind,
         so its size IS the exposed time of the exchange (a ring all-reduce is per-link bound on xGMI: ~64 MiB takes ~1.1 ms at 8
         ranks, 16 MiB a quarter of that).  None: uniform buckets.
         ``overlap=False``: exchange every bucket in ``finish()`` after backward instead of as soon as its last gradient lands --
         required for models that use a parameter more than once per backward (weight tying, a module called twice per forward):
-        the overlapped exchange announces a parameter after its FIRST gradient write and raises if it sees a second one."""
+        the overlapped exchange announces a parameter after its FIRST gradient write and raises if it sees a second one.
+        ``bucket_dtype="bf16"`` (SURVEY 2.3 C1 "fp32 or bf16 flat buckets"; off by default): every bucket travels as bfloat16 -- the
+        rank's f32 gradients are divided by the world size, rounded ONCE to bf16 into a staging buffer, summed by the collective in bf16,
+        and widened back into the f32 flat buffer -- half the bytes on a per-link-bound xGMI ring (ViT-B: 172 instead of 345 MB per
+        step) for a relative error of the averaged gradient of at most ~2^-8 (one rounding per rank + the collective's bf16 additions;
+        tests/test_parallel_cpu.py bounds it at world 2).  Bucket sizes (``bucket_mb`` / ``tail_mb``) keep counting f32 bytes, so the
+        bucket boundaries, and with them the overlap pattern, are the same in both formats."""
         super().__init__()
+        if bucket_dtype not in ("f32", "bf16"):
+            raise ValueError(f"bucket_dtype must be 'f32' or 'bf16', got {bucket_dtype!r}")
+        self.bucket_dtype = bucket_dtype
         self.module = module
         self.pg = process_group
         self.overlap = bool(overlap)
@@ -130,6 +140,7 @@ class DataParallel(nn.Module):
                     p.copy_(flat[off:off + p.numel()].view_as(p))
                     off += p.numel()
         self.linear_schedule = None
+        self._tuning = None
         if self.world > 1 and dev.type == "cuda":
             # The persistent Linear kernels expect one workgroup per CU with a fixed tile list each (132-147 KB of LDS, every VGPR).
             # While an RCCL collective runs beside the backward pass it holds some CUs, the workgroups meant for them start a
@@ -191,6 +202,10 @@ class DataParallel(nn.Module):
             if abs(float(probe.item()) - 1.0) > 1e-6:
                 raise RuntimeError(f"DataParallel: ReduceOp.AVG of ones returned {float(probe.item())!r}")
             self._avg_in_collective = True
+        if self.bucket_dtype == "bf16" and self._avg_in_collective:
+            raise ValueError("DataParallel: bucket_dtype='bf16' divides before it rounds; it does not combine with reduce_avg=True")
+        # staging buffer of the 16-bit exchange: same offsets as the flat f32 gradient buffer
+        self._stage16 = torch.empty_like(self.flat_grad, dtype=torch.bfloat16) if (self.bucket_dtype == "bf16" and self.world > 1) else None
         self._announced = set()
         self._works = []
         self._timing = None  # enable_timing(): per-step records of the exchange
@@ -237,36 +252,53 @@ class DataParallel(nn.Module):
         b["ready"] += 1
         if b["ready"] == b["n"]:
             b["ready"] = 0
-            view = self.flat_grad[b["lo"]:b["hi"]]
             t0 = self._mark()
-            self._works.append((self._exchange(view, async_op=True), self._bucket_of[id(p)], t0))
+            self._works.append((self._exchange(b, async_op=True), self._bucket_of[id(p)], t0))
 
-    def _exchange(self, view, async_op):
-        """mean over the ranks of one bucket, in place"""
+    def _exchange(self, b, async_op):
+        """mean over the ranks of one bucket, in place (f32 buckets) or through the bf16 staging buffer (`_complete` widens it back)"""
+        view = self.flat_grad[b["lo"]:b["hi"]]
         if self._avg_in_collective:
             return dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.pg, async_op=async_op)
         view.div_(self.world)
+        if self._stage16 is not None:
+            view = self._stage16[b["lo"]:b["hi"]].copy_(view)  # the ONE rounding of this rank's contribution
         if self._drain_first:
             torch.cuda.current_stream().synchronize()
-        return dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op)
+        w = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op)
+        if not async_op:
+            self._complete(b)
+        return w
+
+    def _complete(self, b):
+        """behind a finished bucket exchange: the bf16 sum goes back into the f32 gradient buffer (nothing to do for f32 buckets)"""
+        if self._stage16 is not None:
+            self.flat_grad[b["lo"]:b["hi"]].copy_(self._stage16[b["lo"]:b["hi"]])
+
+    def exchange_bytes_per_step(self) -> int:
+        return int(self.flat_grad.numel()) * (2 if self.bucket_dtype == "bf16" else self.flat_grad.element_size())
 
     def set_linear_schedule(self, schedule: str):
         """'per-tile' (one workgroup per tile, the dispatcher balances around CUs an RCCL kernel holds) or 'persistent' (one workgroup
         per CU walks a tile list: the single-GPU schedule).  Process-wide knobs of the library (tad_linear_tuning): `close()` puts the
         single-GPU defaults back."""
-        from . import kernels as _K
+        from .tuning import TuningScope
         if schedule not in ("per-tile", "persistent"):
             raise ValueError(f"linear_schedule must be 'per-tile' or 'persistent', got {schedule!r}")
-        _K.linear_tuning(persistent=int(schedule == "persistent"), splitk_defer=1)
+        if getattr(self, "_tuning", None) is not None:
+            self._tuning.close()
+        # (lock=False: this wrapper keeps its plan for as long as it lives; a scope that held the process-wide lock that long would block
+        #  every other thread's scoped change)
+        self._tuning = TuningScope(persistent=int(schedule == "persistent"), splitk_defer=1, lock=False).__enter__()
         self.linear_schedule = schedule
 
     def close(self):
-        """undo the process-wide Linear scheduling knobs this wrapper set (a later single-GPU model in the same process gets the
-        defaults back)"""
-        if self.linear_schedule is not None:
-            from . import kernels as _K
-            _K.linear_tuning(persistent=_K.LINEAR_TUNING_DEFAULTS["persistent"], splitk_defer=_K.LINEAR_TUNING_DEFAULTS["splitk_defer"])
-            self.linear_schedule = None
+        """undo the process-wide Linear scheduling knobs this wrapper set: whatever was in force before it was built comes back (a later
+        single-GPU model in the same process does not inherit this wrapper's plan)"""
+        if getattr(self, "_tuning", None) is not None:
+            self._tuning.close()
+            self._tuning = None
+        self.linear_schedule = None
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
@@ -313,7 +345,8 @@ class DataParallel(nn.Module):
         return {"steps": len(steps), "exposed_ms": round(mean(exposed), 4), "exposed_ms_max": round(max(exposed), 4),
                 "bucket_ms": [None if not v else round(mean(v), 4) for v in per_bucket],
                 "bucket_mbytes": [round((b["hi"] - b["lo"]) * self.flat_grad.element_size() / 2 ** 20, 1) for b in self.buckets],
-                "late_buckets_per_step": round(mean(late), 2), "overlap": self.overlap, "avg_in_collective": self._avg_in_collective}
+                "late_buckets_per_step": round(mean(late), 2), "overlap": self.overlap, "avg_in_collective": self._avg_in_collective,
+                "bucket_dtype": self.bucket_dtype}
 
     def finish(self):
         """Wait for every in-flight bucket (call after backward, before the optimizer step)."""
@@ -321,6 +354,7 @@ class DataParallel(nn.Module):
         t_in = self._mark()
         for w, bi, t0 in self._works:
             w.wait()
+            self._complete(self.buckets[bi])
             if rec is not None:
                 rec["buckets"].append((bi, t0, self._mark()))
         self._works.clear()
@@ -333,7 +367,7 @@ class DataParallel(nn.Module):
             if b["ready"] or not self.overlap:
                 b["ready"] = 0
                 t0 = self._mark()
-                self._exchange(self.flat_grad[b["lo"]:b["hi"]], async_op=False)
+                self._exchange(b, async_op=False)
                 if rec is not None:
                     rec["buckets"].append((i, t0, self._mark()))
                     rec["late"] += 1

@@ -32,3 +32,35 @@ def test_bench_self_launches_n_ranks_and_prints_one_line():
 def test_bench_single_rank_needs_no_launcher():
     r, lines = _run(["--gpus", "1", "--dry-run"])
     assert r.returncode == 0 and len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 1
+
+
+@pytest.mark.timeout(300)
+def test_bench_scaling_flags_reach_every_rank():
+    """the flags of the first multi-GPU run (tools/scale_run.sh): strong scaling splits --global-batch over the ranks, --linear-schedule and
+    --bucket-dtype are accepted and echoed by the launch plumbing"""
+    r, lines = _run(["--gpus", "2", "--dry-run", "--global-batch", "256", "--linear-schedule", "persistent", "--bucket-dtype", "bf16"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(lines[0])
+    assert out["flags"] == {"linear_schedule": "persistent", "bucket_dtype": "bf16", "global_batch": 256, "per_gpu_batch": 128, "scaling": "strong"}
+    r, lines = _run(["--gpus", "2", "--dry-run"])
+    assert json.loads(lines[0])["flags"] == {"linear_schedule": "auto", "bucket_dtype": "f32", "global_batch": 0, "per_gpu_batch": 32, "scaling": "weak"}
+    r, _ = _run(["--gpus", "1", "--dry-run", "--bucket-dtype", "fp8"])
+    assert r.returncode != 0
+
+
+def test_rccl_summary_reads_the_debug_lines(tmp_path):
+    """`collective.rccl` quotes RCCL's own description of the communicator: parsed from NCCL_DEBUG=INFO text (format of RCCL 2.2x)"""
+    sys.path.insert(0, ROOT)
+    import bench
+    log = tmp_path / "rccl.log"
+    log.write_text("\n".join([
+        "host:1:1 [0] NCCL INFO RCCL version 2.26.6+hip7.0 HEAD:abc",
+        "host:1:1 [0] NCCL INFO comm 0x1 rank 0 nranks 8 cudaDev 0 busId 1000 - Init START",
+        "host:1:1 [0] NCCL INFO Channel 00/0 : 0[0] -> 1[1] via P2P/IPC",
+        "host:1:1 [0] NCCL INFO Channel 01/0 : 0[0] -> 7[7] via P2P/IPC",
+        "host:1:1 [0] NCCL INFO Channel 01/0 : 3[3] -> 4[4] via P2P/IPC",
+        "host:1:1 [0] NCCL INFO 16 coll channels, 16 nvls channels, 16 p2p channels, 2 p2p channels per peer"]))
+    s = bench.rccl_summary(str(log))
+    assert s["channels"] == 2 and s["transports"] == ["P2P/IPC"] and s["peers_of_rank0"] == [1, 7]
+    assert s["transport_of_rank0"] == "xGMI peer-to-peer" and any("RCCL version" in ln for ln in s["lines"])
+    assert "not collected" in bench.rccl_summary(None)["debug_lines"]

@@ -90,3 +90,71 @@ def test_missing_library_fails_loudly(tmp_path, monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.TadError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_linear_workspace_bytes_is_the_split_plan_of_the_launcher(lib_path):
+    """tad_linear_workspace_bytes and the launcher share ONE copy of the split plan's geometry.  Known answers on the 256 CUs
+    the library assumes without a device: ViT-B's Linears never split along K under the default knobs; ViT-L's N = 1024, K = 4096 Linears at
+    32 clips leave a 16-tile tail behind 3 whole rounds = 16 tiles x 8 shares of 256 KiB + the 4 KiB header; and a problem taller than the
+    32-bit offset limit is sized by the row ranges the launcher cuts it into."""
+    from simple_tad_amd import _lib
+    lib = _lib.load()
+    M = 32 * 1568
+    for n, k in ((2304, 768), (768, 768), (3072, 768), (768, 3072), (768, 2304)):
+        assert lib.tad_linear_workspace_bytes(M, n, k) == 0, (n, k)
+    assert lib.tad_linear_workspace_bytes(M, 1024, 4096) == 4096 + 16 * 8 * 256 * 256 * 4
+    # forced split-K ("splitk_tail" 2) takes ViT-B's 76-tile tails as three shares each
+    v = ctypes.c_int(-1)
+    assert lib.tad_linear_tuning_get(b"splitk_tail", ctypes.byref(v)) == 0 and v.value == 1
+    assert lib.tad_linear_tuning(b"splitk_tail", 2) == 0
+    try:
+        assert lib.tad_linear_tuning_get(b"splitk_tail", ctypes.byref(v)) == 0 and v.value == 2
+        assert lib.tad_linear_workspace_bytes(M, 768, 3072) == 4096 + 78 * 3 * 256 * 256 * 4
+    finally:
+        assert lib.tad_linear_tuning(b"splitk_tail", 1) == 0
+    # 573 952 rows x 1024 columns exceed the 32-bit offsets of an f32 epilogue: the launcher runs 523 776 + 50 176 rows (f32) or 524 032 +
+    # 49 920 (16-bit), and the query sizes the workspace for THOSE launches (the 16-tile tail of the 50 176-row range: 128 partial tiles),
+    # not for the 8-tile tail the whole problem would have (64 partial tiles: too small, the split used to drop out quietly)
+    assert lib.tad_linear_workspace_bytes(523776 + M, 1024, 4096) == 4096 + 16 * 8 * 256 * 256 * 4
+    assert lib.tad_linear_tuning_get(b"no_such_knob", ctypes.byref(v)) == -1 and b"unknown key" in lib.tad_last_error_string()
+
+
+def test_tuning_scope_restores_what_it_replaced(lib_path):
+    """two models in one process do not see each other's plan: a TuningScope puts back the knobs, the precision mode and the q pre-scale
+    contract it found, also when the body raises; scopes nest; DataParallel's plan is such a scope"""
+    import simple_tad_amd as T
+    from simple_tad_amd import kernels as K, ops
+    from simple_tad_amd.tuning import TuningScope
+    base = {k: K.linear_tuning_get(k) for k in K.LINEAR_TUNING_DEFAULTS}
+    assert base == K.LINEAR_TUNING_DEFAULTS, "the library's initial knobs are the documented defaults"
+    with TuningScope(precision="half", attn_q_prescale=False, persistent=0, group_m=4):
+        assert (K.linear_tuning_get("persistent"), K.linear_tuning_get("group_m")) == (0, 4)
+        assert T.get_precision() == "half" and ops.get_attn_q_prescale() is False
+        with TuningScope(persistent=1, variant=7):
+            assert (K.linear_tuning_get("persistent"), K.linear_tuning_get("variant"), K.linear_tuning_get("group_m")) == (1, 7, 4)
+        assert (K.linear_tuning_get("persistent"), K.linear_tuning_get("variant")) == (0, 0)
+    assert {k: K.linear_tuning_get(k) for k in K.LINEAR_TUNING_DEFAULTS} == base
+    assert T.get_precision() == "fast" and ops.get_attn_q_prescale() is True
+    with pytest.raises(RuntimeError, match="boom"):
+        with TuningScope(tail_192=0, precision="half"):
+            raise RuntimeError("boom")
+    assert K.linear_tuning_get("tail_192") == 1 and T.get_precision() == "fast"
+    with pytest.raises(Exception):  # a refused value leaves nothing half-applied
+        with TuningScope(group_m=2, variant=6):
+            pass
+    assert K.linear_tuning_get("group_m") == 0 and K.linear_tuning_get("variant") == 0
+    with pytest.raises(ValueError, match="unknown"):
+        TuningScope(no_such_knob=1)
+    # a second thread's scope waits for the first one's instead of interleaving two plans
+    import threading
+    seen = []
+    def other():
+        with TuningScope(group_m=16):
+            seen.append(K.linear_tuning_get("group_m"))
+    with TuningScope(group_m=2):
+        th = threading.Thread(target=other)
+        th.start()
+        th.join(0.2)
+        assert th.is_alive() and seen == [] and K.linear_tuning_get("group_m") == 2
+    th.join(5)
+    assert seen == [16] and K.linear_tuning_get("group_m") == 0

@@ -400,3 +400,33 @@ def test_overflowed_step_is_skipped_on_the_device_and_settled_one_call_later():
         assert any(not torch.equal(v, before[k]) for k, v in m.state_dict().items())
     finally:
         T.set_precision("fast")
+
+
+def test_non_finite_norm_under_clipping_without_scaling_is_a_counted_skip():
+    """bf16 mode, clip_grad on, a NaN in the gradients: the update is skipped on the device (tad_grad_norm_coef makes the coefficient 0),
+    the weights survive, and the skip is accounted for at the next call -- counted, step counts rolled back, scale untouched (ADVICE r05;
+    the reference's clip_grad_norm_ would write NaN into every weight here, utils.py:401-404)."""
+    import simple_tad_amd as T
+    from simple_tad_amd import engine
+    import torch.nn.functional as F
+    torch.manual_seed(0)
+    m = T.VisionTransformer(img_size=32, patch_size=16, embed_dim=128, depth=2, num_heads=2, all_frames=4, tubelet_size=2, num_classes=2,
+                            mlp_ratio=4, qkv_bias=True, init_scale=1.0).cuda().train()
+    x, y = torch.randn(4, 3, 4, 32, 32).cuda(), torch.tensor([0, 1, 1, 0]).cuda()
+    opt = engine.create_optimizer(m, lr=1e-3, weight_decay=0.05)
+    sc = engine.NativeScalerWithGradNormCount(m)
+    assert not sc.scaling()
+    before = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    loss = F.cross_entropy(m(x), y) * float("nan")
+    n1 = sc(loss, opt, clip_grad=1.0, parameters=list(m.parameters()))
+    opt.zero_grad()
+    torch.cuda.synchronize()
+    assert not math.isfinite(float(n1))
+    assert all(torch.equal(v, before[k]) for k, v in m.state_dict().items()), "a NaN norm must leave the parameters untouched"
+    assert opt.steps == 1 and sc.skipped_steps == 0  # (not settled yet)
+    n2 = sc(F.cross_entropy(m(x), y), opt, clip_grad=1.0, parameters=list(m.parameters()))
+    opt.zero_grad()
+    assert math.isfinite(float(n2)) and sc.skipped_steps == 1 and sc.scale == 65536.0
+    assert sc.state_dict()["scale"] == 1.0 and opt.steps == 1, "the skipped step's count was taken back, the good step counted"
+    assert all(int(opt.state[p]["step"]) == 1 for p in m.parameters())
+    assert any(not torch.equal(v, before[k]) for k, v in m.state_dict().items())

@@ -6,12 +6,12 @@
 # it runs on.  Everything is written under gpurun_out/<round>_final/profiles/ too (what travels back).
 set -o pipefail
 R="${1:-r05}"; O="gpurun_out/${R}_final"; P="$O/profiles"; mkdir -p "$P"; export TMPDIR=/tmp
-if [ -f simple_tad_amd/libtad_ablation.so ]; then
-  TAD_LIB=simple_tad_amd/libtad_ablation.so timeout -k 10 300 python3 tools/exp_clock.py --out "$P/${R}_clock.json" > "$O/clock.log" 2>&1 || { echo "clock failed"; tail -5 "$O/clock.log"; exit 1; }
+if [ -f build_exp/libtad_ablation.so ]; then
+  TAD_LIB=build_exp/libtad_ablation.so timeout -k 10 300 python3 tools/exp_clock.py --out "$P/${R}_clock.json" > "$O/clock.log" 2>&1 || { echo "clock failed"; tail -5 "$O/clock.log"; exit 1; }
   cp "$P/${R}_clock.json" profiles/
 fi
-if [ -f simple_tad_amd/libtad_ablation.so ]; then  # the IEEE-half twins' clock: not read by bench.py, kept beside the bf16 one
-  TAD_LIB=simple_tad_amd/libtad_ablation.so timeout -k 10 300 python3 tools/exp_clock.py --dtype f16 --out "$P/${R}_clock_f16.json" > "$O/clock_f16.log" 2>&1 && cp "$P/${R}_clock_f16.json" profiles/ || echo "f16 clock failed"
+if [ -f build_exp/libtad_ablation.so ]; then  # the IEEE-half twins' clock: not read by bench.py, kept beside the bf16 one
+  TAD_LIB=build_exp/libtad_ablation.so timeout -k 10 300 python3 tools/exp_clock.py --dtype f16 --out "$P/${R}_clock_f16.json" > "$O/clock_f16.log" 2>&1 && cp "$P/${R}_clock_f16.json" profiles/ || echo "f16 clock failed"
 fi
 echo "[collect_final] clock done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > "$O/kt.log" 2>&1 || { echo "kernel trace failed"; tail -5 "$O/kt.log"; exit 1; }

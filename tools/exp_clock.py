@@ -3,7 +3,7 @@
 
 Needs an ablation build next to the production one (only that build carries the stamps):
     TAD_BUILD_LIB=libtad_ablation.so TAD_BUILD_ABLATION=1 python -m simple_tad_amd.build --force
-    TAD_LIB=simple_tad_amd/libtad_ablation.so python tools/exp_clock.py --out profiles/r03_clock.json
+    TAD_LIB=build_exp/libtad_ablation.so python tools/exp_clock.py --out profiles/r03_clock.json
 For each probe: >= 2 s of back-to-back launches on random data, then ONE stamped launch; every workgroup records s_memtime (shader
 clock) and s_memrealtime (100 MHz) at the start and the end of its loop (gemm_nt 256x256: around the K loop of each tile; attention
 dK/dV: around the tile loop); clock = d(memtime) / d(memrealtime) x 100 MHz, median over workgroups / tiles.

@@ -13,9 +13,9 @@ for mode in fast half; do
   find "$O/kt_$mode" -name "*.csv" -size +8M -delete 2>/dev/null
   tail -1 "$O/kt_$mode.log" | python3 -c "import json,sys; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$mode', j['value'], j['ms_per_step'])"
 done
-if [ -f simple_tad_amd/libtad_ablation.so ]; then
+if [ -f build_exp/libtad_ablation.so ]; then
   for dt in bf16 f16; do
-    TAD_LIB=simple_tad_amd/libtad_ablation.so timeout -k 10 300 python3 tools/exp_clock.py --dtype $dt --out "$O/clock_$dt.json" > "$O/clock_$dt.log" 2>&1 || { echo "clock $dt failed"; tail -5 "$O/clock_$dt.log"; exit 1; }
+    TAD_LIB=build_exp/libtad_ablation.so timeout -k 10 300 python3 tools/exp_clock.py --dtype $dt --out "$O/clock_$dt.json" > "$O/clock_$dt.log" 2>&1 || { echo "clock $dt failed"; tail -5 "$O/clock_$dt.log"; exit 1; }
     grep -v "^{" "$O/clock_$dt.log"
   done
 fi
