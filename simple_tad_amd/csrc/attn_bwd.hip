@@ -706,9 +706,10 @@ namespace tad { namespace knobs {
 #ifndef TAD_OPND_F16
 unsigned long long* attn_stamps = nullptr;
 int attn_dma_mode = getenv("TAD_ATTN_DMA_MODE") ? atoi(getenv("TAD_ATTN_DMA_MODE")) : 0;  // 2 / 3: timing-only ablations (ablation builds); shared with attn_fwd.hip
+int attn_fwd_q64 = getenv("TAD_ATTN_FWD_Q64") ? atoi(getenv("TAD_ATTN_FWD_Q64")) : 0;  // 1: the forward with 64 query rows per wave (attn_fwd_q64_kernel; experiment, round 6)
 #else
 extern unsigned long long* attn_stamps;
-extern int attn_dma_mode;
+extern int attn_dma_mode, attn_fwd_q64;
 #endif
 }}  // namespace tad::knobs
 using namespace tad::knobs;
@@ -723,6 +724,11 @@ extern "C" int tad_attn_tuning(const char* key, int value) {
     TAD_REQUIRE(value == 0, "attn_tuning: dma_mode=%d: only 0 outside ablation builds (2 / 3 are timing-only ablations)", value);
 #endif
     attn_dma_mode = value;
+    return TAD_OK;
+  }
+  if (!strcmp(key, "fwd_q64")) {
+    TAD_REQUIRE(value == 0 || value == 1, "attn_tuning: fwd_q64=%d not in {0, 1}", value);
+    attn_fwd_q64 = value;
     return TAD_OK;
   }
   set_error("attn_tuning: unknown key '%s'", key);

@@ -490,11 +490,221 @@ __global__ __launch_bounds__(256, TAD_FWD_ROWSUM_VALU ? 4 : 1) void attn_fwd_ker
   if (qrow < N && h5 == 0 && lse) lse[((int64_t)b * H + head) * N + qrow] = QS ? (m_run + __log2f(l_tot)) * 0.69314718055994530942f : m_run * scale + __logf(l_tot);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Q64 (experiment, round 6; tad_attn_tuning("fwd_q64", 1) / TAD_ATTN_FWD_Q64=1; head_dim 64, pre-scaled q, 16-bit output, no dropout):
+// the same forward with SIXTY-FOUR query rows per wave -- two 32-row halves that share every K and V^T fragment the wave reads -- and two
+// waves per workgroup (128 query rows per workgroup as before, so the grid and the ragged last block are unchanged).  Why: per 32 x 32 x 16
+// matrix instruction the production kernel reads 1 KiB of fragments from the LDS (a wave re-reads the whole 64-key K and V tile for its 32
+// rows), twice what the four-wave GEMM loop reads per matrix-pipe cycle; sharing the fragments between two row halves halves the LDS read
+// bytes per score, the lever MI355X_MICROARCH.md ranks next to "fewer VALU instructions" for a kernel that runs at the chip's power limit.
+// The price: ~200 registers per lane (two score / output / Q sets), i.e. TWO waves per SIMD instead of four.  Same arithmetic in the same
+// order per row as attn_fwd_kernel: results are bit-identical.
+template <bool HAS_LO>
+__global__ __launch_bounds__(128, 2) void attn_fwd_q64_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, uint16_t* __restrict__ out_lo,
+                                                              float* __restrict__ lse, int N, int H, int B) {
+  constexpr int HD = 64, NKS = 4, TILE_BYTES = KV_TILE * 128, BUF_BYTES = 2 * TILE_BYTES, NWV = 2, QH = 2;
+  __shared__ __attribute__((aligned(1024))) char lds[2 * BUF_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nblk = (N + Q_BLOCK - 1) / Q_BLOCK;
+  const int lin = xcd_remap(blockIdx.x, gridDim.x);
+  const int qblk = lin % nblk, pair = lin / nblk;
+  const int head = pair % H, b = pair / H;
+  const int q0 = qblk * Q_BLOCK + wave * (QH * Q_WAVE);
+  const bool wave_live = q0 < N;  // wave-uniform
+  const int ql = lane & 31, h5 = lane >> 5;
+  const int64_t tok_stride = (int64_t)3 * H * HD;
+  const uint16_t* base = qkv + (int64_t)b * N * tok_stride + head * HD;
+
+  op16x8 qf[QH][NKS];
+#pragma unroll
+  for (int hh = 0; hh < QH; ++hh) {
+    int qrow = q0 + 32 * hh + ql;
+    if (qrow > N - 1) qrow = N - 1;  // clamped rows are computed but never stored
+    const uint16_t* qp = base + (int64_t)qrow * tok_stride + 8 * h5;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) qf[hh][ks] = *reinterpret_cast<const op16x8*>(qp + 16 * ks);
+  }
+  // staging as in attn_fwd_kernel; a tile's 8 + 8 one-KiB pieces are shared by TWO waves: wave w moves pieces w, w + 2, w + 4, w + 6 of K and of V
+  const uint32_t qkv_bytes = (uint32_t)B * (uint32_t)N * (uint32_t)tok_stride * 2u;
+  const auto rs_qkv = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(qkv), 0, (int)qkv_bytes, 0x00020000);
+  const int dkey = lane >> 3, dch = lane & 7;
+  uint32_t dma_k[4], dma_v[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int key = (wave + NWV * i) * 8 + dkey;
+    const uint32_t rowb = (uint32_t)(((int64_t)b * N + key) * tok_stride * 2) + (uint32_t)(head * HD * 2);
+    dma_k[i] = rowb + (uint32_t)(H * HD * 2) + (uint32_t)((dch ^ swk(key)) << 4);
+    dma_v[i] = rowb + (uint32_t)(2 * H * HD * 2) + (uint32_t)((dch ^ swv(key)) << 4);
+  }
+  const uint32_t tile_step = (uint32_t)(tok_stride * 2);
+#define Q64_DMA_TILE(buf, kv0)                                                                                                          \
+  {                                                                                                                                     \
+    char* kl_ = lds + (buf) * BUF_BYTES;                                                                                                \
+    const uint32_t adv_ = (uint32_t)(kv0) * tile_step;                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                                       \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_qkv, LDS_PTR(kl_ + (wave + NWV * i) * 1024), 16, dma_k[i] + adv_, 0, 0, 0);           \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                                       \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_qkv, LDS_PTR(kl_ + TILE_BYTES + (wave + NWV * i) * 1024), 16, dma_v[i] + adv_, 0, 0, 0); \
+  }
+  f32x16 o[QH][2];
+#pragma unroll
+  for (int hh = 0; hh < QH; ++hh)
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[hh][dt][r] = 0.f;
+  const int G = lane >> 4, li = lane & 15;
+  const int v_q = li >> 2, v_p = li & 3;
+  const int v_h = G >> 1, v_dc = 16 * (G & 1) + 4 * v_p;
+  uint32_t v_rd[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt) {
+    const int col = dt * 32 + v_dc, key = 4 * v_h + v_q;
+    v_rd[dt] = lds_addr(lds) + (uint32_t)(key * 128 + (((col >> 3) ^ swv(key)) << 4) + (col & 7) * 2);
+  }
+  uint32_t k_rd[NKS];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) k_rd[ks] = lds_addr(lds) + (uint32_t)(ql * 128 + (((2 * ks + h5) ^ swk(ql)) << 4));
+  op16x8 sel;  // row-sum selector of attn_fwd_kernel
+  {
+    const int m = lane & 15, kg = lane >> 4;
+    const bool on = ((m & 7) == 0 && (kg & 1) == 0) || ((m & 7) == 4 && (kg & 1) == 1);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sel[e] = (op16_t)(on ? 1.0f : 0.0f);
+  }
+  const int nt = (N + KV_TILE - 1) / KV_TILE;
+  float m_run[QH] = {-1e30f, -1e30f}, l_run[QH] = {0.f, 0.f};
+  auto fwd_tile = [&](auto BUFC, const int T) {
+    constexpr int BUF = decltype(BUFC)::value;
+    const int kv0 = T * KV_TILE;
+    if (T + 1 < nt) Q64_DMA_TILE(BUF ^ 1, kv0 + KV_TILE);
+    if (wave_live) {
+      op16x8 kf[2][NKS];
+      f32x16 s[QH][2];
+      static_for<0, 2 * NKS>([&](auto ic) {
+        constexpr int i_ = decltype(ic)::value, kt = i_ / NKS, ks = i_ % NKS;
+        kf[kt][ks] = lds_read_b128<op16x8, BUF * BUF_BYTES + kt * 32 * 128>(k_rd[ks]);
+      });
+#pragma unroll
+      for (int hh = 0; hh < QH; ++hh)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[hh][kt][r] = 0.f;
+      static_for<0, 2 * NKS>([&](auto ic) {
+        constexpr int i_ = decltype(ic)::value, kt = i_ / NKS, ks = i_ % NKS;
+        lds_wait<2 * NKS - 1 - i_>(kf[kt][ks]);
+        s[0][kt] = TAD_MFMA_32x32x16(kf[kt][ks], qf[0][ks], s[0][kt]);
+        s[1][kt] = TAD_MFMA_32x32x16(kf[kt][ks], qf[1][ks], s[1][kt]);
+      });
+      if (kv0 + KV_TILE > N) {
+        int lim = N - kv0 - 4 * h5;
+        asm volatile("" : "+v"(lim));
+#pragma unroll
+        for (int hh = 0; hh < QH; ++hh)
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if (kt * 32 + (r & 3) + 8 * (r >> 2) >= lim) s[hh][kt][r] = -1e30f;
+      }
+      op16x8 pf[QH][2][2];
+#pragma unroll
+      for (int hh = 0; hh < QH; ++hh) {
+        float mloc = s[hh][0][0];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[hh][kt][r]);
+        const float m_tile = half_swap_max(mloc);
+        if (__any((m_tile - m_run[hh]) > RESCALE_THR)) {
+          const float m_new = fmaxf(m_run[hh], m_tile);
+          const float alpha = fast_exp2(m_run[hh] - m_new);
+          m_run[hh] = m_new;
+          l_run[hh] *= alpha;
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[hh][dt][r] *= alpha;
+        }
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[hh][kt][s2][j] = (op16_t)fast_exp2(s[hh][kt][8 * s2 + j] - m_run[hh]);
+      }
+      f32x4 rs[QH] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      s16x4 vlo[2][2], vhi[2][2];  // [group parity][dt]
+      auto v_issue = [&](auto gc, auto pc) {
+        constexpr int g_ = decltype(gc)::value, par = decltype(pc)::value;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          vlo[par][dt] = lds_tr16_b64<BUF * BUF_BYTES + TILE_BYTES + g_ * 16 * 128>(v_rd[dt]);
+          vhi[par][dt] = lds_tr16_b64<BUF * BUF_BYTES + TILE_BYTES + g_ * 16 * 128 + 8 * 128>(v_rd[dt]);
+        }
+      };
+      v_issue(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+      static_for<0, 4>([&](auto gc) {
+        constexpr int g_ = decltype(gc)::value, par = g_ & 1;
+        if constexpr (g_ < 3) v_issue(std::integral_constant<int, g_ + 1>{}, std::integral_constant<int, par ^ 1>{});
+#pragma unroll
+        for (int hh = 0; hh < QH; ++hh) rs[hh] = TAD_MFMA_16x16x32(sel, pf[hh][g_ >> 1][g_ & 1], rs[hh]);
+        lds_wait<(g_ < 3 ? 4 : 0)>(vlo[par][0], vhi[par][0], vlo[par][1], vhi[par][1]);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const op16x8 vf = join_tr(vlo[par][dt], vhi[par][dt]);
+#pragma unroll
+          for (int hh = 0; hh < QH; ++hh) o[hh][dt] = TAD_MFMA_32x32x16(vf, pf[hh][g_ >> 1][g_ & 1], o[hh][dt]);
+        }
+      });
+#pragma unroll
+      for (int hh = 0; hh < QH; ++hh) l_run[hh] += rs[hh][0];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+  Q64_DMA_TILE(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int t = 0; t < nt; t += 2) {
+    fwd_tile(std::integral_constant<int, 0>{}, t);
+    if (t + 1 < nt) fwd_tile(std::integral_constant<int, 1>{}, t + 1);
+  }
+#undef Q64_DMA_TILE
+  // ---- epilogue (the tile ring is free: the loop ended on a barrier): per 32-row half exactly attn_fwd_kernel's
+#pragma unroll
+  for (int hh = 0; hh < QH; ++hh) {
+    const int qh0 = q0 + 32 * hh;
+    if (qh0 >= N) continue;  // (wave-uniform)
+    const float inv = 1.f / l_run[hh];
+    const int64_t obase0 = (((int64_t)b * N + qh0) * H + head) * HD;
+    uint2 pk[2][4], lo[2][4];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const float v0 = o[hh][dt][4 * r4 + 0] * inv, v1 = o[hh][dt][4 * r4 + 1] * inv, v2 = o[hh][dt][4 * r4 + 2] * inv, v3 = o[hh][dt][4 * r4 + 3] * inv;
+        pk[dt][r4].x = pack_op16x2(v0, v1);
+        pk[dt][r4].y = pack_op16x2(v2, v3);
+        asm volatile("" : "+v"(pk[dt][r4].x), "+v"(pk[dt][r4].y));  // (see attn_fwd_kernel: one rounding of the stored word, then its residual)
+        lo[dt][r4].x = pack_op16x2(v0 - op16_lo_f32(pk[dt][r4].x), v1 - op16_hi_f32(pk[dt][r4].x));
+        lo[dt][r4].y = pack_op16x2(v2 - op16_lo_f32(pk[dt][r4].y), v3 - op16_hi_f32(pk[dt][r4].y));
+      }
+    store_rows_via_lds(lds + wave * ROW_PATCH_BYTES, pk, out + obase0, (int64_t)H * HD, N - qh0, lane);
+    if (HAS_LO) store_rows_via_lds(lds + wave * ROW_PATCH_BYTES, lo, out_lo + obase0, (int64_t)H * HD, N - qh0, lane);
+    const int qrow = qh0 + ql;
+    if (qrow < N && h5 == 0 && lse) lse[((int64_t)b * H + head) * N + qrow] = (m_run[hh] + __log2f(l_run[hh])) * 0.69314718055994530942f;
+  }
+}
+
 TAD_NAMESPACE_END
 
 using namespace tad;
 
-namespace tad { namespace knobs { extern int attn_dma_mode; } }  // attn_bwd.hip (tad_attn_tuning)
+namespace tad { namespace knobs { extern int attn_dma_mode, attn_fwd_q64; } }  // attn_bwd.hip (tad_attn_tuning)
 
 extern "C" int tad_attn_fwd(const uint16_t* qkv, void* out, int out_dtype, uint16_t* out_lo, float* lse, int B, int N, int H, int d,
                             float scale, int q_prescaled, float dropout_p, uint32_t seed, tad_stream_t stream) {
@@ -513,6 +723,12 @@ extern "C" int tad_attn_fwd(const uint16_t* qkv, void* out, int out_dtype, uint1
               (long long)B * N * 3 * H * HD * 2, B, N, H);
   TAD_REQUIRE((int64_t)((N + Q_BLOCK - 1) / Q_BLOCK) * H * B < (1ll << 31), "attn_fwd: grid too large");
   const dim3 grid((unsigned)(((N + Q_BLOCK - 1) / Q_BLOCK) * H * B)), block(256);
+  // (experiment) sixty-four query rows per wave: attn_fwd_q64_kernel, same grid, 128 threads -- only the production contract of the training step
+  if (tad::knobs::attn_fwd_q64 && d == 64 && q_prescaled && dropout_p == 0.f && out_dtype == TAD_OP16) {
+    if (out_lo) hipLaunchKernelGGL((attn_fwd_q64_kernel<true>), grid, dim3(128), 0, (hipStream_t)stream, qkv, (uint16_t*)out, out_lo, lse, N, H, B);
+    else hipLaunchKernelGGL((attn_fwd_q64_kernel<false>), grid, dim3(128), 0, (hipStream_t)stream, qkv, (uint16_t*)out, out_lo, lse, N, H, B);
+    return check_launch("attn_fwd_q64");
+  }
 #define LAUNCH_FWD___(H_, O_, Q_, D_, M_) hipLaunchKernelGGL((attn_fwd_kernel<H_, O_, Q_, D_, M_>), grid, block, 0, (hipStream_t)stream, qkv, out, out_lo, lse, N, H, B, scale, drop)
 #define LAUNCH_FWD__(O_, Q_, D_, M_) { if (d == 64) LAUNCH_FWD___(64, O_, Q_, D_, M_); else LAUNCH_FWD___(80, O_, Q_, D_, M_); }
 #define LAUNCH_FWD_(O_, Q_, M_) { if (dropout_p > 0.f) LAUNCH_FWD__(O_, Q_, true, M_) else LAUNCH_FWD__(O_, Q_, false, M_) }

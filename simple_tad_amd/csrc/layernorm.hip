@@ -7,6 +7,13 @@
 TAD_NAMESPACE_BEGIN
 
 constexpr int LN_MAX_V = 8;  // float4 per lane -> D <= 64*4*8 = 2048
+#ifndef TAD_LN_NT
+#define TAD_LN_NT 0  // (experiment) cache policy of LayerNorm's once-touched streams, a bit mask: 1 = the backward's loads of x, dy and the
+                     // incoming residual gradient (each read for the last time here) non-temporal; 2 = the forward's load of x; 4 = the backward's
+                     // store of the residual gradient (next read a whole block later); 8 = the forward's store.  Round 2 measured the single bits null on
+                     // the round-2 step; re-measured at step level in round 6 (experiments/README.md r06)
+#endif
+constexpr bool LN_NT_BWD_LD = (TAD_LN_NT & 1) != 0, LN_NT_FWD_LD = (TAD_LN_NT & 2) != 0, LN_NT_BWD_ST = (TAD_LN_NT & 4) != 0, LN_NT_FWD_ST = (TAD_LN_NT & 8) != 0;
 
 int launch_reduce_partials(const float* partial, float* out, int splits, int64_t n, int accumulate, hipStream_t st);
 int launch_reduce_cols(const float* partial, float* out0, float* out1, float* out2, int nq, int splits, int n, int accumulate,
@@ -27,7 +34,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = lane + 64 * i;
-    v[i] = (c < D4) ? ldg_f4<false>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    v[i] = (c < D4) ? ldg_f4<LN_NT_FWD_LD>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
   }
   const float mu = wave_sum(s) / (float)D;
@@ -60,9 +67,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
         uint2 p;
         p.x = pack_op16x2(o.x, o.y);
         p.y = pack_op16x2(o.z, o.w);
-        stg_u2<false>(reinterpret_cast<uint2*>((uint16_t*)y + row * D) + c, p);
+        stg_u2<LN_NT_FWD_ST>(reinterpret_cast<uint2*>((uint16_t*)y + row * D) + c, p);
       } else {
-        stg_f4<false>(reinterpret_cast<float4*>((float*)y + row * D) + c, o);
+        stg_f4<LN_NT_FWD_ST>(reinterpret_cast<float4*>((float*)y + row * D) + c, o);
       }
     }
   }
@@ -117,10 +124,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
     for (int i = 0; i < NV; ++i) {
       const int c = lane + 64 * i;
       if (FULL || c < D4) {
-        xv[i] = ldg_f4<false>(reinterpret_cast<const float4*>(x + row * D) + c);
-        if (DY_BF16) dyp[i] = ldg_u2<false>(reinterpret_cast<const uint2*>((const uint16_t*)dy + row * D) + c);
-        else dyv[i] = ldg_f4<false>(reinterpret_cast<const float4*>((const float*)dy + row * D) + c);
-        rv[i] = ldg_f4<false>(reinterpret_cast<const float4*>(rsrc + row * D) + c);
+        xv[i] = ldg_f4<LN_NT_BWD_LD>(reinterpret_cast<const float4*>(x + row * D) + c);
+        if (DY_BF16) dyp[i] = ldg_u2<LN_NT_BWD_LD>(reinterpret_cast<const uint2*>((const uint16_t*)dy + row * D) + c);
+        else dyv[i] = ldg_f4<LN_NT_BWD_LD>(reinterpret_cast<const float4*>((const float*)dy + row * D) + c);
+        rv[i] = ldg_f4<LN_NT_BWD_LD>(reinterpret_cast<const float4*>(rsrc + row * D) + c);
       }
     }
     const float mu = mean[row], rs = rstd[row];
@@ -162,7 +169,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = lane + 64 * i;
-      if (FULL || c < D4) stg_f4<false>(reinterpret_cast<float4*>(dx + row * D) + c, o[i]);
+      if (FULL || c < D4) stg_f4<LN_NT_BWD_ST>(reinterpret_cast<float4*>(dx + row * D) + c, o[i]);
       // the bf16 copy and the column sums feed the branch Linear, whose output was scaled per sample (drop-path)
       o[i].x *= sc; o[i].y *= sc; o[i].z *= sc; o[i].w *= sc;
       if (FULL || c < D4) { cs[i].x += o[i].x; cs[i].y += o[i].y; cs[i].z += o[i].z; cs[i].w += o[i].w; }

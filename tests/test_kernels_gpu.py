@@ -247,6 +247,32 @@ def test_attention_fwd_bwd(K, B, N, H, prescaled):
         check(g[:, :, i], r[:, :, i], tol=2 * BF16_ULP, what=f"attn d{nm}")
 
 
+@pytest.mark.parametrize("B,N,H", [(2, 100, 2), (1, 1568, 2), (3, 64, 1), (2, 8, 3), (1, 129, 1), (4, 600, 12), (1, 200, 1)])
+def test_attention_fwd_q64_variant_is_bit_identical(K, B, N, H):
+    """the opt-in forward with 64 query rows per wave (tad_attn_tuning("fwd_q64", 1): two 32-row halves share every K / V fragment read) does
+    the same arithmetic in the same order per row: out, out_lo and lse are bit-identical to the production kernel's, ragged blocks, a
+    rescale-forcing spike and whole dead halves included"""
+    scale = 64 ** -0.5
+    qkv = bf(R.tensor_for(f"att.qkv{N}", (B * N, 3 * H * 64), scale=1.0))
+    if N == 200:  # late maxima (cdna_hip_programming.md rule 26): a key in tile 2 far above everything before it
+        q4 = qkv.reshape(B, N, 3, H, 64).clone()
+        q4[0, 150, 1, 0] = q4[0, 17, 0, 0] * 6.0
+        q4[0, 64, 1, 0] = q4[0, 70, 0, 0] * 5.0
+        qkv = bf(q4.reshape(B * N, -1))
+    opnd, _ = prescaled_pair(qkv, B, N, H, scale, bf)
+    qd = dev(opnd).to(torch.bfloat16)
+    ref = K.attn_fwd(qd, B, N, H, scale, want_lo=True, q_prescaled=True)
+    K.attn_tuning(fwd_q64=1)
+    try:
+        got = K.attn_fwd(qd, B, N, H, scale, want_lo=True, q_prescaled=True)
+        got_nolo = K.attn_fwd(qd, B, N, H, scale, q_prescaled=True)
+    finally:
+        K.attn_tuning(fwd_q64=0)
+    for a, b, nm in zip(ref, got, ("out", "lse", "out_lo")):
+        assert torch.equal(a, b), nm
+    assert torch.equal(got_nolo[0], ref[0]) and torch.equal(got_nolo[1], ref[1])
+
+
 @pytest.mark.parametrize("prescaled", [True, False], ids=["q_prescaled", "plain_q"])
 def test_attention_softmax_spike(K, prescaled):
     """Force every branch of the online softmax's offset handling (cdna_hip_programming.md rule 26: a rare data-dependent branch needs an

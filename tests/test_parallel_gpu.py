@@ -247,7 +247,7 @@ def _nccl_world1(q):
         dp = DataParallel(m, bucket_mb=0.25)
         g = torch.randn_like(dp.flat_grad)
         dp.flat_grad.copy_(g)
-        works = [dp._exchange(dp.flat_grad[b["lo"]:b["hi"]], async_op=True) for b in dp.buckets]
+        works = [dp._exchange(b, async_op=True) for b in dp.buckets]
         for w in works:
             w.wait()
         torch.cuda.synchronize()

@@ -1,48 +1,95 @@
 #!/bin/bash
-# PMC passes over the GEMM kernels at the benchmark shapes (run ON the GPU box): where does the operand staging path (TA -> TCP -> L2 -> fabric) spend
-# its cycles?   tools/pmc_gemm.sh [tag]   -> gpurun_out/<tag>_pmc_gemm/summary.txt
+# PMC passes over the GEMM kernels, PER LINEAR SHAPE of a ViT-B block as the model launches it (run ON the GPU box):
+#   tools/pmc_gemm.sh [tag] [extra pass names...]     -> gpurun_out/<tag>_pmc_gemm/summary.txt
+# Workload: tools/pmc_gemm_shapes.py (eight Linears + the weight gradients, fixed order; its manifest says how many gemm launches a call of
+# each shape makes, so every dispatch of a pass is attributed to a shape by its position in the dispatch sequence).
+# What it answers: matrix-pipe busy % per shape from the SQ counters (not from wall-clock division), bytes fetched through
+# the L2's memory side / algorithmic bytes, L2 hit rate, and where the operand staging path (TA -> TCP -> L2 -> fabric) spends its cycles.
+# (at most two counters of one TCP / TCC / TA block per pass: "Request exceeds the capabilities of the hardware to collect" otherwise -- and that
+#  failure hangs until the timeout; the SQ block takes eight.  The program goes directly after `--`.)
 export TMPDIR=/tmp
-O="gpurun_out/${1:-r04}_pmc_gemm"; mkdir -p "$O"
+TAG="${1:-r06}"; shift || true
+O="gpurun_out/${TAG}_pmc_gemm"; mkdir -p "$O"
 run() {  # name, counters...
   local name="$1"; shift
-  timeout -k 10 90 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$O/$name" -- python3 tools/bench_kernels.py --only gemm_nt,gemm_tn --iters 3 > "$O/$name.log" 2>&1 || { echo "pass $name failed"; tail -3 "$O/$name.log"; return 1; }
+  timeout -k 10 120 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$O/$name" -- python3 tools/pmc_gemm_shapes.py --iters 3 --manifest "$O/manifest.json" > "$O/$name.log" 2>&1 \
+    || { echo "pass $name failed"; tail -3 "$O/$name.log"; return 1; }
+  echo "[pmc_gemm] pass $name done"
 }
-# (at most two counters of one block per pass: "Request exceeds the capabilities of the hardware to collect" otherwise -- and that failure hangs)
-run a TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE || exit 1
-run a2 TA_DATA_STALLED_BY_TC_CYCLES_sum TA_BUFFER_READ_LDS_WAVEFRONTS_sum || exit 1
-run b TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum || exit 1
-run b2 TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum || exit 1
-run b3 TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum || exit 1
+run s1 SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY || exit 1
+run s2 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_MISC SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE || exit 1
+run f FETCH_SIZE || exit 1
+run w WRITE_SIZE || exit 1
 run c TCC_HIT_sum TCC_MISS_sum || exit 1
 run c2 TCC_REQ_sum TCC_EA0_RDREQ_sum || exit 1
-run d TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum GRBM_GUI_ACTIVE || exit 1
-run d2 TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_LFIFO_STALL_CYCLES_sum || exit 1
+run b TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum || exit 1
+run b2 TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum || exit 1
+# optional passes named on the command line as name:COUNTER[,COUNTER] (counters this script does not know to exist on gfx950: a failure is reported, not fatal)
+for spec in "$@"; do
+  run "${spec%%:*}" $(echo "${spec#*:}" | tr ',' ' ') || echo "[pmc_gemm] optional pass ${spec%%:*} failed"
+done
 python3 - "$O" <<'PY'
-import csv, glob, sys, collections, re
+import csv, glob, json, os, sys, collections, re
 O = sys.argv[1]
-agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(lambda: collections.defaultdict(set))
-order = {}
-PASSES = ["a", "a2", "b", "b2", "b3", "c", "c2", "d", "d2"]
-for p in PASSES:
-    for f in glob.glob(f"{O}/{p}/*/*counter_collection.csv"):
-        for r in csv.DictReader(open(f)):
-            n = r["Kernel_Name"]
-            m = re.search(r"(gemm_nt_kernel|gemm_tn_kernel)<([^>]*)>", n)
-            if not m: continue
-            # one line per (kernel instantiation, grid): the benchmark launches every shape with its own grid / template arguments
-            k = f"{m.group(1)}<{m.group(2)}> grid {r.get('Grid_Size', '?')}"
-            agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k][p].add(r["Dispatch_Id"])
-lines = []
-for k, c in sorted(agg.items()):
-    n = {p: max(len(cnt[k][p]), 1) for p in PASSES}
-    cyc = c["GRBM_GUI_ACTIVE"] / (n["a"] + n["d"]) / 8.0  # GPU-active cycles per launch (the counter is summed over the 8 XCDs)
-    if cyc <= 0: continue
-    per = lambda name, p: c[name] / n[p]
-    lines.append(f"{k}: launches {n['a']}, {cyc:.3e} GPU-active cycles per launch and XCD; percentages = counter summed over the 256 CUs / (256 x cycles)")
-    lines.append(f"   TA busy (sum over 256 TAs) {per('TA_TA_BUSY_sum','a') / cyc / 256 * 100:5.1f} % of cycles; address path stalled by TC {per('TA_ADDR_STALLED_BY_TC_CYCLES_sum','a') / cyc / 256 * 100:5.1f} %, data path stalled by TC {per('TA_DATA_STALLED_BY_TC_CYCLES_sum','a2') / cyc / 256 * 100:5.1f} %; LDS-DMA wave-instructions {per('TA_BUFFER_READ_LDS_WAVEFRONTS_sum','a2'):.3e}")
-    lines.append(f"   TCP: busy {per('TCP_GATE_EN1_sum','b') / cyc / 256 * 100:5.1f} %, waiting for L2 data {per('TCP_PENDING_STALL_CYCLES_sum','b') / cyc / 256 * 100:5.1f} %, tag-conflict stalls {per('TCP_READ_TAGCONFLICT_STALL_CYCLES_sum','b3') / cyc / 256 * 100:5.1f} %, TCR->TCP stalls {per('TCP_TCR_TCP_STALL_CYCLES_sum','b3') / cyc / 256 * 100:5.1f} %, TA data stalls {per('TCP_TCP_TA_DATA_STALL_CYCLES_sum','d2') / cyc / 256 * 100:5.1f} %, latency FIFO full {per('TCP_LFIFO_STALL_CYCLES_sum','d2') / cyc / 256 * 100:5.1f} %; read requests to L2 {per('TCP_TCC_READ_REQ_sum','b2'):.3e}, mean L2 read latency {per('TCP_TCC_READ_REQ_LATENCY_sum','b2') / max(per('TCP_TCC_READ_REQ_sum','b2'), 1):.0f} cycles")
-    lines.append(f"   L2: requests {per('TCC_REQ_sum','c2'):.3e}, hit {per('TCC_HIT_sum','c'):.3e} miss {per('TCC_MISS_sum','c'):.3e} ({100 * per('TCC_HIT_sum','c') / max(per('TCC_HIT_sum','c') + per('TCC_MISS_sum','c'), 1):.1f} % hits), fabric read requests {per('TCC_EA0_RDREQ_sum','c2'):.3e}")
-    lines.append(f"   address translation: UTCL1 hits {per('TCP_UTCL1_TRANSLATION_HIT_sum','d'):.3e} misses {per('TCP_UTCL1_TRANSLATION_MISS_sum','d'):.3e}; TCP cache accesses {per('TCP_TOTAL_CACHE_ACCESSES_sum','d'):.3e}")
-open(f"{O}/summary.txt", "w").write("\n".join(lines) + "\n"); print("\n".join(lines))
+man = json.load(open(os.path.join(O, "manifest.json")))
+shapes = man["shapes"]
+GEMM = re.compile(r"gemm_nt_kernel|gemm_tn_w4_kernel|gemm_tn_kernel")
+def per_shape(pass_name):
+    """{shape name: {counter: value summed over the gemm dispatches of ONE call, averaged over the calls}}, dispatches attributed in order"""
+    rows = []
+    for f in glob.glob(f"{O}/{pass_name}/*/*counter_collection.csv"):
+        rows += list(csv.DictReader(open(f)))
+    if not rows:
+        return None
+    by_disp = collections.OrderedDict()
+    for r in sorted(rows, key=lambda r: int(r["Dispatch_Id"])):
+        if not GEMM.search(r["Kernel_Name"]):
+            continue
+        d = by_disp.setdefault(int(r["Dispatch_Id"]), {"kernel": r["Kernel_Name"], "grid": r.get("Grid_Size"), "c": {}})
+        d["c"][r["Counter_Name"]] = d["c"].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    disp = list(by_disp.values())
+    out, i = {}, 0
+    for s in shapes:
+        n = s["calls"] * s["gemm_launches_per_call"]
+        mine = disp[i:i + n]
+        i += n
+        if len(mine) < n:
+            return {"error": f"pass {pass_name}: {len(disp)} gemm dispatches, the manifest expects more (at shape {s['name']})"}
+        mine = mine[s["gemm_launches_per_call"]:]  # drop the first (warm-up / allocation) call
+        acc = collections.defaultdict(float)
+        for d in mine:
+            for k, v in d["c"].items():
+                acc[k] += v
+        calls = s["calls"] - 1
+        out[s["name"]] = {k: v / calls for k, v in acc.items()}
+        out[s["name"]]["_kernels"] = sorted({re.sub(r"^void |\(.*$", "", d["kernel"])[:90] + f" grid {d['grid']}" for d in mine})
+    if i != len(disp):
+        out["_warning"] = f"pass {pass_name}: {len(disp) - i} gemm dispatches beyond the manifest"
+    return out
+P = {p: per_shape(p) for p in sorted({os.path.basename(os.path.dirname(os.path.dirname(f))) for f in glob.glob(f"{O}/*/*/*counter_collection.csv")})}
+lines = [f"# tools/pmc_gemm.sh: M = {man['M']}, D = {man['D']}; per CALL of each Linear (its planned launches together), mean of {man['iters']} calls; SQ cycle counters are",
+         "# summed over the chip; `matrix pipe busy` = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES); FETCH_SIZE x 2 per the guide's gfx950 correction"]
+for p, v in P.items():
+    if isinstance(v, dict) and ("error" in v or "_warning" in v):
+        lines.append(f"# {v.get('error') or v.get('_warning')}")
+g = lambda p, s, k: (P.get(p) or {}).get(s, {}).get(k, float("nan"))  # noqa: E731
+for s in shapes:
+    n = s["name"]
+    busy = g("s1", n, "SQ_VALU_MFMA_BUSY_CYCLES") / (4 * g("s1", n, "SQ_BUSY_CU_CYCLES") + 1e-9)
+    wc = g("s1", n, "SQ_WAVE_CYCLES") + 1e-9
+    fetch, write = 2 * g("f", n, "FETCH_SIZE") * 1024 if g("f", n, "FETCH_SIZE") == g("f", n, "FETCH_SIZE") else float("nan"), g("w", n, "WRITE_SIZE") * 1024
+    lines.append(f"{n} ({s['kernel']} N={s['N']} K={s['K']}, {s['gemm_launches_per_call']} launch(es) per call; algorithmic {s['bytes'] / 1e6:.1f} MB, {s['flops'] / 1e9:.1f} GF)")
+    lines.append(f"   matrix pipe busy {100 * busy:5.1f} %  (MFMA busy cycles {g('s1', n, 'SQ_VALU_MFMA_BUSY_CYCLES'):.3e}, of which beside VALU {100 * g('s1', n, 'SQ_VALU_MFMA_COEXEC_CYCLES') / (g('s1', n, 'SQ_VALU_MFMA_BUSY_CYCLES') + 1e-9):.1f} %; MFMA insts {g('s2', n, 'SQ_INSTS_MFMA'):.3e} = {16 * g('s2', n, 'SQ_INSTS_MFMA'):.3e} pipe cycles at 16 each)")
+    lines.append(f"   waves: parked (waitcnt / barrier) {100 * g('s1', n, 'SQ_WAIT_ANY') / wc:4.1f} %  issue-stalled {100 * g('s1', n, 'SQ_WAIT_INST_ANY') / wc:4.1f} %  issuing {100 * g('s1', n, 'SQ_ACTIVE_INST_ANY') / wc:4.1f} % (VALU {100 * g('s1', n, 'SQ_ACTIVE_INST_VALU') / wc:4.1f} %); VALU insts {g('s2', n, 'SQ_INSTS_VALU'):.3e}, LDS issue {g('s2', n, 'SQ_ACTIVE_INST_LDS'):.3e} / LDS-issue stall {g('s2', n, 'SQ_WAIT_INST_LDS'):.3e}, GUI-active cycles per XCD {g('s2', n, 'GRBM_GUI_ACTIVE') / 8:.3e}")
+    lines.append(f"   memory side of the L2: fetched {fetch / 1e6:7.1f} MB + written {write / 1e6:7.1f} MB = {(fetch + write) / 1e6:7.1f} MB = {(fetch + write) / s['bytes']:.2f} x algorithmic"
+                 + (f" (reads alone {fetch / (s['a_bytes'] + s['w_bytes']):.2f} x the two operands; x {s['a_bytes'] / 1e6:.1f} MB, W {s['w_bytes'] / 1e6:.1f} MB)" if "a_bytes" in s else ""))
+    hit, miss = g("c", n, "TCC_HIT_sum"), g("c", n, "TCC_MISS_sum")
+    lines.append(f"   L2: requests {g('c2', n, 'TCC_REQ_sum'):.3e}, hits {100 * hit / (hit + miss + 1e-9):.1f} %, fabric read requests {g('c2', n, 'TCC_EA0_RDREQ_sum'):.3e}; TCP busy {g('b', n, 'TCP_GATE_EN1_sum'):.3e} cycles, waiting for L2 data {100 * g('b', n, 'TCP_PENDING_STALL_CYCLES_sum') / (g('b', n, 'TCP_GATE_EN1_sum') + 1e-9):.1f} % of them, mean L2 read latency {g('b2', n, 'TCP_TCC_READ_REQ_LATENCY_sum') / (g('b2', n, 'TCP_TCC_READ_REQ_sum') + 1e-9):.0f} cycles")
+    for p in P:
+        if p not in ("s1", "s2", "f", "w", "c", "c2", "b", "b2") and isinstance(P[p], dict) and n in P[p]:
+            lines.append(f"   pass {p}: " + ", ".join(f"{k} {v:.4e}" for k, v in P[p][n].items() if not k.startswith("_")))
+    lines.append("   kernels: " + "; ".join((P.get("s1") or {}).get(n, {}).get("_kernels", [])))
+open(f"{O}/summary.txt", "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
 PY
 find "$O" -name "*.csv" -size +4M -delete 2>/dev/null; true
