@@ -75,7 +75,7 @@ def parse_args():
                     "INIT / GRAPH lines of rank 0 in a temporary file: version, channels, transport per peer) into the `collective` object")
     ap.add_argument("--no-live-profile", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip everything after the timed region except cpu_baseline")
-    ap.add_argument("--only-extras", default="", help="comma list out of roofline_all,engine_loop,fwd_only,half,precise,mae_pretrain,torch_route,vit_small,vit_large "
+    ap.add_argument("--only-extras", default="", help="comma list out of power,roofline_all,engine_loop,fwd_only,half,precise,mae_pretrain,torch_route,vit_small,vit_large "
                                                       "(default: all)")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel-class table to stderr")
     ap.add_argument("--dry-run", action="store_true", help="launch plumbing only: rendezvous, one all-reduce, rank 0 prints the world size "
@@ -99,6 +99,89 @@ def self_launch(args):
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     print(f"[bench] starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
     sys.exit(subprocess.call(cmd, env=env))
+
+
+class PowerSampler:
+    """Board power, power cap and shader clock of the GPUs visible in sysfs (amdgpu hwmon: power1_average / power1_input in microwatts,
+    power1_cap, freq1_input), read by a thread every `period` seconds while a region runs.  Which card is the one under load is decided
+    from the samples (the card whose mean power is highest): the container sees every card of the host in sysfs but runs on one.
+    Why it is in the bench line: every MFMA kernel of the step runs AT the board's power cap, so the cap, not the
+    matrix pipe's nominal rate, is what bounds the step -- the line carries the evidence with every run."""
+
+    def __init__(self, period=0.05):
+        import glob
+        self.period, self.samples, self._stop, self._th = period, [], None, None
+        self.cards = []
+        for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            p = next((os.path.join(d, f) for f in ("power1_average", "power1_input") if os.path.exists(os.path.join(d, f))), None)
+            if p:
+                self.cards.append((d, p))
+
+    def _read(self):
+        out = []
+        for d, p in self.cards:
+            try:
+                w = int(open(p).read()) / 1e6
+                f = os.path.join(d, "freq1_input")
+                out.append((w, int(open(f).read()) / 1e6 if os.path.exists(f) else None))
+            except Exception:  # noqa: BLE001
+                out.append((None, None))
+        return out
+
+    def caps(self):
+        caps = []
+        for d, _ in self.cards:
+            try:
+                caps.append(int(open(os.path.join(d, "power1_cap")).read()) / 1e6)
+            except Exception:  # noqa: BLE001
+                caps.append(None)
+        return caps
+
+    def start(self):
+        import threading
+        self.samples, self._stop = [], threading.Event()
+
+        def loop():
+            while not self._stop.is_set():
+                self.samples.append((time.perf_counter(), self._read()))
+                self._stop.wait(self.period)
+        self._th = threading.Thread(target=loop, daemon=True)
+        self._th.start()
+        return self
+
+    def stop(self, drop_s=0.0):
+        """per card: {mean_w, max_w, mean_sclk_mhz, n} over the samples taken at least `drop_s` after start()"""
+        if self._th is None:
+            return None
+        self._stop.set()
+        self._th.join()
+        self._th = None
+        if not self.samples or not self.cards:
+            return None
+        t0 = self.samples[0][0]
+        keep = [s for t, s in self.samples if t - t0 >= drop_s] or [s for _, s in self.samples]
+        per = []
+        for c in range(len(self.cards)):
+            ws = [s[c][0] for s in keep if s[c][0] is not None]
+            fs = [s[c][1] for s in keep if s[c][1] is not None]
+            per.append({"mean_w": sum(ws) / len(ws) if ws else None, "max_w": max(ws) if ws else None,
+                        "mean_sclk_mhz": sum(fs) / len(fs) if fs else None, "n": len(ws)})
+        return per
+
+    def summary(self, per, seconds_per_step=None):
+        """the card under load, as one small object for the bench line"""
+        if not per:
+            return {"error": "no amdgpu hwmon power file readable under /sys/class/drm"}
+        loaded = max(range(len(per)), key=lambda i: per[i]["mean_w"] or 0.0)
+        c, caps = per[loaded], self.caps()
+        cap = caps[loaded] if loaded < len(caps) else None
+        out = {"mean_w": round(c["mean_w"], 1) if c["mean_w"] else None, "max_w": c["max_w"], "cap_w": cap,
+               "frac_of_cap": round(c["mean_w"] / cap, 4) if (c["mean_w"] and cap) else None,
+               "mean_sclk_mhz": round(c["mean_sclk_mhz"]) if c["mean_sclk_mhz"] else None, "samples": c["n"],
+               "source": f"sysfs hwmon of the loaded card ({len(per)} cards visible, index {loaded}), sampled every {self.period:g} s during the timed region"}
+        if seconds_per_step and c["mean_w"]:
+            out["joules_per_step"] = round(c["mean_w"] * seconds_per_step, 2)
+        return out
 
 
 def rccl_summary(log_path):
@@ -430,7 +513,7 @@ def main():
         B = args.global_batch // world
     x = torch.randn(B, 3, args.frames, 224, 224, device=dev)
     y = torch.randint(0, 2, (B,), device=dev)
-    total_steps = args.steps + args.warmup + 128  # (+ the un-timed extra steps after the region)
+    total_steps = args.steps + args.warmup + 512  # (+ the un-timed extra steps after the region: power, roofline_all, engine_loop, half, precise)
     lr_sched = E.cosine_scheduler(5e-4 * B * world / 256, 1e-6, 1, max(total_steps, 2), warmup_epochs=0)
 
     dp = opt = scaler = None
@@ -513,6 +596,7 @@ def main():
     if rank == 0 and not args.no_live_profile:
         prof = K.LaunchProfiler(only=["gemm_nt"], stride=13)
         K.set_profiler(prof)
+    power = PowerSampler().start() if rank == 0 else None  # (a thread that reads two sysfs files every 50 ms: no GPU work, no sync)
     barrier()
     t0 = time.perf_counter()
     for it in range(args.steps):
@@ -521,6 +605,7 @@ def main():
     dt_own = time.perf_counter() - t0  # this rank's own time, before it waits for the others
     barrier()
     dt = time.perf_counter() - t0
+    power_cards = power.stop() if power is not None else None
     K.set_profiler(None)
     collective = None
     if distributed:
@@ -571,6 +656,12 @@ def main():
     }
     if collective is not None:
         out["collective"] = collective
+    try:
+        out["power"] = power.summary(power_cards, seconds_per_step=dt / args.steps)
+        if out["power"].get("joules_per_step"):
+            out["power"]["picojoules_per_algorithmic_flop"] = round(out["power"]["joules_per_step"] / (B * fl) * 1e12, 3)
+    except Exception as e:  # noqa: BLE001
+        out["power"] = {"error": repr(e)}
     fp = read_profiles()
     out["from_profiles"] = fp
     held = fp.get("held_clock_mhz", {})
@@ -601,7 +692,7 @@ def main():
                 out["roofline"]["traffic_over_algorithmic"] = round(out["roofline"]["traffic"] / max(out["roofline"]["algorithmic_bytes"], 1), 3)
 
     want = set(filter(None, args.only_extras.split(","))) or {"roofline_all", "engine_loop", "fwd_only", "half", "precise", "mae_pretrain", "torch_route",
-                                                                "vit_small", "vit_large", "inference_b1"}
+                                                                "vit_small", "vit_large", "inference_b1", "power"}
     extras = world == 1 and not args.no_extras and args.mode == "train" and args.graph != 1
     if args.precision != "fast":  # the other modes' objects compare against the bf16 headline: only the per-class table makes sense here
         want &= {"roofline_all"}
@@ -634,6 +725,24 @@ def main():
                 ent.update({"bound": "hbm", "achieved": round(gbs, 1), "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)})
             ra[k] = ent
         return ra
+
+    if extras and "power" in want:
+        # ---- board power in steady state: the hwmon reading is a moving average over about a second, so the 0.9 s timed region above reads low
+        # (`power.timed_region`); here the same step runs back to back for ~3 s and the first 1.2 s of samples are dropped
+        try:
+            ps = PowerSampler(period=0.02).start()
+            n_p = max(60, int(3.0 / max(dt / args.steps, 1e-3)))
+            dtp = timed_steps(0, n_p)
+            pw = ps.summary(ps.stop(drop_s=1.2), seconds_per_step=dtp)
+            pw["steps"], pw["ms_per_step"] = n_p, round(1e3 * dtp, 3)
+            if pw.get("joules_per_step"):
+                pw["picojoules_per_algorithmic_flop"] = round(pw["joules_per_step"] / (B * fl) * 1e12, 3)
+            pw["timed_region"] = out.get("power")
+            pw["reading"] = ("the whole training step draws this share of the board's power cap: the cap, not the matrix pipe's nominal rate, bounds every MFMA "
+                             "kernel of the step (DESIGN.md section 3a; per kernel class: tools/power_probe.py -> profiles/r06_power.txt)")
+            out["power"] = pw
+        except Exception as e:  # noqa: BLE001
+            out["power"] = {"error": repr(e), "timed_region": out.get("power")}
 
     if extras and "roofline_all" in want:
         # ---- every kernel class, HIP events around every launch of 3 extra steps (the events add ~20 us of queue time per launch, so

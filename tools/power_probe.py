@@ -113,7 +113,29 @@ def main():
     ap.add_argument("--seconds", type=float, default=4.0)
     ap.add_argument("--only", default="")
     ap.add_argument("--out", default="")
+    ap.add_argument("--cmd", default="", help="sample while this command runs (a child process, e.g. tools/micro/mfma_power 16 5) instead of the built-in classes")
     a = ap.parse_args()
+    if a.cmd:
+        import shlex
+        import subprocess
+        sm = Sampler()
+        caps = sm.caps()
+        sm.start()
+        t0 = time.perf_counter()
+        pr = subprocess.run(shlex.split(a.cmd), capture_output=True, text=True)
+        dt = time.perf_counter() - t0
+        per = sm.stop(drop_s=1.5)
+        print(pr.stdout[-1500:], pr.stderr[-300:])
+        card = max(range(len(per)), key=lambda i: per[i]["mean_w"] or 0.0) if per else None
+        res = {"cmd": a.cmd, "seconds": dt, "caps_w": caps, "cards": per, "loaded_card_index": card, "stdout_tail": pr.stdout.strip().splitlines()[-3:]}
+        if card is not None:
+            c = per[card]
+            print(f"[power_probe] {a.cmd}: mean {c['mean_w']:.0f} W, max {c['max_w']:.0f} W of a {caps[card]} W cap, mean shader clock {c['mean_sclk_mhz'] or 0:.0f} MHz "
+                  f"({c['n']} samples after the first 1.5 s)")
+        if a.out:
+            os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+            json.dump(res, open(a.out, "w"), indent=1)
+        return
     import simple_tad_amd as T
     from simple_tad_amd import engine as E, kernels as K
     dev, bf = torch.device("cuda", 0), torch.bfloat16
@@ -136,26 +158,30 @@ def main():
     g, bb = torch.ones(D, device=dev), torch.zeros(D, device=dev)
     _, mean, rstd = K.layernorm_fwd(xf, g, bb, 1e-6)
 
-    torch.manual_seed(0)
-    model = T.create_model("vit_base_patch16_224", pretrained=False, num_classes=2, all_frames=16, tubelet_size=2, final_reduction="fc_norm",
-                           drop_path_rate=0.1, init_scale=0.001, use_flash_attn=True).to(dev).train()
-    from simple_tad_amd.parallel import DataParallel
-    dp = DataParallel(model, bucket_mb=64.0)
-    opt = E.create_optimizer(dp, lr=1e-3, weight_decay=0.05, layer_decay=0.75)
-    scaler = E.NativeScalerWithGradNormCount(dp)
-    crit = torch.nn.CrossEntropyLoss()
-    clip = torch.randn(B, 3, 16, 224, 224, device=dev)
-    y = torch.randint(0, 2, (B,), device=dev)
-    params = list(model.parameters())
-    dp.zero_grad()
+    only = [o for o in a.only.split(",") if o]
+    need_model = not only or any(n.startswith(o) for o in only for n in ("step", "forward_only"))
+    step = fwd_only = None
+    if need_model:
+      torch.manual_seed(0)
+      model = T.create_model(  "vit_base_patch16_224", pretrained=False, num_classes=2, all_frames=16, tubelet_size=2, final_reduction="fc_norm",
+                             drop_path_rate=0.1, init_scale=0.001, use_flash_attn=True).to(dev).train()
+      from simple_tad_amd.parallel import DataParallel
+      dp = DataParallel(model, bucket_mb=64.0)
+      opt = E.create_optimizer(dp, lr=1e-3, weight_decay=0.05, layer_decay=0.75)
+      scaler = E.NativeScalerWithGradNormCount(dp)
+      crit = torch.nn.CrossEntropyLoss()
+      clip = torch.randn(B, 3, 16, 224, 224, device=dev)
+      y = torch.randint(0, 2, (B,), device=dev)
+      params = list(model.parameters())
+      dp.zero_grad()
 
-    def step():
-        scaler(crit(dp(clip), y), opt, parameters=params, update_grad=True)
-        dp.zero_grad()
+      def step():
+          scaler(crit(dp(clip), y), opt, parameters=params, update_grad=True)
+          dp.zero_grad()
 
-    def fwd_only():
-        with torch.no_grad():
-            model(clip)
+      def fwd_only():
+          with torch.no_grad():
+              model(clip)
 
     work = {
         "idle": (None, 0.0),
@@ -169,12 +195,11 @@ def main():
         "attn_bwd": (lambda: K.attn_bwd(qkv, out, dout, lse, B, N, H, 0.125, out_lo=lo, q_prescaled=True), 8.0 * B * H * N * N * 64),
         "layernorm_bwd": (lambda: K.layernorm_bwd(dout, xf, g, mean, rstd, dres=xf, want_bf16=True, want_colsum=True), 0.0),
     }
-    only = [o for o in a.only.split(",") if o]
     sm = Sampler()
     caps = sm.caps()
     rows = {}
     for name, (fn, flops) in work.items():
-        if only and not any(name.startswith(o) for o in only):
+        if (only and not any(name.startswith(o) for o in only)) or (fn is None and name != "idle"):
             continue
         if fn is not None:
             for _ in range(3):
@@ -197,9 +222,10 @@ def main():
         print(name, json.dumps(rows[name]), flush=True)
     # the card that carries the load is the one whose power moves most between idle and the step
     res_out = {"caps_w": caps, "source": "sysfs hwmon" if sm._hw else ("amdsmi" if sm._smi else sm.src), "classes": rows, "device": K.device_info()}
-    if "idle" in rows and "step" in rows and rows["idle"]["cards"] and rows["step"]["cards"]:
-        d = [(s["mean_w"] or 0) - (i["mean_w"] or 0) for s, i in zip(rows["step"]["cards"], rows["idle"]["cards"])]
-        card = max(range(len(d)), key=lambda i: d[i])
+    loaded = [r for n, r in rows.items() if n != "idle" and r["cards"]]
+    if loaded:
+        ncard = len(loaded[0]["cards"])
+        card = max(range(ncard), key=lambda i: max((r["cards"][i]["mean_w"] or 0) for r in loaded))
         res_out["loaded_card_index"] = card
         print(f"\n{'class':40s} {'W mean':>8s} {'W max':>8s} {'cap':>6s} {'% cap':>6s} {'sclk MHz':>9s} {'ms/call':>9s} {'TFLOP/s':>8s} {'J/call':>8s}")
         for name, r in rows.items():
