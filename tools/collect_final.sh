@@ -5,7 +5,7 @@
 # installed into profiles/ BEFORE `python bench.py` runs, so the bench line's `from_profiles` entries are current for the sources
 # it runs on.  Everything is written under gpurun_out/<round>_final/profiles/ too (what travels back).
 set -o pipefail
-R="${1:-r05}"; O="gpurun_out/${R}_final"; P="$O/profiles"; mkdir -p "$P"; export TMPDIR=/tmp
+R="${1:-r06}"; O="gpurun_out/${R}_final"; P="$O/profiles"; mkdir -p "$P"; export TMPDIR=/tmp
 if [ -f build_exp/libtad_ablation.so ]; then
   TAD_LIB=build_exp/libtad_ablation.so timeout -k 10 300 python3 tools/exp_clock.py --out "$P/${R}_clock.json" > "$O/clock.log" 2>&1 || { echo "clock failed"; tail -5 "$O/clock.log"; exit 1; }
   cp "$P/${R}_clock.json" profiles/
