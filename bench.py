@@ -382,7 +382,7 @@ def cpu_baseline_child(threads, frames, batch=2):
             p_.grad = None
         torch.nn.functional.cross_entropy(O.forward(x, P, depth=12, num_heads=12, tubelet=2, patch=16), y).backward()
 
-    for i in range(3):  # pass 0 is the warm-up; the parent reports the LAST pass that finished inside its limit
+    for i in range(2):  # pass 0 is the warm-up, pass 1 the timed one (~36 s each on the GPU box's 16-core share); the parent reports the LAST pass that finished inside its limit
         t0 = time.perf_counter()
         one()
         print(json.dumps({"s_per_batch": time.perf_counter() - t0, "pass": "warm-up" if i == 0 else f"timed {i}", "reps": 1, "threads": threads, "batch": batch}), flush=True)

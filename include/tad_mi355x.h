@@ -80,6 +80,13 @@ int tad_im2col_tubelets(const float* x, uint16_t* cols, int B, int C, int T, int
 int tad_patch_embed_fwd(const float* x, const uint16_t* w_bf16, const float* bias, const float* pos,
                         float* out, uint16_t* cols, int B, int C, int T, int H, int W, int tubelet,
                         int patch, int D, tad_stream_t stream);
+/* The same forward as an IMPLICIT GEMM: the x operand is read straight from the f32 clip (register-staged, rounded to the
+ * operand format as tad_im2col_tubelets rounds it), no patch matrix is written -- for forwards that keep nothing for a backward pass (eval,
+ * no_grad, inference); the training step uses tad_patch_embed_fwd, whose patch matrix the weight gradient reads again.  Bit-identical to
+ * tad_patch_embed_fwd.  patch must be 16 (TAD_EINVAL otherwise: callers fall back to the explicit form); clip and weight < 2 GiB each. */
+int tad_patch_embed_fwd_implicit(const float* x, const uint16_t* w_bf16, const float* bias, const float* pos,
+                                 float* out, int B, int C, int T, int H, int W, int tubelet, int patch, int D,
+                                 tad_stream_t stream);
 /* Input stage: the same patch matrix straight from uint8 frames [B,T,H,W,3] (decoder / cv2 layout) with the
  * reference's normalisation v = (u8/255 - mean[c]) / std[c] in f32 (run_inference.py:15-34 prepare_image; dota.py:443-460
  * tensor_normalize) -- bit-identical to tad_im2col_tubelets on the normalised f32 clip.  mean3 / std3: HOST arrays in RGB order;
@@ -396,6 +403,8 @@ int tad_im2col_tubelets_u8_f16(const uint8_t* frames, uint16_t* cols, int B, int
                                const float* mean3, const float* std3, int bgr, int t_offset, tad_stream_t stream);
 int tad_patch_embed_fwd_f16(const float* x, const uint16_t* w_f16, const float* bias, const float* pos, float* out, uint16_t* cols,
                             int B, int C, int T, int H, int W, int tubelet, int patch, int D, tad_stream_t stream);
+int tad_patch_embed_fwd_implicit_f16(const float* x, const uint16_t* w_f16, const float* bias, const float* pos, float* out, int B, int C,
+                                     int T, int H, int W, int tubelet, int patch, int D, tad_stream_t stream);
 int tad_patch_embed_gemm_f16(const uint16_t* cols, const uint16_t* w_f16, const float* bias, const float* pos, float* out, int64_t M,
                              int ntok, int D, int K, tad_stream_t stream);
 int tad_patch_embed_bwd_f16(const uint16_t* dy_f16, const uint16_t* cols, float* dW, float* db, void* ws, size_t ws_bytes, int64_t M,

@@ -22,6 +22,7 @@ SIGNATURES = {
     "tad_patch_embed_ldk": (_i, [_i, _i, _i]),
     "tad_im2col_tubelets": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "tad_patch_embed_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "tad_patch_embed_fwd_implicit": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "tad_im2col_tubelets_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, C.POINTER(_f), C.POINTER(_f), _i, _i, _vp]),
     "tad_patch_embed_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
     "tad_patch_embed_bwd_workspace_bytes": (_sz, [_i64, _i, _i]),
@@ -89,6 +90,7 @@ F16_TWINS = {
     "tad_scale_cast_bf16": "tad_scale_cast_f16", "tad_colsum_bf16": "tad_colsum_f16", "tad_split_bf16x3": "tad_split_f16x3",
     "tad_im2col_tubelets": "tad_im2col_tubelets_f16", "tad_im2col_tubelets_u8": "tad_im2col_tubelets_u8_f16",
     "tad_patch_embed_fwd": "tad_patch_embed_fwd_f16", "tad_patch_embed_gemm": "tad_patch_embed_gemm_f16",
+    "tad_patch_embed_fwd_implicit": "tad_patch_embed_fwd_implicit_f16",
     "tad_patch_embed_bwd": "tad_patch_embed_bwd_f16", "tad_layernorm_fwd": "tad_layernorm_fwd_f16",
     "tad_layernorm_bwd": "tad_layernorm_bwd_f16", "tad_linear_fwd": "tad_linear_fwd_f16", "tad_linear_fwd_qkv": "tad_linear_fwd_qkv_f16",
     "tad_linear_bwd_input": "tad_linear_bwd_input_f16", "tad_linear_bwd_weight": "tad_linear_bwd_weight_f16",

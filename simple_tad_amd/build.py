@@ -18,10 +18,10 @@ _LIB_NAME = os.environ.get("TAD_BUILD_LIB", "libtad_ablation.so" if _ABLATION el
 EXP_DIR = os.path.join(os.path.dirname(HERE), "build_exp")
 _PRODUCTION = _LIB_NAME == "libtad_mi355x.so"
 LIB = os.path.join(HERE if _PRODUCTION else EXP_DIR, os.path.basename(_LIB_NAME))
-SOURCES = ["capi.hip", "elementwise.hip", "layernorm.hip", "gemm.hip", "gemm_w4.hip", "attn_fwd.hip", "attn_bwd.hip", "attn_f32.hip", "precise.hip", "optim.hip", "mae.hip", "metrics.hip", "collective.hip"]
+SOURCES = ["capi.hip", "elementwise.hip", "patch_embed.hip", "layernorm.hip", "gemm.hip", "gemm_w4.hip", "attn_fwd.hip", "attn_bwd.hip", "attn_f32.hip", "precise.hip", "optim.hip", "mae.hip", "metrics.hip", "collective.hip"]
 # Sources that touch 16-bit GEMM / attention operands are compiled a second time with -DTAD_OPND_F16: the same kernels for IEEE half
 # operands, exported as tad_*_f16 (csrc/common.h, csrc/opnd_f16_names.h; include/tad_mi355x.h "IEEE half operand twins").
-F16_SOURCES = ["elementwise.hip", "layernorm.hip", "gemm.hip", "gemm_w4.hip", "attn_fwd.hip", "attn_bwd.hip", "optim.hip"]
+F16_SOURCES = ["elementwise.hip", "patch_embed.hip", "layernorm.hip", "gemm.hip", "gemm_w4.hip", "attn_fwd.hip", "attn_bwd.hip", "optim.hip"]
 # gemm_w4.hip (four waves of 128 x 128 outputs: 256 accumulator registers per lane) needs its accumulators in the AGPR half of the register
 # file: compiled without the vgpr-form switch below.  It includes gemm.hip for the kernel template.
 NO_VGPR_FORM = {"gemm_w4.hip"}

@@ -12,6 +12,7 @@
 #define tad_im2col_tubelets_u8 tad_im2col_tubelets_u8_f16
 #define tad_patch_embed_fwd tad_patch_embed_fwd_f16
 #define tad_patch_embed_gemm tad_patch_embed_gemm_f16
+#define tad_patch_embed_fwd_implicit tad_patch_embed_fwd_implicit_f16
 #define tad_patch_embed_bwd tad_patch_embed_bwd_f16
 #define tad_layernorm_fwd tad_layernorm_fwd_f16
 #define tad_layernorm_bwd tad_layernorm_bwd_f16

@@ -343,6 +343,30 @@ def patch_embed_fwd(x, w_bf16, bias, pos, tubelet: int, patch: int):
     return out, cols
 
 
+def patch_embed_fwd_implicit(x, w_bf16, bias, pos, tubelet: int, patch: int):
+    """the same forward without a patch matrix (tad_patch_embed_fwd_implicit: the x operand read straight from the f32 clip); for forwards that keep
+    nothing for a backward pass.  Returns out [B,N,D] f32, or None when the implicit kernel does not take the case (patch != 16, a clip of 2 GiB
+    and more): the caller then uses patch_embed_fwd"""
+    _req(x, torch.float32, "patch_embed.x")
+    op = _req16(w_bf16, "patch_embed.w")
+    B, Cc, T, H, W = x.shape
+    D, K = w_bf16.shape
+    if patch != 16 or K != Cc * tubelet * 256 or x.numel() * 4 >= (1 << 31) or D % 4 or T % tubelet or H % 16 or W % 16:
+        return None
+    ntok = (T // tubelet) * (H // patch) * (W // patch)
+    if pos is not None:
+        _req(pos, torch.float32, "patch_embed.pos")
+        if tuple(pos.shape) != (ntok, D):
+            raise _lib.TadError(f"patch_embed: pos_embed shape {tuple(pos.shape)} != {(ntok, D)}")
+    if bias is not None:
+        _req(bias, torch.float32, "patch_embed.bias")
+    out = torch.empty((B, ntok, D), dtype=torch.float32, device=x.device)
+    with _timed("patch_embed_fwd", 2.0 * B * ntok * D * K, 4.0 * x.numel() + 4.0 * B * ntok * D):
+        check(_fn("tad_patch_embed_fwd_implicit", op)(x.data_ptr(), w_bf16.data_ptr(), _p(bias), _p(pos), out.data_ptr(), B, Cc, T, H, W, tubelet, patch, D,
+                                                       _stream()), "tad_patch_embed_fwd_implicit")
+    return out
+
+
 # ----------------------------------------------------------------------------- layernorm
 def layernorm_fwd(x, gamma, beta, eps: float, out_dtype=None, save_stats=True):
     """out_dtype: torch.float32, or a 16-bit operand format (None = the process-wide one)"""

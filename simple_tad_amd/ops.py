@@ -323,6 +323,13 @@ class PatchEmbedFn(_Fn):
         # patch sizes whose K = C*tub*p*p is not a multiple of 64 (ViT-L/14: 1176): the patch matrix and the weight operand carry zero
         # columns up to tad_patch_embed_ldk (1216); a pure configuration change for the callers
         ldk = K.patch_embed_ldk(xc.shape[1], tubelet, patch)
+        if not _differentiated(ctx):
+            # nothing is kept for a backward pass (eval / no_grad / inference): the implicit GEMM reads the clip itself and
+            # writes no patch matrix; bit-identical to the explicit form below, which the training step needs for its weight gradient
+            out = K.patch_embed_fwd_implicit(xc, w_bf16(weight, False), _f32c(bias), _f32c(pos), tubelet, patch)
+            if out is not None:
+                ctx.params = (weight, bias)
+                return out
         out, cols = K.patch_embed_fwd(xc, K.pad_k(w_bf16(weight, _differentiated(ctx)), ldk), _f32c(bias), _f32c(pos), tubelet, patch)
         ctx.save_for_backward(cols)
         ctx.params = (weight, bias)

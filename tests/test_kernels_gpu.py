@@ -97,6 +97,56 @@ def test_patch_embed_fwd(K):
     assert torch.equal(cols.cpu().float().reshape(1, 8, 1536), O.im2col_tubelets(bf(x), 2, 16))
 
 
+@pytest.mark.parametrize("B,T,HW,D,bias,pos", [(1, 4, 32, 64, True, True), (2, 8, 224, 384, True, True), (3, 16, 224, 768, True, False), (5, 2, 48, 200, False, True),
+                                               (2, 16, 224, 1024, False, False)])
+@pytest.mark.parametrize("fmt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_patch_embed_implicit_gemm_is_bit_identical_to_the_explicit_route(K, B, T, HW, D, bias, pos, fmt):
+    """the forward that reads the clip itself (tad_patch_embed_fwd_implicit: no patch matrix) gives the bits of im2col + gemm_nt --
+    same rounding of x, same matrix instruction and k order, bias first, position row last -- at ragged row / column tiles (M = 5 * 9 tokens,
+    D = 200), the real ViT-S / ViT-B / ViT-L widths, with and without bias / pos_embed, in both operand formats; and it is what a no_grad
+    forward of the module runs"""
+    g = torch.Generator().manual_seed(B * 1000 + D)
+    x = torch.randn(B, 3, T, HW, HW, generator=g)
+    w = (torch.randn(D, 3 * 2 * 256, generator=g) * 0.02).to(fmt)
+    ntok = (T // 2) * (HW // 16) ** 2
+    bv = torch.randn(D, generator=g) if bias else None
+    pv = torch.randn(ntok, D, generator=g) if pos else None
+    K.set_operand_dtype(fmt)
+    try:
+        ref, _ = K.patch_embed_fwd(dev(x), dev(w), None if bv is None else dev(bv), None if pv is None else dev(pv), 2, 16)
+        got = K.patch_embed_fwd_implicit(dev(x), dev(w), None if bv is None else dev(bv), None if pv is None else dev(pv), 2, 16)
+    finally:
+        K.set_operand_dtype(torch.bfloat16)
+    assert got is not None and got.shape == ref.shape and torch.equal(got, ref)
+    # patch sizes the implicit kernel is not written for fall back (None), and the C entry point refuses them
+    assert K.patch_embed_fwd_implicit(dev(torch.randn(1, 3, 2, 28, 28)), dev(torch.zeros(8, 1216)).to(torch.bfloat16), None, None, 2, 14) is None
+
+
+def test_no_grad_forward_takes_the_implicit_patch_embedding():
+    import simple_tad_amd as T
+    from simple_tad_amd import kernels as KK
+    torch.manual_seed(0)
+    m = T.VisionTransformer(img_size=32, patch_size=16, embed_dim=128, depth=1, num_heads=2, all_frames=4, tubelet_size=2, num_classes=2, mlp_ratio=4,
+                            qkv_bias=True, init_scale=1.0).cuda()
+    x = torch.randn(2, 3, 4, 32, 32).cuda()
+    calls = {"implicit": 0, "explicit": 0}
+    imp, exp = KK.patch_embed_fwd_implicit, KK.patch_embed_fwd
+    KK.patch_embed_fwd_implicit = lambda *a, **k: (calls.__setitem__("implicit", calls["implicit"] + 1), imp(*a, **k))[1]
+    KK.patch_embed_fwd = lambda *a, **k: (calls.__setitem__("explicit", calls["explicit"] + 1), exp(*a, **k))[1]
+    try:
+        m.eval()
+        with torch.no_grad():
+            y0 = m(x)
+        assert calls == {"implicit": 1, "explicit": 0}
+        m.train()
+        y1 = m(x)
+        y1.sum().backward()
+        assert calls == {"implicit": 1, "explicit": 1} and m.patch_embed.proj.weight.grad is not None
+    finally:
+        KK.patch_embed_fwd_implicit, KK.patch_embed_fwd = imp, exp
+    torch.testing.assert_close(y0, y1.detach(), rtol=1e-6, atol=1e-6)  # (the patch embedding's bits are equal: test above; no dropout / drop-path in this model)
+
+
 # ------------------------------------------------------------------ layernorm
 @pytest.mark.parametrize("rows,D", [(150, 128), (37, 384), (1030, 768), (5, 1024), (9, 1280)])
 def test_layernorm_fwd_bwd(K, rows, D):

@@ -110,6 +110,8 @@ def main():
         bias = torch.zeros(D, device=dev)
         ms = timeit(lambda: K.patch_embed_fwd(xv, w, bias, pos, 2, 16), a.iters)
         rows.append(("patch_embed_fwd", ms, 2.0 * M * D * 1536 / ms / 1e9))
+        ms = timeit(lambda: K.patch_embed_fwd_implicit(xv, w, bias, pos, 2, 16), a.iters)
+        rows.append(("patch_embed_fwd_implicit (no patch matrix; eval / no_grad)", ms, 2.0 * M * D * 1536 / ms / 1e9))
         ms = timeit(lambda: K.im2col_tubelets(xv, 2, 16), a.iters)
         rows.append((f"  im2col alone ({(4.0 * xv.numel() + 2.0 * M * 1536) / ms / 1e6:.0f} GB/s)", ms, 0.0))
         fr = torch.randint(0, 256, (B, 16, 224, 224, 3), dtype=torch.uint8, device=dev)
