@@ -313,6 +313,12 @@ class LayerNormFn(_Fn):
 
 
 # --------------------------------------------------------------------------- PatchEmbed (+ pos_embed)
+# The implicit patch embedding (tad_patch_embed_fwd_implicit) is taken by forwards without a backward pass once the problem fills the chip: measured
+# (tools/bench_kernels.py --only patch, us, explicit / implicit): 32 clips D = 768 264 / 245, D = 384 193 / 152, ONE clip (78 tiles of 128 x 128 on 256
+# CUs, 24 dependent K-tiles each) 23 / 33 -- below two tiles per CU the im2col + GEMM pair is faster
+IMPLICIT_PATCH_EMBED_MIN_TILES = 512
+
+
 class PatchEmbedFn(_Fn):
     """Conv3d(k=s=(tub,p,p)) + flatten/transpose (+ sinusoid pos_embed) (modeling_finetune.py:181-190, 312-313)."""
 
@@ -323,7 +329,8 @@ class PatchEmbedFn(_Fn):
         # patch sizes whose K = C*tub*p*p is not a multiple of 64 (ViT-L/14: 1176): the patch matrix and the weight operand carry zero
         # columns up to tad_patch_embed_ldk (1216); a pure configuration change for the callers
         ldk = K.patch_embed_ldk(xc.shape[1], tubelet, patch)
-        if not _differentiated(ctx):
+        ntok_ = (xc.shape[2] // tubelet) * (xc.shape[3] // patch) * (xc.shape[4] // patch)
+        if not _differentiated(ctx) and -(-xc.shape[0] * ntok_ // 128) * -(-weight.shape[0] // 128) >= IMPLICIT_PATCH_EMBED_MIN_TILES:
             # nothing is kept for a backward pass (eval / no_grad / inference): the implicit GEMM reads the clip itself and
             # writes no patch matrix; bit-identical to the explicit form below, which the training step needs for its weight gradient
             out = K.patch_embed_fwd_implicit(xc, w_bf16(weight, False), _f32c(bias), _f32c(pos), tubelet, patch)

@@ -129,8 +129,10 @@ def test_no_grad_forward_takes_the_implicit_patch_embedding():
     m = T.VisionTransformer(img_size=32, patch_size=16, embed_dim=128, depth=1, num_heads=2, all_frames=4, tubelet_size=2, num_classes=2, mlp_ratio=4,
                             qkv_bias=True, init_scale=1.0).cuda()
     x = torch.randn(2, 3, 4, 32, 32).cuda()
+    from simple_tad_amd import ops as OPS
     calls = {"implicit": 0, "explicit": 0}
-    imp, exp = KK.patch_embed_fwd_implicit, KK.patch_embed_fwd
+    imp, exp, min_tiles = KK.patch_embed_fwd_implicit, KK.patch_embed_fwd, OPS.IMPLICIT_PATCH_EMBED_MIN_TILES
+    OPS.IMPLICIT_PATCH_EMBED_MIN_TILES = 0  # (this tiny model is far below the size from which the implicit route is the faster one)
     KK.patch_embed_fwd_implicit = lambda *a, **k: (calls.__setitem__("implicit", calls["implicit"] + 1), imp(*a, **k))[1]
     KK.patch_embed_fwd = lambda *a, **k: (calls.__setitem__("explicit", calls["explicit"] + 1), exp(*a, **k))[1]
     try:
@@ -144,6 +146,7 @@ def test_no_grad_forward_takes_the_implicit_patch_embedding():
         assert calls == {"implicit": 1, "explicit": 1} and m.patch_embed.proj.weight.grad is not None
     finally:
         KK.patch_embed_fwd_implicit, KK.patch_embed_fwd = imp, exp
+        OPS.IMPLICIT_PATCH_EMBED_MIN_TILES = min_tiles
     torch.testing.assert_close(y0, y1.detach(), rtol=1e-6, atol=1e-6)  # (the patch embedding's bits are equal: test above; no dropout / drop-path in this model)
 
 
