@@ -108,11 +108,11 @@ class PowerSampler:
     Why it is in the bench line: every MFMA kernel of the step runs AT the board's power cap, so the cap, not the
     matrix pipe's nominal rate, is what bounds the step -- the line carries the evidence with every run."""
 
-    def __init__(self, period=0.05):
+    def __init__(self, period=0.05, sysfs_root="/sys"):
         import glob
         self.period, self.samples, self._stop, self._th = period, [], None, None
         self.cards = []
-        for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+        for d in sorted(glob.glob(os.path.join(sysfs_root, "class/drm/card*/device/hwmon/hwmon*"))):
             p = next((os.path.join(d, f) for f in ("power1_average", "power1_input") if os.path.exists(os.path.join(d, f))), None)
             if p:
                 self.cards.append((d, p))

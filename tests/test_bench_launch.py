@@ -64,3 +64,29 @@ def test_rccl_summary_reads_the_debug_lines(tmp_path):
     assert s["channels"] == 2 and s["transports"] == ["P2P/IPC"] and s["peers_of_rank0"] == [1, 7]
     assert s["transport_of_rank0"] == "xGMI peer-to-peer" and any("RCCL version" in ln for ln in s["lines"])
     assert "not collected" in bench.rccl_summary(None)["debug_lines"]
+
+
+def test_power_sampler_reads_hwmon_and_picks_the_loaded_card(tmp_path):
+    """bench.py's `power` object: board power / cap / shader clock from the amdgpu hwmon files, the card under load = the one with the highest
+    mean power (the container sees every card of the host), joules per step = mean power x step time; no card readable -> an error entry, not
+    an exception"""
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    for i, (uw, cap, hz) in enumerate(((250_000_000, 1_400_000_000, 97_000_000), (1_395_000_000, 1_400_000_000, 2_135_000_000))):
+        d = tmp_path / f"class/drm/card{i}/device/hwmon/hwmon{i}"
+        d.mkdir(parents=True)
+        (d / "power1_average").write_text(str(uw))
+        (d / "power1_cap").write_text(str(cap))
+        (d / "freq1_input").write_text(str(hz))
+    ps = bench.PowerSampler(period=0.01, sysfs_root=str(tmp_path)).start()
+    time.sleep(0.08)
+    per = ps.stop()
+    assert len(per) == 2 and per[0]["mean_w"] == 250.0 and per[1]["mean_w"] == 1395.0 and per[1]["n"] >= 3
+    out = ps.summary(per, seconds_per_step=0.0422)
+    assert out["mean_w"] == 1395.0 and out["cap_w"] == 1400.0 and out["frac_of_cap"] == 0.9964 and out["mean_sclk_mhz"] == 2135
+    assert out["joules_per_step"] == round(1395.0 * 0.0422, 2) and "index 1" in out["source"]
+    empty = bench.PowerSampler(sysfs_root=str(tmp_path / "nothing")).start()
+    assert "error" in empty.summary(empty.stop())
+    share = bench.host_cpu_share()
+    assert share["os_cpu_count"] >= share["usable"] >= 1
