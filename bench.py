@@ -741,6 +741,9 @@ def main():
             pw["reading"] = ("the whole training step draws this share of the board's power cap: the cap, not the matrix pipe's nominal rate, bounds every MFMA "
                              "kernel of the step (DESIGN.md section 3a; per kernel class: tools/power_probe.py -> profiles/r06_power.txt)")
             out["power"] = pw
+            if isinstance(out.get("roofline"), dict) and pw.get("frac_of_cap"):
+                # the nominal-peak fraction above is measured on a board that runs this kernel (and the whole step) at its power cap: DESIGN.md section 3a
+                out["roofline"]["board_power_frac_of_cap_during_step"] = pw["frac_of_cap"]
         except Exception as e:  # noqa: BLE001
             out["power"] = {"error": repr(e), "timed_region": out.get("power")}
 
