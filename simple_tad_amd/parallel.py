@@ -344,7 +344,8 @@ class DataParallel(nn.Module):
         mean = lambda v: (sum(v) / len(v)) if v else None  # noqa: E731
         return {"steps": len(steps), "exposed_ms": round(mean(exposed), 4), "exposed_ms_max": round(max(exposed), 4),
                 "bucket_ms": [None if not v else round(mean(v), 4) for v in per_bucket],
-                "bucket_mbytes": [round((b["hi"] - b["lo"]) * self.flat_grad.element_size() / 2 ** 20, 1) for b in self.buckets],
+                # (bytes on the wire: two per element with bf16 buckets)
+                "bucket_mbytes": [round((b["hi"] - b["lo"]) * (2 if self.bucket_dtype == "bf16" else self.flat_grad.element_size()) / 2 ** 20, 1) for b in self.buckets],
                 "late_buckets_per_step": round(mean(late), 2), "overlap": self.overlap, "avg_in_collective": self._avg_in_collective,
                 "bucket_dtype": self.bucket_dtype}
 

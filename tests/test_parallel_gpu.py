@@ -97,7 +97,7 @@ def test_bench_self_launch_two_gpus_over_rccl():
     assert out["config"]["global_batch"] == 16 and out["value"] > 0 and out["scaling"] == "weak"
 
 
-@pytest.mark.parametrize("extra,gb,scaling", [([], 8, "weak"), (["--global-batch", "8"], 8, "strong")])
+@pytest.mark.parametrize("extra,gb,scaling", [([], 8, "weak"), (["--global-batch", "8"], 8, "strong"), (["--bucket-dtype", "bf16"], 8, "weak")])
 def test_bench_two_ranks_over_gloo_on_one_gpu_reports_the_exchange(extra, gb, scaling):
     """The N > 1 path of bench.py end to end on ONE GPU (two ranks share it, gradients travel over gloo): one rank-0 JSON line with
     n_gpus = 2 and a `collective` object that says how the exchange went -- exposed all-reduce time, per-bucket time, per-rank step
@@ -122,6 +122,8 @@ def test_bench_two_ranks_over_gloo_on_one_gpu_reports_the_exchange(extra, gb, sc
     assert all(v is not None and v > 0 for v in c["bucket_ms"]) and c["exposed_ms"] > 0 and c["late_buckets_per_step"] == 0
     assert len(c["rank_ms_per_step"]["all"]) == 2 and c["rank_ms_per_step"]["min"] <= c["rank_ms_per_step"]["max"] <= out["ms_per_step"] * 1.05
     assert "per-tile" in c["linear_schedule"] and c["avg_in_collective"] is False
+    assert c["bucket_dtype"] == ("bf16" if "bf16" in extra else "f32") and "version" in c["rccl"] or "version_error" in c["rccl"]
+    assert c["allreduce_bytes_per_step"] == (2 if "bf16" in extra else 4) * (c["allreduce_bytes_per_step"] // (2 if "bf16" in extra else 4))
 
 
 def _two_rank_step(backend):
